@@ -1,0 +1,367 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+CPU restatement (torch CPU fp32, optionally fp64) of the reference's per-crop forward hot path:
+
+  * plain HRNet           /root/reference/lib/models/pose_hrnet.py:428-463
+  * RSGNet                /root/reference/lib/models/pose_rsgnet.py:921-1021
+  * TRP (SpatialRelationHead) /root/reference/lib/models/association.py:280-301
+  * SGM (KTMachine)       /root/reference/lib/models/pose_rsgnet.py:576-600
+
+It is a *functional* restatement: it takes a reference-named ``state_dict`` (a mapping name -> tensor)
+plus the cfg and walks the graph with ``torch.nn.functional`` primitives.  The arithmetic itself lives
+in PyTorch's CPU operators (third-party; version used here: torch 2.10.0) exactly as it does for the
+reference.
+
+Parity pin: the reference holds no golden vectors or tests for this path.  This oracle is
+pinned by fixtures under ``tests/golden/`` that ``oracle/make_goldens.py`` produced by importing the
+reference's own ``lib/models`` in the build container and running it on CPU; ``tests/test_oracle.py``
+re-checks this file against those fixtures (≤1e-5 max-abs).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The product path (``rsgnet_amd``) never does.
+
+Two extra modes exist purely for testing:
+  * ``calibrate=True``  — every BatchNorm takes its statistics from the current batch and writes them
+    back into the state dict as running stats (what ``model.train()`` with ``momentum=1`` does in the
+    reference: normalise with the biased batch variance, store the unbiased one).
+    ``make_goldens.py`` uses it to give the synthetic weights realistic, non-identity BN statistics.
+  * ``emulate='fp16'|'bf16'`` — rounds activations and BN-folded weights where the HIP path stores
+    them in 16 bits (accumulation stays fp32), to predict the HIP path's error on CPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Mapping, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5  # nn.BatchNorm2d / nn.GroupNorm default, pose_rsgnet.py:31, association.py:244
+
+# pose_rsgnet.py:523-555 — KTMachine always uses the 14 CrowdPose names / 14 limb rules
+_KPT_NAMES = ("left_shoulder", "right_shoulder", "left_elbow", "right_elbow", "left_wrist",
+              "right_wrist", "left_hip", "right_hip", "left_knee", "right_knee", "left_ankle",
+              "right_ankle", "head", "neck")
+_LIMB_RULES = (("head", "neck"), ("right_shoulder", "neck"), ("left_shoulder", "neck"),
+               ("left_shoulder", "left_elbow"), ("right_shoulder", "right_elbow"),
+               ("left_elbow", "left_wrist"), ("right_elbow", "right_wrist"),
+               ("left_hip", "right_hip"), ("left_hip", "left_knee"), ("right_hip", "right_knee"),
+               ("left_knee", "left_ankle"), ("right_knee", "right_ankle"),
+               ("left_shoulder", "left_hip"), ("right_shoulder", "right_hip"))
+
+
+def limb_prior(num_limbs: int, num_joints: int) -> np.ndarray:
+    """pose_rsgnet.py:558-573 — binary limb x joint prior (rows beyond 14 stay zero)."""
+    idx = {n: i for i, n in enumerate(_KPT_NAMES)}
+    m = np.zeros((num_limbs, num_joints), dtype=np.float32)
+    for i, (a, b) in enumerate(_LIMB_RULES):
+        m[i, idx[a]] = 1
+        m[i, idx[b]] = 1
+    return m
+
+
+def geometry_embeddings(image_wh) -> np.ndarray:
+    """pose_rsgnet.py:800-815 — the constant 4-channel location map [1,4,H/4,W/4]."""
+    w, h = int(image_wh[0] / 4), int(image_wh[1] / 4)
+    xs = np.arange(w, dtype=np.float32)
+    ys = np.arange(h, dtype=np.float32)
+    m = np.zeros((4, h, w))
+    m[0] += (xs / w)[None, :]
+    m[1] += (ys / h)[:, None]
+    m[2] += (xs - w / 2.0)[None, :]
+    m[3] += (ys - h / 2.0)[:, None]
+    return m[None].astype(np.float32)
+
+
+class Ctx:
+    """Walk state: the weights, the mode switches and a few taps for block-level tests."""
+
+    def __init__(self, sd: Mapping[str, torch.Tensor], dtype=torch.float32, calibrate=False,
+                 emulate: Optional[str] = None):
+        self.sd: Dict[str, torch.Tensor] = sd if calibrate else dict(sd)
+        self.dtype = dtype
+        self.calibrate = calibrate
+        self.emu = {None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[emulate]
+        self.taps: Dict[str, torch.Tensor] = {}
+
+    def p(self, name: str) -> torch.Tensor:
+        return self.sd[name].to(self.dtype)
+
+    def has(self, name: str) -> bool:
+        return name in self.sd
+
+    def store(self, x: torch.Tensor) -> torch.Tensor:
+        """Where the HIP path writes an activation in 16 bits."""
+        if self.emu is None:
+            return x
+        return x.to(self.emu).to(self.dtype)
+
+
+def _bn_coeffs(ctx: Ctx, name: str, x: Optional[torch.Tensor]):
+    """(scale, shift) of an eval-mode BatchNorm; in calibrate mode first set the running stats."""
+    if ctx.calibrate:
+        dims = [d for d in range(x.dim()) if d != 1]
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=dims)
+        var_b = x.var(dim=dims, unbiased=False)
+        ctx.sd[name + ".running_mean"] = mean.to(torch.float32)
+        ctx.sd[name + ".running_var"] = (var_b * (n / max(n - 1, 1))).to(torch.float32)
+        inv = torch.rsqrt(var_b + BN_EPS)  # training normalises with the biased variance
+    else:
+        mean = ctx.p(name + ".running_mean")
+        inv = torch.rsqrt(ctx.p(name + ".running_var") + BN_EPS)
+    scale = ctx.p(name + ".weight") * inv
+    shift = ctx.p(name + ".bias") - mean * scale
+    return scale, shift
+
+
+def conv_unit(ctx: Ctx, x, conv: str, bn: Optional[str] = None, *, stride=1, relu=False,
+              residual=None, transposed=False):
+    """conv (+bias) -> [BatchNorm] -> [+residual] -> [ReLU]: the unit the HIP path fuses.
+
+    Exact mode does the four steps as the reference does (separate ops, fp32).  Emulation mode folds
+    the BN scale into the weight, rounds weight and output to 16 bits and keeps the bias in fp32,
+    which is what the HIP kernels compute.
+    """
+    w = ctx.p(conv + ".weight")
+    b = ctx.p(conv + ".bias") if ctx.has(conv + ".bias") else None
+    k = w.shape[-1]
+    pad = (k - 1) // 2 if not transposed else 1
+
+    def run(xx, ww, bb):
+        if transposed:  # ConvTranspose2d(k=4, s=2, p=1, op=0), pose_rsgnet.py:727-734
+            return F.conv_transpose2d(xx, ww, bb, stride=2, padding=pad)
+        return F.conv2d(xx, ww, bb, stride=stride, padding=pad)
+
+    if ctx.emu is None or ctx.calibrate:
+        y = run(x, w, b)
+        if bn is not None:
+            s, t = _bn_coeffs(ctx, bn, y)
+            y = y * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+    if bn is not None:
+        s, t = _bn_coeffs(ctx, bn, None)
+    else:
+        s, t = torch.ones(w.shape[1 if transposed else 0], dtype=ctx.dtype), 0.0
+    shape = (1, -1, 1, 1) if transposed else (-1, 1, 1, 1)
+    wq = (w * s.view(shape)).to(ctx.emu).to(ctx.dtype)
+    bias = t if b is None else (b * s + t)
+    y = run(x, wq, None) + (bias.view(1, -1, 1, 1) if torch.is_tensor(bias) else bias)
+    if residual is not None:
+        y = y + residual
+    if relu:
+        y = F.relu(y)
+    return ctx.store(y)
+
+
+# ------------------------------------------------------------------------------------------------
+# backbone (shared by pose_hrnet.py and pose_rsgnet.py — the reference duplicates the code)
+# ------------------------------------------------------------------------------------------------
+
+def bottleneck(ctx: Ctx, x, pre: str):
+    """pose_rsgnet.py:57-95."""
+    res = x
+    if ctx.has(pre + ".downsample.0.weight"):
+        res = conv_unit(ctx, x, pre + ".downsample.0", pre + ".downsample.1")
+    y = conv_unit(ctx, x, pre + ".conv1", pre + ".bn1", relu=True)
+    y = conv_unit(ctx, y, pre + ".conv2", pre + ".bn2", relu=True)
+    return conv_unit(ctx, y, pre + ".conv3", pre + ".bn3", relu=True, residual=res)
+
+
+def basic_block(ctx: Ctx, x, pre: str):
+    """pose_rsgnet.py:25-54 (HRNet branches never carry a downsample)."""
+    y = conv_unit(ctx, x, pre + ".conv1", pre + ".bn1", relu=True)
+    return conv_unit(ctx, y, pre + ".conv2", pre + ".bn2", relu=True, residual=x)
+
+
+def hr_module(ctx: Ctx, xs: List[torch.Tensor], pre: str, n_out: int):
+    """HighResolutionModule.forward, pose_rsgnet.py:254-272; fuse layers :194-249."""
+    nb = len(xs)
+    xs = list(xs)
+    for b in range(nb):
+        k = 0
+        while ctx.has(f"{pre}.branches.{b}.{k}.conv1.weight"):
+            xs[b] = basic_block(ctx, xs[b], f"{pre}.branches.{b}.{k}")
+            k += 1
+    if nb == 1:
+        return xs
+    outs = []
+    for i in range(n_out):
+        y = None
+        for j in range(nb):
+            fl = f"{pre}.fuse_layers.{i}.{j}"
+            if j == i:
+                t = xs[j]
+            elif j > i:  # 1x1 + BN then nearest upsample by 2^(j-i)
+                t = conv_unit(ctx, xs[j], fl + ".0", fl + ".1")
+                t = F.interpolate(t, scale_factor=2 ** (j - i), mode="nearest")
+            else:  # (i-j) strided 3x3; ReLU on all but the last
+                t = xs[j]
+                for k in range(i - j):
+                    t = conv_unit(ctx, t, f"{fl}.{k}.0", f"{fl}.{k}.1", stride=2,
+                                  relu=(k != i - j - 1))
+            y = t if y is None else y + t
+        outs.append(ctx.store(F.relu(y)))
+    return outs
+
+
+def _count(ctx: Ctx, fmt: str) -> int:
+    n = 0
+    while ctx.has(fmt.format(n)):
+        n += 1
+    return n
+
+
+def backbone(ctx: Ctx, x, cfg) -> List[torch.Tensor]:
+    """_forward_visual_encoder, pose_rsgnet.py:921-953 == pose_hrnet.py:429-459."""
+    extra = cfg["MODEL"]["EXTRA"]
+    x = ctx.store(x.to(ctx.dtype))
+    x = conv_unit(ctx, x, "conv1", "bn1", stride=2, relu=True)
+    x = conv_unit(ctx, x, "conv2", "bn2", stride=2, relu=True)
+    ctx.taps["stem"] = x
+    for k in range(4):
+        x = bottleneck(ctx, x, f"layer1.{k}")
+    ctx.taps["layer1"] = x
+
+    ys = [x]
+    for sidx in (2, 3, 4):
+        scfg = extra[f"STAGE{sidx}"]
+        nb = scfg["NUM_BRANCHES"]
+        tr = f"transition{sidx - 1}"
+        xs = []
+        for i in range(nb):
+            if i < len(ys):
+                if ctx.has(f"{tr}.{i}.0.weight"):
+                    xs.append(conv_unit(ctx, ys[i], f"{tr}.{i}.0", f"{tr}.{i}.1", relu=True))
+                else:
+                    xs.append(ys[i])
+            else:  # new branch: strided conv(s) from the lowest-resolution map, :938-951
+                t = ys[-1]
+                for j in range(_count(ctx, tr + f".{i}." + "{}.0.weight")):
+                    t = conv_unit(ctx, t, f"{tr}.{i}.{j}.0", f"{tr}.{i}.{j}.1", stride=2, relu=True)
+                xs.append(t)
+        nmod = scfg["NUM_MODULES"]
+        for m in range(nmod):
+            last = sidx == 4 and m == nmod - 1  # multi_scale_output=False, :899-904
+            xs = hr_module(ctx, xs, f"stage{sidx}.{m}", 1 if last else nb)
+        ys = xs
+        ctx.taps[f"stage{sidx}"] = ys[0]
+    return ys
+
+
+def hrnet_forward(sd, cfg, x, **kw) -> torch.Tensor:
+    """pose_hrnet.PoseHighResolutionNet.forward, pose_hrnet.py:428-463 -> [B,J,H/4,W/4]."""
+    ctx = kw.pop("ctx", None) or Ctx(sd, **kw)
+    with torch.no_grad():
+        ys = backbone(ctx, x, cfg)
+        w, b = ctx.p("final_layer.weight"), ctx.p("final_layer.bias")
+        if ctx.emu is not None:
+            w = w.to(ctx.emu).to(ctx.dtype)
+        return F.conv2d(ys[0], w, b, padding=(w.shape[-1] - 1) // 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# RSGNet head
+# ------------------------------------------------------------------------------------------------
+
+def type_templates(ctx: Ctx) -> torch.Tensor:
+    """type_fc(type_features): Linear(no bias) -> BatchNorm1d -> ReLU on [J,T], pose_rsgnet.py:679-683,972."""
+    t = ctx.p("type_features") @ ctx.p("type_fc.0.weight").t()
+    s, sh = _bn_coeffs(ctx, "type_fc.1", t)
+    return F.relu(t * s + sh)
+
+
+def kt_machine(ctx: Ctx, wk: torch.Tensor) -> torch.Tensor:
+    """KTMachine.forward, pose_rsgnet.py:592-600: joint classifier weights -> limb classifier weights."""
+    n_out, n_in, h, w = wk.shape
+    k = ctx.p("kt_machine.matrix_limb") * ctx.p("kt_machine.real_matrix_limb")
+    t = k @ wk.reshape(n_out, n_in * h * w)
+    t = F.linear(t, ctx.p("kt_machine.kpt_transformer.0.weight"), ctx.p("kt_machine.kpt_transformer.0.bias"))
+    t = F.leaky_relu(t, 0.02)
+    t = F.linear(t, ctx.p("kt_machine.kpt_transformer.2.weight"), ctx.p("kt_machine.kpt_transformer.2.bias"))
+    return t.reshape(t.shape[0], n_in, h, w)
+
+
+def relation_head(ctx: Ctx, x, want_scores=True):
+    """SpatialRelationHead.forward (sub_sample=False), association.py:280-301.
+
+    Returns (relation_embs [B,C,H,W], relation_score [B,S,S] or None).  theta = phi = x (no
+    projection), attention is an un-normalised sigmoid of the Gram matrix.
+    """
+    b, c, h, w = x.shape
+    g = F.conv2d(x, ctx.p("relation_head.g.weight"), ctx.p("relation_head.g.bias"))
+    g = g.view(b, c, -1).permute(0, 2, 1)                      # [B,S,C]
+    xf = x.view(b, c, -1)                                       # [B,C,S]
+    embs = torch.empty(b, h * w, c, dtype=x.dtype)
+    scores = torch.empty(b, h * w, h * w, dtype=x.dtype) if want_scores else None
+    for i in range(b):                                          # per crop: keeps the S*S map small
+        r = torch.sigmoid(xf[i].t() @ xf[i])
+        embs[i] = r @ g[i]
+        if want_scores:
+            scores[i] = r
+    e = embs.permute(0, 2, 1).contiguous().view(b, c, h, w)
+    ctx.taps["relation_embs_raw"] = e
+    e = F.conv2d(e, ctx.p("relation_head.W.0.weight"), ctx.p("relation_head.W.0.bias"))
+    e = F.group_norm(e, 8, ctx.p("relation_head.W.1.weight"), ctx.p("relation_head.W.1.bias"), BN_EPS)
+    return ctx.store(e), scores
+
+
+def rsgnet_forward(sd, cfg, x, relation_target=None, want_scores=True, **kw):
+    """RSGNet.forward, pose_rsgnet.py:955-1021.
+
+    Returns (multi_kpt_scores, kpt_scores, limbs_scores, relation_scores) like the reference;
+    relation_scores is [B,S,S], or [B] when ``relation_target`` is given, or None when
+    ``want_scores=False`` (a test convenience: the 37.7 MB/crop map is the one thing the HIP path
+    never materialises unless asked).
+    """
+    ctx = kw.pop("ctx", None) or Ctx(sd, **kw)
+    model = cfg["MODEL"]
+    with torch.no_grad():
+        vis = backbone(ctx, x, cfg)[0]
+        ctx.taps["vis"] = vis
+        wm, bm = ctx.p("multi_final_layer.weight"), ctx.p("multi_final_layer.bias")
+        if ctx.emu is not None:
+            wm = wm.to(ctx.emu).to(ctx.dtype)
+        multi = F.conv2d(vis, wm, bm)                                            # :961
+        vis = conv_unit(ctx, vis, "vis_conv.0", "vis_conv.1", relu=True)          # :965
+        b, j, h, w = multi.shape
+        tm = type_templates(ctx)                                                  # [J,T] :971-972
+        if ctx.emu is None or ctx.calibrate:
+            tmap = (multi.reshape(b, j, h * w).permute(0, 2, 1) @ tm)             # [B,S,T] :974
+            tmap = tmap.permute(0, 2, 1).reshape(b, tm.shape[1], h, w)
+            typ = conv_unit(ctx, tmap, "type_conv.0", "type_conv.1", relu=True)   # :977
+        else:
+            # the HIP path's exact fold: a 3x3 conv J->C0 with W'[o,j] = sum_c W[o,c] Tm[j,c]
+            s, t = _bn_coeffs(ctx, "type_conv.1", None)
+            wf = torch.einsum("ocyx,jc->ojyx", ctx.p("type_conv.0.weight"), tm) * s.view(-1, 1, 1, 1)
+            typ = F.conv2d(ctx.store(multi), wf.to(ctx.emu).to(ctx.dtype), None, padding=1)
+            typ = ctx.store(F.relu(typ + t.view(1, -1, 1, 1)))
+        loc = conv_unit(ctx, ctx.p("loc_features"), "loc_conv.0", "loc_conv.1", relu=True)  # :979
+        f = torch.cat((vis, typ, loc.repeat(b, 1, 1, 1)), dim=1)                  # :982
+        f = conv_unit(ctx, f, "contact_conv.0", "contact_conv.1", relu=True)
+        f = conv_unit(ctx, f, "predict_contact_net.0", "predict_contact_net.1", relu=True)
+        ctx.taps["final_vis"] = f
+        rel, scores = relation_head(ctx, f, want_scores or relation_target is not None)   # :987
+        ctx.taps["relation_feats"] = rel
+        k = conv_unit(ctx, torch.cat((rel, f), dim=1), "kpt_net.0", "kpt_net.1", relu=True)  # :991-992
+        if model["UP_SCALE"] > 1:
+            k = conv_unit(ctx, k, "predict_convtranspose.0", "predict_convtranspose.1", relu=True,
+                          transposed=True)                                        # :994
+        k = conv_unit(ctx, k, "predict_net.0", "predict_net.1", relu=True)        # :999
+        wf_, bf_ = ctx.p("final_layer.weight"), ctx.p("final_layer.bias")
+        kpt = F.conv2d(k, wf_.to(ctx.emu).to(ctx.dtype) if ctx.emu is not None else wf_, bf_)  # :1000
+        lf = conv_unit(ctx, f, "limbs_net.0", "limbs_net.1", relu=True)           # :1003
+        wl = kt_machine(ctx, ctx.p("final_layer.weight"))                         # :1004
+        ctx.taps["limb_weights"] = wl
+        limbs = F.conv2d(lf, wl.to(ctx.emu).to(ctx.dtype) if ctx.emu is not None else wl)  # :1005
+        if model["UP_SCALE"] > 1:                                                 # :1008-1012
+            multi = F.interpolate(multi, scale_factor=2, mode="bilinear", align_corners=True)
+            limbs = F.interpolate(limbs, scale_factor=2, mode="bilinear", align_corners=True)
+        limbs = torch.sigmoid(limbs)                                              # :1013
+        if relation_target is not None:                                           # :1014-1018
+            scores = ((relation_target.to(ctx.dtype) - scores) ** 2).mean(dim=(1, 2))
+        return multi, kpt, limbs, scores

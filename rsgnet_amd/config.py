@@ -1,0 +1,111 @@
+"""Config surface of the drop-in boundary.
+
+The reference reads its yacs ``cfg`` with BOTH attribute access (``cfg.MODEL.EXTRA``,
+/root/reference/lib/models/pose_rsgnet.py:607) and item access (``cfg['MODEL']['EXTRA']['STAGE2']``,
+pose_rsgnet.py:621).  yacs is not a dependency here: :class:`Cfg` is a plain ``dict`` subclass that
+offers both, and :func:`as_cfg` wraps whatever the caller hands to ``get_pose_net`` (a yacs CfgNode,
+a nested dict loaded from one of the reference's experiment yamls, or a :class:`Cfg`).
+
+Defaults mirror /root/reference/lib/config/default.py:36-62 for the keys the hot path reads.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Mapping, Sequence
+
+
+class Cfg(dict):
+    """dict with attribute access; nested mappings are wrapped on the way in."""
+
+    def __init__(self, *a, **kw):
+        super().__init__()
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, _wrap(v))
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:  # same failure mode as yacs
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return Cfg({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+def _wrap(v: Any) -> Any:
+    if isinstance(v, Cfg):
+        return v
+    if isinstance(v, Mapping):
+        return Cfg(v)
+    if isinstance(v, (list, tuple)):
+        return type(v)(_wrap(x) for x in v)
+    return v
+
+
+# lib/config/default.py:36-62 (only what lib/models reads)
+_MODEL_DEFAULTS = dict(
+    NAME="pose_hrnet", INIT_WEIGHTS=True, PRETRAINED="", NUM_JOINTS=17, NUM_LIMBS=18,
+    IMAGE_SIZE=[256, 256], HEATMAP_SIZE=[64, 64], UP_SCALE=1, FINAL_DECONV_KERNEL_SIZE=4,
+    NUM_TYPE_VECTOR=256, UDP_POSE_ON=False, RELATION_SUB_SAMPLE=False,
+)
+
+
+def as_cfg(cfg: Any) -> Cfg:
+    """Normalise a yacs node / nested dict / Cfg into a Cfg with the model defaults filled in."""
+    if not isinstance(cfg, Mapping):
+        raise TypeError("cfg must be a mapping (yacs CfgNode, dict or rsgnet_amd.config.Cfg)")
+    out = Cfg(copy.deepcopy(dict(cfg)))
+    if "MODEL" not in out:
+        raise KeyError("cfg.MODEL is required")
+    for k, v in _MODEL_DEFAULTS.items():
+        out.MODEL.setdefault(k, copy.deepcopy(v))
+    ntv = out.MODEL.NUM_TYPE_VECTOR
+    if isinstance(ntv, Sequence) and not isinstance(ntv, (str, bytes)):
+        # experiments/coco/hrnet/rsgnet_w48_*.yaml:34-35 give a one-element list where an int is
+        # meant (SURVEY §0 defect 4); accept it instead of failing in nn.Linear.
+        if len(ntv) != 1:
+            raise ValueError("MODEL.NUM_TYPE_VECTOR must be an int")
+        out.MODEL["NUM_TYPE_VECTOR"] = int(ntv[0])
+    return out
+
+
+def _stage(nmod: int, chans: Sequence[int]) -> dict:
+    nb = len(chans)
+    return dict(NUM_MODULES=nmod, NUM_BRANCHES=nb, BLOCK="BASIC", NUM_BLOCKS=[4] * nb,
+                NUM_CHANNELS=list(chans), FUSE_METHOD="SUM")
+
+
+_BACKBONE = ["conv1", "bn1", "conv2", "bn2", "layer1", "transition1", "stage2", "transition2",
+             "stage3", "transition3", "stage4"]
+
+
+def make_cfg(name: str = "pose_hrnet", width: int = 32, image_wh: Sequence[int] = (192, 256),
+             num_joints: int = 17, num_limbs: int | None = None) -> Cfg:
+    """The MODEL section of the reference's experiment yamls, built in code.
+
+    ``make_cfg('pose_hrnet', 32)`` == experiments/coco/hrnet/w32_256x192_adam_lr1e-3.yaml:25-85,
+    ``make_cfg('pose_rsgnet', 32)`` == experiments/coco/hrnet/rsgnet_w32_256x192_adam_lr1e-3.yaml:26-105,
+    ``make_cfg('pose_rsgnet', 32, num_joints=14)`` == the CrowdPose yaml (NUM_LIMBS 14),
+    ``make_cfg('pose_rsgnet', 48, (288, 384))`` == rsgnet_w48_384x288 with NUM_TYPE_VECTOR as an int.
+    """
+    w = int(width)
+    chans = [w, 2 * w, 4 * w, 8 * w]
+    extra = dict(PRETRAINED_LAYERS=list(_BACKBONE), FINAL_CONV_KERNEL=1,
+                 STAGE2=_stage(1, chans[:2]), STAGE3=_stage(4, chans[:3]), STAGE4=_stage(3, chans))
+    model = dict(NAME=name, INIT_WEIGHTS=True, PRETRAINED="", NUM_JOINTS=num_joints,
+                 TARGET_TYPE="gaussian", IMAGE_SIZE=list(image_wh),
+                 HEATMAP_SIZE=[image_wh[0] // 4, image_wh[1] // 4], EXTRA=extra)
+    if name == "pose_rsgnet":
+        if num_limbs is None:
+            num_limbs = 18 if num_joints == 17 else 14
+        extra["OUTPUT_CONVS"] = list(chans)
+        model.update(NUM_LIMBS=num_limbs, FINAL_DECONV_KERNEL_SIZE=4, NUM_TYPE_VECTOR=600,
+                     UP_SCALE=2, RELATION_SUB_SAMPLE=False,
+                     HEATMAP_SIZE=[image_wh[0] // 2, image_wh[1] // 2])
+    return as_cfg(dict(MODEL=model))

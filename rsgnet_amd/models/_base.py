@@ -1,0 +1,92 @@
+"""Shared behaviour of the two drop-in models: plan cache, loud failure off-GPU, init_weights."""
+from __future__ import annotations
+
+import logging
+import os
+
+import torch
+import torch.nn as nn
+
+logger = logging.getLogger(__name__)
+
+
+class HipPoseModule(nn.Module):
+    """nn.Module facade over a compiled HIP execution plan.
+
+    The module owns reference-named parameters (``_tree.py``); ``forward`` hands the input to a plan
+    (``rsgnet_amd.plan``) that was built from those parameters: BatchNorm folded into fp16 weights,
+    weights packed into MFMA fragment order, a static NHWC activation arena, and the launch list.
+    The plan is rebuilt whenever the parameters may have changed (``load_state_dict``, ``train()``,
+    ``.to()/.cuda()``) or the batch size / device changes.
+
+    There is deliberately NO CPU or eager fallback: off the GPU, or without the HIP library,
+    ``forward`` raises.
+    """
+
+    #: storage/MFMA input type of the plan; accumulation is always fp32
+    compute_dtype = "fp16"
+
+    def __init__(self):
+        super().__init__()
+        self._plans = {}
+
+    # -- plan lifecycle ---------------------------------------------------------------------
+    def invalidate_plan(self) -> None:
+        self._plans = {}
+
+    def _apply(self, fn, *a, **kw):
+        self.invalidate_plan()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_plan()
+        return super().load_state_dict(*a, **kw)
+
+    def train(self, mode: bool = True):
+        self.invalidate_plan()
+        return super().train(mode)
+
+    def _build_plan(self, batch: int, device: torch.device):  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def plan_for(self, x: torch.Tensor):
+        if x.device.type != "cuda":
+            raise RuntimeError(
+                f"{type(self).__name__} runs only on an AMD GPU through librsgnet_hip.so; got a "
+                f"{x.device.type} tensor. There is no CPU fallback (the CPU oracle lives in oracle/ "
+                "and is test infrastructure).")
+        if self.training:
+            raise NotImplementedError(
+                "training-mode forward (batch-statistics BatchNorm + backward kernels) is not built "
+                "yet; call model.eval() — see DESIGN.md 'next rows'.")
+        key = (int(x.shape[0]), x.device.index, self.compute_dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._build_plan(int(x.shape[0]), x.device)
+            self._plans[key] = plan
+        return plan
+
+    # -- reference-compatible initialisation --------------------------------------------------
+    def init_weights(self, pretrained: str = "") -> None:
+        """pose_hrnet.py:465-495 / pose_rsgnet.py:1023-1063: N(0, 1e-3) convs/linears/deconvs, zero
+        biases, identity BatchNorm affine, then a partial load filtered by PRETRAINED_LAYERS."""
+        logger.info("=> init weights from normal distribution")
+        linear_too = getattr(self, "_init_linear", False)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) or (linear_too and isinstance(m, nn.Linear)):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if os.path.isfile(pretrained):
+            sd = torch.load(pretrained, map_location="cpu")
+            logger.info("=> loading pretrained model %s", pretrained)
+            layers = list(self.pretrained_layers)
+            keep = {k: v for k, v in sd.items() if k.split(".")[0] in layers or layers[0] == "*"}
+            self.load_state_dict(keep, strict=False)
+        elif pretrained:
+            logger.error("=> please download pre-trained models first!")
+            raise ValueError("{} is not exist!".format(pretrained))
+        self.invalidate_plan()
