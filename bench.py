@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s, HRNet-W32 256x192, batch 64 per GPU, forward (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one forward of the drop-in ``models.pose_hrnet`` over one batch of synthetic crops that is
+already resident in HBM.  Crops are independent, so N GPUs run N independent shards (weak scaling, no
+collective on the data path).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GFLOP_PER_IMG = {"hrnet_w32_256x192": 15.29, "rsgnet_w32_256x192_coco": 17.80}
+PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
+WORKLOADS = {
+    "hrnet_w32_256x192": ("pose_hrnet", 32, (192, 256), 17, 64),
+    "rsgnet_w32_256x192_coco": ("pose_rsgnet", 32, (192, 256), 17, 64),
+}
+
+
+def make_model(tag):
+    from rsgnet_amd import make_cfg, models
+    from rsgnet_amd.weights import synth_state_dict
+    name, width, wh, joints, batch = WORKLOADS[tag]
+    cfg = make_cfg(name, width, wh, joints)
+    model = getattr(models, name).get_pose_net(cfg, is_train=False)
+    bn = dict(np.load(os.path.join(ROOT, "tests", "golden", f"bnstats_{tag}.npz")))
+    sd = synth_state_dict(model.state_dict(), 0, bn)
+    model.load_state_dict(sd)
+    return cfg, model.eval(), sd, wh, batch
+
+
+def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0):
+    """The CPU oracle (port of the reference's torch-CPU forward) timed on this box's host cores."""
+    from oracle import pose_oracle as po
+    from rsgnet_amd.weights import synth_input
+    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    torch.set_num_threads(cores)
+    b = 8
+    x = synth_input(b, wh, 1)
+    fwd = (lambda: po.hrnet_forward(sd, cfg, x)) if cfg.MODEL.NAME == "pose_hrnet" else \
+          (lambda: po.rsgnet_forward(sd, cfg, x, want_scores=True))
+    fwd()
+    best, t_end, n = 1e9, time.time() + budget_s, 0
+    while n < 5 and time.time() < t_end:
+        t0 = time.time()
+        fwd()
+        best = min(best, time.time() - t0)
+        n += 1
+    return {"value": round(b / best, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} forwards of batch {b} (best), {tag}, torch {torch.__version__} CPU fp32, eval"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="hrnet_w32_256x192", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the metric's 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", default="", help="write a per-op timing table (JSON) to this path")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an AMD GPU (no CPU fallback path exists)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rsgnet_amd.weights import synth_input
+    cfg, model, sd, wh, batch = make_model(a.workload)
+    if a.batch:
+        batch = a.batch
+    model = model.to(dev)
+    x = synth_input(batch, wh, seed=rank).to(dev)          # resident in HBM before the timed region
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    for _ in range(max(a.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    o0 = out if torch.is_tensor(out) else out[1]
+    assert torch.isfinite(o0).all(), "non-finite heatmaps"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(a.steps):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier()
+    dev_ms = e0.elapsed_time(e1)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+
+    plan = model.plan_for(x)
+    per_op = None
+    if a.per_op and rank == 0:
+        per_op = []
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for name, op in plan.ops:
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2):
+                op(st)
+            s0.record()
+            for _ in range(5):
+                op(st)
+            s1.record()
+            torch.cuda.synchronize()
+            per_op.append({"op": name, "us": round(s0.elapsed_time(s1) / 5 * 1e3, 2)})
+        with open(a.per_op, "w") as f:
+            json.dump({"workload": a.workload, "batch": batch, "ops": per_op, "convs": plan.conv_log}, f)
+
+    if rank == 0:
+        ms = wall / a.steps * 1e3
+        imgs = world * batch * a.steps / wall
+        gflop = GFLOP_PER_IMG[a.workload]
+        # roofline of the dominant kernel family (conv_igemm_kernel: >95% of device time): algorithmic
+        # FLOPs of one step / device time of one step measured with HIP events on the launch stream
+        ach = gflop * batch / (dev_ms / a.steps) / 1e3 * 1e0   # GFLOP / ms = TFLOP/s
+        line = {
+            "metric": "images/sec HRNet-W32 256x192 bs64 fwd" if a.workload.startswith("hrnet") else
+                      "images/sec RSGNet-W32 256x192 bs64 fwd",
+            "value": round(imgs, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": model.compute_dtype, "data": "synthetic",
+            "config": {"workload": a.workload, "per_gpu_batch": batch, "global_batch": batch * world,
+                       "image": f"{wh[1]}x{wh[0]}", "parallelism": f"dp{world} (independent shards)",
+                       "weights": "synthetic name-keyed rule + calibrated BN stats", "hip_graph": plan.use_graph,
+                       "launches_per_step": len(plan.ops)},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "conv_igemm_kernel (all launches of one forward)",
+                         "device_ms_per_step": round(dev_ms / a.steps, 4),
+                         "algorithmic_gflop_per_image": gflop},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

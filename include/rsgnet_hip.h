@@ -1,0 +1,125 @@
+/*
+ * librsgnet_hip.so — C ABI of the MI355X (gfx950) kernels behind RSGNet's per-crop forward hot path.
+ *
+ * The reference has no FFI: its hot path is torch operators called from
+ * lib/models/pose_hrnet.py, pose_rsgnet.py and association.py.  Each entry point below
+ * replaces the torch-operator group named in its comment; a maintainer binds them with ctypes (see
+ * INTEGRATION.md).  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; nothing is retained past the call
+ *   - activations are NHWC, 16-bit (dtype RSG_F16 or RSG_BF16), channel counts padded as documented
+ *   - `stream` is a hipStream_t passed as void*; kernels are only enqueued, never synchronised
+ *   - return value: 0 on success, non-zero on error; rsg_last_error() gives the message (thread-local)
+ */
+#ifndef RSGNET_HIP_H
+#define RSGNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { RSG_F16 = 0, RSG_BF16 = 1 };
+
+const char* rsg_last_error(void);
+int rsg_version(void);
+
+/* ---- convolution family ---------------------------------------------------------------------
+ * One implicit-GEMM kernel family covers
+ *   nn.Conv2d 3x3 s1/s2 p1 + BatchNorm2d(eval) [+ residual] [+ ReLU]   pose_hrnet.py:23-59,62-101,
+ *                                                                       336-375 (transitions), 215-243 (fuse down)
+ *   nn.Conv2d 1x1 (+BN | +bias)                                         pose_hrnet.py:68-76,203-208,326-332
+ *   nn.ConvTranspose2d k4 s2 p1 + BN + ReLU (as 4 sub-pixel 2x2 convs)  pose_rsgnet.py:727-736
+ *   functional conv2d with SGM-generated weights                        pose_rsgnet.py:1005
+ * BatchNorm is folded into the packed weights/bias by rsg_pack_conv_weights_host().
+ *
+ * Input  : [batch, in_h, in_w, in_ld] 16-bit, the conv reads channels [0, in_c) of each pixel
+ *          (pass a pointer already offset to the first channel when reading a slice of a concat buffer);
+ *          in_c must equal rsg_conv_padded_cin(real cin) and the padding channels must hold zeros.
+ * Output : out16  [batch, phys_h, phys_w, out_ld] 16-bit, channels [0, round_up(out_c,32)) written
+ *          (padding channels get bias-only values = 0 when packed by the packer), and/or
+ *          out_nchw_f32 [batch, out_c, phys_h, phys_w] fp32 (classifier heads).
+ * Geometry: logical output pixel (y,x), y<out_h, x<out_w reads input (y*stride + ky - pad_y, ...)
+ *          and lands on physical pixel (y*up + up_y, x*up + up_x)  (up=1, up_y=up_x=0 for plain convs;
+ *          up=2 for the deconv phases).
+ */
+typedef struct rsg_conv_desc {
+    const void* in;
+    const void* w_packed;      /* from rsg_pack_conv_weights_host, copied to the device */
+    const float* bias;         /* [round_up(out_c,32)] */
+    const void* residual;      /* optional, [batch, phys_h, phys_w, res_ld] 16-bit, added before ReLU */
+    void* out16;               /* optional */
+    float* out_nchw_f32;       /* optional */
+    int32_t batch, in_h, in_w, in_c, in_ld;
+    int32_t out_h, out_w, out_c, out_ld, res_ld;
+    int32_t kh, kw, stride, pad_y, pad_x;
+    int32_t up, up_y, up_x, phys_h, phys_w;
+    int32_t relu;
+    int32_t dtype;             /* RSG_F16 | RSG_BF16 */
+    int32_t tile_hint;         /* 0 = auto; else (WM<<16)|(NT<<8)|TH<<4.. see rsg_conv_plan */
+    int32_t reserved;
+} rsg_conv_desc;
+
+int rsg_conv_igemm(const rsg_conv_desc* d, void* stream);
+
+/* what the auto-tiler picked for a descriptor (for logging / tuning): fills 8 ints
+ * {CINB, WM, WN, NT, TH, TW, lds_bytes, grid_x} */
+int rsg_conv_plan(const rsg_conv_desc* d, int32_t* out8);
+
+int32_t rsg_conv_padded_cin(int32_t cin);              /* 3->16, 17->32, multiples of 16 kept ... */
+size_t rsg_conv_packed_bytes(int32_t cin, int32_t cout, int32_t kh, int32_t kw);
+/* HOST function.  w_oihw_host: fp32 [cout][cin][kh][kw] (nn.Conv2d layout).  scale/shift: per-cout
+ * folded BatchNorm (gamma/sqrt(var+eps), beta - mean*scale) or NULL; conv_bias: per-cout or NULL.
+ * Writes the fragment-ordered 16-bit weights (rsg_conv_packed_bytes) and fp32 bias [round_up(cout,32)]:
+ *   w' = w*scale (rounded once to 16 bits), bias' = conv_bias*scale + shift. */
+int rsg_pack_conv_weights_host(const float* w_oihw_host, const float* scale_host, const float* shift_host,
+                               const float* conv_bias_host, int32_t cin, int32_t cout, int32_t kh,
+                               int32_t kw, int32_t dtype, void* w_packed_host, float* bias_host);
+
+/* ---- layout / elementwise -------------------------------------------------------------------- */
+/* x.float NCHW -> NHWC 16-bit with channels zero-padded to c_pad (input of the stem conv,
+ * pose_hrnet.py:429; replaces the implicit layout the reference's conv1 reads) */
+int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch, int32_t c, int32_t h, int32_t w,
+                           int32_t c_pad, int32_t dtype, void* stream);
+
+/* HighResolutionModule fuse for ONE output branch (pose_hrnet.py:259-266):
+ *   out = ReLU( sum_k same[k] + sum_k nearest_up(low[k], low_shift[k]) )
+ * same[k]: [batch,h,w,c] 16-bit (identity branch and the strided-conv results),
+ * low[k]:  [batch,h>>s,w>>s,c] 16-bit (the 1x1+BN results, upsampled by 2^s = nn.Upsample nearest). */
+int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const void* const* low,
+                    const int32_t* low_shift, int32_t n_low, void* out, int32_t batch, int32_t h,
+                    int32_t w, int32_t c, int32_t dtype, void* stream);
+
+/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) [+ sigmoid] on fp32 NCHW
+ * (pose_rsgnet.py:1009-1013) */
+int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t planes, int32_t h, int32_t w,
+                            int32_t sigmoid, void* stream);
+
+/* ---- TRP: SpatialRelationHead (association.py:280-301) ---------------------------------------- */
+/* E[b,i,:] = sum_j sigmoid(<x_i,x_j>) * g_j   without materialising the S x S map.
+ * x: [batch,S,ld_x] 16-bit (channels [0,C)), gT: [batch,C,S] 16-bit pair (hi, lo) of the projected
+ * values g = conv1x1(x)+b split as g = hi + lo, E out: fp32 [batch,S,C].  C must be 32 or 48. */
+int rsg_trp_attention(const void* x, int32_t ld_x, const void* gT_hi, const void* gT_lo, float* e_out,
+                      int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
+/* g projection in transposed, split form: gT_{hi,lo}[b,c,s] from x [batch,S,ld_x] with fp32 weights
+ * w[C][C], bias[C] (association.py:288-289) */
+int rsg_trp_project_g(const void* x, int32_t ld_x, const float* w, const float* bias, void* gT_hi,
+                      void* gT_lo, int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
+/* W: conv1x1(+bias) then GroupNorm(8,C) on E, written 16-bit into out[b,s, 0:C] of a buffer with
+ * channel stride out_ld (association.py:298-300) */
+int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,
+                 const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
+                 int32_t dtype, void* stream);
+/* optional materialisation of relation_score [batch,S,S] fp32 (association.py:294-295) */
+int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S, int32_t C,
+                   int32_t dtype, void* stream);
+/* training tail (pose_rsgnet.py:1014-1018) with the target kept factored, T = p p^T:
+ * mse[b] = mean_ij (p_i p_j - sigmoid(<x_i,x_j>))^2 ; p: fp32 [batch,S] */
+int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, int32_t batch,
+                         int32_t S, int32_t C, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSGNET_HIP_H */

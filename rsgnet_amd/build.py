@@ -1,0 +1,66 @@
+"""Build librsgnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "librsgnet_hip.so")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: librsgnet_hip.so cannot be built")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    srcs = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(os.path.dirname(PKG), "include", "rsgnet_hip.h")]
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every csrc/*.hip for gfx950 and link them into rsgnet_amd/lib/librsgnet_hip.so."""
+    if not force and not stale():
+        return LIB
+    hipcc = _hipcc()
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+
+    def cc(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(cc, srcs))
+    tmp = LIB + ".tmp"
+    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", tmp],
+                       capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

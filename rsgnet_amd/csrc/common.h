@@ -1,0 +1,49 @@
+// Shared helpers for librsgnet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/rsgnet_hip.h"
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+extern thread_local char g_rsg_err[512];
+
+#define RSG_FAIL(...)                                        \
+    do {                                                     \
+        snprintf(g_rsg_err, sizeof(g_rsg_err), __VA_ARGS__); \
+        return 1;                                            \
+    } while (0)
+
+#define RSG_CHECK_LAUNCH(what)                                                            \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess) RSG_FAIL("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+    } while (0)
+
+// 16-bit storage types: one struct per dtype so kernels can be templated on it.
+struct F16 {
+    typedef _Float16 elem;
+    typedef h8_t vec8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __host__ __forceinline__ float to_f32(elem v) { return (float)v; }
+    static __device__ __host__ __forceinline__ elem from_f32(float v) { return (elem)v; }
+};
+struct BF16 {
+    typedef __bf16 elem;
+    typedef b8_t vec8;
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __host__ __forceinline__ float to_f32(elem v) { return (float)v; }
+    static __device__ __host__ __forceinline__ elem from_f32(float v) { return (elem)v; }
+};
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

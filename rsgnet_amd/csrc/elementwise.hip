@@ -1,0 +1,168 @@
+// Bandwidth-bound helpers around the convolution kernels (gfx950): 16 bytes per lane everywhere.
+#include "common.h"
+
+// ---- NCHW fp32 -> NHWC 16-bit, channels zero-padded (stem input; pose_hrnet.py:429) ---------------
+// One thread per pixel: reads c planes (coalesced across the wave along W), writes c_pad*2 bytes.
+template <class DT, int CPAD>
+__global__ void __launch_bounds__(256) nchw_to_nhwc16_kernel(const float* __restrict__ in, char* __restrict__ out,
+                                                            int c, int hw, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / hw;
+    const int s = (int)(i - b * hw);
+    typename DT::elem v[CPAD];
+#pragma unroll
+    for (int k = 0; k < CPAD; ++k) v[k] = (typename DT::elem)0.f;
+#pragma unroll
+    for (int k = 0; k < CPAD; ++k)
+        if (k < c) v[k] = (typename DT::elem)in[(b * c + k) * hw + s];
+    uint4* o = reinterpret_cast<uint4*>(out + i * CPAD * 2);
+#pragma unroll
+    for (int k = 0; k < CPAD / 8; ++k) {
+        typename DT::vec8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = v[k * 8 + e];
+        o[k] = __builtin_bit_cast(uint4, t);
+    }
+}
+
+extern "C" int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch, int32_t c, int32_t h,
+                                      int32_t w, int32_t c_pad, int32_t dtype, void* stream) {
+    if (!in || !out) RSG_FAIL("nchw_to_nhwc16: null pointer");
+    if (c_pad != 16 || c > c_pad || c < 1) RSG_FAIL("nchw_to_nhwc16: c=%d c_pad=%d (only c_pad=16)", c, c_pad);
+    const long total = (long)batch * h * w;
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == RSG_BF16)
+        hipLaunchKernelGGL((nchw_to_nhwc16_kernel<BF16, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           in, (char*)out, c, h * w, total);
+    else
+        hipLaunchKernelGGL((nchw_to_nhwc16_kernel<F16, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           in, (char*)out, c, h * w, total);
+    RSG_CHECK_LAUNCH("nchw_to_nhwc16");
+    return 0;
+}
+
+// ---- HighResolutionModule fuse (pose_hrnet.py:259-266) ------------------------------------------------
+struct FuseArgs {
+    const char* same[4];
+    const char* low[3];
+    int shift[3];
+    int n_same, n_low;
+    char* out;
+    int h, w, c8;   // c8 = channels / 8
+    long total;     // batch*h*w*c8 16-byte vectors
+};
+
+template <class DT>
+__global__ void __launch_bounds__(256) hr_fuse_kernel(const FuseArgs a) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int k = 0; k < a.n_same; ++k) {
+            const typename DT::vec8 v =
+                __builtin_bit_cast(typename DT::vec8, reinterpret_cast<const uint4*>(a.same[k])[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+        if (a.n_low) {
+            const int cg = (int)(i % a.c8);
+            long pix = i / a.c8;
+            const int x = (int)(pix % a.w);
+            pix /= a.w;
+            const int y = (int)(pix % a.h);
+            const long b = pix / a.h;
+            for (int k = 0; k < a.n_low; ++k) {
+                const int s = a.shift[k];
+                const long src = ((b * (a.h >> s) + (y >> s)) * (a.w >> s) + (x >> s)) * a.c8 + cg;
+                const typename DT::vec8 v =
+                    __builtin_bit_cast(typename DT::vec8, reinterpret_cast<const uint4*>(a.low[k])[src]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        }
+        typename DT::vec8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (typename DT::elem)fmaxf(acc[e], 0.f);
+        reinterpret_cast<uint4*>(a.out)[i] = __builtin_bit_cast(uint4, o);
+    }
+}
+
+extern "C" int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const void* const* low,
+                               const int32_t* low_shift, int32_t n_low, void* out, int32_t batch,
+                               int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
+    if (n_same < 1 || n_same > 4 || n_low < 0 || n_low > 3 || !out) RSG_FAIL("hr_fuse: bad operand count");
+    if (c % 8) RSG_FAIL("hr_fuse: channels %d not a multiple of 8", c);
+    FuseArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int k = 0; k < n_same; ++k) a.same[k] = (const char*)same[k];
+    for (int k = 0; k < n_low; ++k) {
+        a.low[k] = (const char*)low[k];
+        a.shift[k] = low_shift[k];
+        if ((h & ((1 << a.shift[k]) - 1)) || (w & ((1 << a.shift[k]) - 1)) || a.shift[k] < 1)
+            RSG_FAIL("hr_fuse: %dx%d not divisible by 2^%d", h, w, a.shift[k]);
+    }
+    a.n_same = n_same; a.n_low = n_low; a.out = (char*)out;
+    a.h = h; a.w = w; a.c8 = c / 8;
+    a.total = (long)batch * h * w * a.c8;
+    long blocks = (a.total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (dtype == RSG_BF16)
+        hipLaunchKernelGGL(hr_fuse_kernel<BF16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(hr_fuse_kernel<F16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH("hr_fuse_sum");
+    return 0;
+}
+
+// ---- bilinear x2, align_corners=True, optional sigmoid, fp32 NCHW (pose_rsgnet.py:1009-1013) -----------
+// src = dst * (in-1)/(out-1); out = 2*in.  One thread per 4 consecutive output x (16-byte store).
+__global__ void __launch_bounds__(256) bilinear2x_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int h, int w, long total4, int sigmoid) {
+    const int ow = 2 * w, oh = 2 * h;
+    const float ry = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
+    const float rx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int ow4 = ow / 4;
+        const int x4 = (int)(i % ow4);
+        long t = i / ow4;
+        const int oy = (int)(t % oh);
+        const long pl = t / oh;
+        const float sy = ry * oy;
+        int y0 = (int)sy;
+        if (y0 > h - 1) y0 = h - 1;
+        const int y1 = y0 < h - 1 ? y0 + 1 : y0;
+        const float wy = sy - (float)y0;
+        const float* r0 = in + (pl * h + y0) * w;
+        const float* r1 = in + (pl * h + y1) * w;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ox = x4 * 4 + k;
+            const float sx = rx * ox;
+            int xa = (int)sx;
+            if (xa > w - 1) xa = w - 1;
+            const int xb = xa < w - 1 ? xa + 1 : xa;
+            const float wx = sx - (float)xa;
+            // same association as ATen's upsample_bilinear2d: lerp in x on both rows, then in y
+            const float top = r0[xa] * (1.f - wx) + r0[xb] * wx;
+            const float bot = r1[xa] * (1.f - wx) + r1[xb] * wx;
+            float v = top * (1.f - wy) + bot * wy;
+            if (sigmoid) v = 1.f / (1.f + __expf(-v));
+            o[k] = v;
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t planes, int32_t h, int32_t w,
+                                       int32_t sigmoid, void* stream) {
+    if (!in || !out || planes < 1 || h < 1 || w < 2 || (w % 2)) RSG_FAIL("bilinear2x: bad arguments");
+    const long total4 = (long)planes * (2 * h) * (2 * w / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(bilinear2x_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, out, h, w,
+                       total4, sigmoid);
+    RSG_CHECK_LAUNCH("bilinear2x");
+    return 0;
+}

@@ -1,0 +1,79 @@
+"""ctypes binding of librsgnet_hip.so (the C ABI in include/rsgnet_hip.h).
+
+Loading fails loudly: there is no fallback implementation of any entry point.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+RSG_F16, RSG_BF16 = 0, 1
+DTYPES = {"fp16": RSG_F16, "bf16": RSG_BF16}
+
+
+class ConvDesc(C.Structure):
+    """struct rsg_conv_desc (include/rsgnet_hip.h)."""
+    _fields_ = [
+        ("inp", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("out16", C.c_void_p), ("out_nchw_f32", C.c_void_p),
+        ("batch", C.c_int32), ("in_h", C.c_int32), ("in_w", C.c_int32), ("in_c", C.c_int32), ("in_ld", C.c_int32),
+        ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_c", C.c_int32), ("out_ld", C.c_int32), ("res_ld", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
+        ("up", C.c_int32), ("up_y", C.c_int32), ("up_x", C.c_int32), ("phys_h", C.c_int32), ("phys_w", C.c_int32),
+        ("relu", C.c_int32), ("dtype", C.c_int32), ("tile_hint", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/rsgnet_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _fp = C.c_void_p, C.c_int32, C.c_void_p
+SYMBOLS = {
+    "rsg_last_error": (C.c_char_p, []),
+    "rsg_version": (C.c_int, []),
+    "rsg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "rsg_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
+    "rsg_conv_padded_cin": (C.c_int32, [_i]),
+    "rsg_conv_packed_bytes": (C.c_size_t, [_i, _i, _i, _i]),
+    "rsg_pack_conv_weights_host": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rsg_nchw_f32_to_nhwc16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsg_hr_fuse_sum": (C.c_int, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _vp,
+                                  _i, _i, _i, _i, _i, _vp]),
+    "rsg_bilinear2x_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_attention": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_project_g": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsg_trp_scores": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def lib() -> C.CDLL:
+    """Load (once) the HIP library; raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -m rsgnet_amd.build` (hipcc, gfx950). "
+                "rsgnet_amd has no non-HIP fallback.")
+        l = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)      # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc:
+        msg = lib().rsg_last_error().decode(errors="replace")
+        raise RuntimeError(f"librsgnet_hip {what}: {msg}")

@@ -1,0 +1,416 @@
+"""Execution plans: the reference's nn.Module graphs lowered to a flat list of HIP kernel launches.
+
+A plan is built once per (model weights, batch size, device):
+  1. *record*  — walk the model (same order as /root/reference/lib/models/pose_hrnet.py:428-463 and
+     pose_rsgnet.py:921-1021) and record ops on virtual NHWC 16-bit tensors; fold every BatchNorm
+     into the preceding conv and pack the weights into MFMA fragment order (C packer);
+  2. *allocate* — linear-scan the op list and give virtual tensors physical buffers, reusing a buffer
+     as soon as its last reader has run (keeps the working set inside the 256 MB Infinity Cache);
+  3. *lower*   — fill one ``rsg_conv_desc`` (or argument tuple) per op with raw device pointers;
+  4. *run*     — enqueue the launches on the caller's stream, or replay them from a captured HIP graph.
+
+Only pointers and sizes cross into librsgnet_hip.so; torch is used for memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+
+BN_EPS = 1e-5
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class VT:
+    """Virtual NHWC 16-bit activation [B,H,W,ld]; ``view(c0, c)`` addresses a channel slice of it."""
+
+    __slots__ = ("H", "W", "C", "ld", "coff", "base", "pinned", "first", "last", "storage", "name")
+
+    def __init__(self, H, W, C_, ld=None, pinned=False, name=""):
+        self.H, self.W, self.C = H, W, C_
+        self.ld = ld if ld is not None else C_
+        self.coff = 0
+        self.base: "VT" = self
+        self.pinned = pinned
+        self.first = self.last = -1
+        self.storage: Optional[torch.Tensor] = None
+        self.name = name
+
+    def view(self, c0: int, c: int) -> "VT":
+        v = VT(self.H, self.W, c, self.ld, name=self.name + f"[{c0}:{c0 + c}]")
+        v.coff = self.coff + c0
+        v.base = self.base
+        return v
+
+    def ptr(self) -> int:
+        return self.base.storage.data_ptr() + self.coff * 2
+
+    def nbytes(self, batch: int) -> int:
+        return batch * self.H * self.W * self.ld * 2
+
+    def tensor(self, batch: int) -> torch.Tensor:
+        """[B,H,W,C] view of the live buffer (debug / tests)."""
+        t = self.base.storage[: batch * self.H * self.W * self.ld].view(batch, self.H, self.W, self.ld)
+        return t[..., self.coff: self.coff + self.C]
+
+
+class Plan:
+    def __init__(self, model: nn.Module, batch: int, device: torch.device, dtype: str):
+        if dtype not in hip.DTYPES:
+            raise ValueError(f"compute dtype {dtype!r}; expected one of {list(hip.DTYPES)}")
+        self.lib = hip.lib()
+        self.batch = batch
+        self.device = device
+        self.dtype_name = dtype
+        self.dtype = hip.DTYPES[dtype]
+        self.tdtype = torch.float16 if dtype == "fp16" else torch.bfloat16
+        self.ops: List[Tuple[str, Callable[[int], None]]] = []
+        self._rec: List[dict] = []          # recorded ops before lowering
+        self._keep: List[object] = []       # ctypes structs / tensors that must outlive the plan
+        self._vts: List[VT] = []
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.use_graph = os.environ.get("RSGNET_HIP_GRAPH", "1") != "0"
+        self.conv_log: List[dict] = []
+        self.flops = 0
+
+    # ------------------------------------------------------------------ recording
+    def new(self, H, W, C_, ld=None, pinned=False, name="") -> VT:
+        vt = VT(H, W, C_, ld, pinned, name)
+        self._vts.append(vt)
+        return vt
+
+    def _touch(self, idx: int, *vts: Optional[VT]):
+        for v in vts:
+            if v is None:
+                continue
+            b = v.base
+            if b.first < 0:
+                b.first = idx
+            b.last = max(b.last, idx)
+
+    def _dev(self, arr: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        self._keep.append(t)
+        return t
+
+    def pack_conv(self, w: torch.Tensor, scale, shift, bias) -> Tuple[torch.Tensor, torch.Tensor, int, int]:
+        """w: fp32 [O,I,kh,kw] (CPU).  Returns (packed weights u8 on device, bias f32 on device)."""
+        w = w.detach().to("cpu", torch.float32).contiguous()
+        O, I, kh, kw = w.shape
+        nbytes = self.lib.rsg_conv_packed_bytes(I, O, kh, kw)
+        wp = np.empty(nbytes, dtype=np.uint8)
+        bo = np.empty(_round_up(O, 32), dtype=np.float32)
+
+        def p(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(a) else a,
+                                     dtype=np.float32)
+            self._tmp.append(a)
+            return a.ctypes.data
+
+        self._tmp = []
+        wn = w.numpy()
+        hip.check(self.lib.rsg_pack_conv_weights_host(wn.ctypes.data, p(scale), p(shift), p(bias), I, O, kh, kw,
+                                                      self.dtype, wp.ctypes.data, bo.ctypes.data), "pack")
+        self._tmp = []
+        return self._dev(wp), self._dev(bo), I, O
+
+    @staticmethod
+    def bn_fold(bn: Optional[nn.Module]):
+        """eval-mode BatchNorm as (scale, shift) in fp64->fp32."""
+        if bn is None:
+            return None, None
+        g = bn.weight.detach().double().cpu()
+        b = bn.bias.detach().double().cpu()
+        m = bn.running_mean.detach().double().cpu()
+        v = bn.running_var.detach().double().cpu()
+        s = g / torch.sqrt(v + bn.eps)
+        return s.float(), (b - m * s).float()
+
+    def conv(self, x: VT, weight: torch.Tensor, bn: Optional[nn.Module] = None, bias=None, *, stride=1,
+             relu=False, residual: Optional[VT] = None, out: Optional[VT] = None,
+             out_f32: Optional[torch.Tensor] = None, want16=True, pad=None, up=(1, 0, 0),
+             out_hw=None, phys_hw=None, name="") -> Optional[VT]:
+        """Record conv(+BN)(+bias)(+residual)(+ReLU).  ``x.C`` must be the padded input channels."""
+        scale, shift = self.bn_fold(bn)
+        wp, bo, I, O = self.pack_conv(weight, scale, shift, bias)
+        kh, kw = int(weight.shape[2]), int(weight.shape[3])
+        cin_pad = self.lib.rsg_conv_padded_cin(I)
+        if x.C != cin_pad:
+            raise ValueError(f"{name}: input view has {x.C} channels, conv needs padded cin {cin_pad}")
+        if pad is None:
+            pad = ((kh - 1) // 2, (kw - 1) // 2)
+        if out_hw is None:
+            out_hw = ((x.H + 2 * pad[0] - kh) // stride + 1, (x.W + 2 * pad[1] - kw) // stride + 1)
+        if phys_hw is None:
+            phys_hw = (out_hw[0] * up[0], out_hw[1] * up[0])
+        cpad = _round_up(O, 32)
+        if want16 and out is None:
+            out = self.new(phys_hw[0], phys_hw[1], cpad, name=name)
+        if out is not None and (out.H, out.W) != tuple(phys_hw):
+            raise ValueError(f"{name}: output buffer is {out.H}x{out.W}, conv writes {phys_hw}")
+        idx = len(self._rec)
+        self._touch(idx, x, residual, out)
+        self._rec.append(dict(kind="conv", x=x, wp=wp, bias=bo, res=residual, out=out, out_f32=out_f32,
+                              I=cin_pad, O=O, kh=kh, kw=kw, stride=stride, pad=pad, up=up, out_hw=out_hw,
+                              phys_hw=phys_hw, relu=relu, name=name))
+        self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
+        return out
+
+    def fuse(self, same: Sequence[VT], low: Sequence[Tuple[VT, int]], name="") -> VT:
+        ref = same[0]
+        out = self.new(ref.H, ref.W, ref.C, name=name)
+        idx = len(self._rec)
+        self._touch(idx, out, *same, *[v for v, _ in low])
+        self._rec.append(dict(kind="fuse", same=list(same), low=list(low), out=out, name=name))
+        return out
+
+    def custom(self, name: str, reads: Sequence[VT], writes: Sequence[VT], make: Callable[[], Callable[[int], None]]):
+        """Record an op whose launcher is created by ``make()`` after buffers have addresses."""
+        idx = len(self._rec)
+        self._touch(idx, *reads, *writes)
+        self._rec.append(dict(kind="custom", make=make, name=name))
+
+    # ------------------------------------------------------------------ allocation + lowering
+    def finalize(self):
+        B = self.batch
+        free: Dict[int, List[torch.Tensor]] = {}
+        expiring: Dict[int, List[VT]] = {}
+        bases = [v for v in self._vts if v.base is v and v.first >= 0]
+        by_first: Dict[int, List[VT]] = {}
+        for v in bases:
+            by_first.setdefault(v.first, []).append(v)
+        total = 0
+        for idx in range(len(self._rec)):
+            for v in by_first.get(idx, []):
+                n = v.nbytes(B) // 2
+                pool = free.get(n)
+                if pool and not v.pinned:
+                    v.storage = pool.pop()
+                else:
+                    v.storage = torch.zeros(n, dtype=self.tdtype, device=self.device)
+                    total += n * 2
+                if not v.pinned:
+                    expiring.setdefault(v.last, []).append(v)
+            # outputs of op idx may not alias its inputs: release only AFTER the op
+            for v in expiring.get(idx, []):
+                free.setdefault(v.nbytes(B) // 2, []).append(v.storage)
+        self.arena_bytes = total
+        for r in self._rec:
+            getattr(self, "_lower_" + r["kind"])(r)
+        self._rec = []
+
+    def _lower_conv(self, r):
+        d = hip.ConvDesc()
+        x: VT = r["x"]
+        d.inp = x.ptr()
+        d.w_packed = r["wp"].data_ptr()
+        d.bias = r["bias"].data_ptr()
+        d.residual = r["res"].ptr() if r["res"] is not None else None
+        d.out16 = r["out"].ptr() if r["out"] is not None else None
+        d.out_nchw_f32 = r["out_f32"].data_ptr() if r["out_f32"] is not None else None
+        d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = self.batch, x.H, x.W, r["I"], x.ld
+        d.out_h, d.out_w, d.out_c = r["out_hw"][0], r["out_hw"][1], r["O"]
+        d.out_ld = r["out"].ld if r["out"] is not None else _round_up(r["O"], 32)
+        d.res_ld = r["res"].ld if r["res"] is not None else 0
+        d.kh, d.kw, d.stride = r["kh"], r["kw"], r["stride"]
+        d.pad_y, d.pad_x = r["pad"]
+        d.up, d.up_y, d.up_x = r["up"]
+        d.phys_h, d.phys_w = r["phys_hw"]
+        d.relu = 1 if r["relu"] else 0
+        d.dtype = self.dtype
+        d.tile_hint = 0
+        self._keep.append(d)
+        info = (C.c_int32 * 8)()
+        hip.check(self.lib.rsg_conv_plan(C.byref(d), info), r["name"])
+        self.conv_log.append(dict(name=r["name"], cin=r["I"], cout=r["O"], k=r["kh"], s=r["stride"],
+                                  hw=r["out_hw"], tile=list(info)))
+        fn, ref = self.lib.rsg_conv_igemm, C.byref(d)
+        nm = r["name"]
+
+        def launch(stream, fn=fn, ref=ref, nm=nm):
+            rc = fn(ref, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((r["name"], launch))
+
+    def _lower_fuse(self, r):
+        same, low, out = r["same"], r["low"], r["out"]
+        for v in list(same) + [v for v, _ in low]:
+            if v.ld != v.C or v.coff:
+                raise ValueError("fuse operands must be dense tensors")
+        sp = (C.c_void_p * 4)(*[v.ptr() for v in same])
+        lp = (C.c_void_p * 3)(*[v.ptr() for v, _ in low])
+        sh = (C.c_int32 * 3)(*[s for _, s in low])
+        self._keep += [sp, lp, sh]
+        args = (sp, len(same), lp, sh, len(low), out.ptr(), self.batch, out.H, out.W, out.C, self.dtype)
+        fn, nm = self.lib.rsg_hr_fuse_sum, r["name"]
+
+        def launch(stream):
+            rc = fn(*args, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((r["name"], launch))
+
+    def _lower_custom(self, r):
+        self.ops.append((r["name"], r["make"]()))
+
+    # ------------------------------------------------------------------ execution
+    def launch_all(self, stream: Optional[int] = None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        for _, op in self.ops:
+            op(s)
+
+    def _replay(self):
+        if not self.use_graph:
+            self.launch_all()
+            return
+        if self.graph is None:
+            # warm-up launches outside capture (lazy module loading), then capture
+            self.launch_all()
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.launch_all()
+            self.graph = g
+        self.graph.replay()
+
+
+# ====================================================================================================
+# HRNet backbone recorder (shared by both models)
+# ====================================================================================================
+
+class _BackboneMixin:
+    def _record_input(self: Plan, H: int, W: int):
+        self.x_static = torch.zeros(self.batch, 3, H, W, dtype=torch.float32, device=self.device)
+        x16 = self.new(H, W, 16, name="x_nhwc16")
+        lib, B, dt = self.lib, self.batch, self.dtype
+
+        def make():
+            src, dst = self.x_static.data_ptr(), x16.ptr()
+
+            def launch(stream):
+                hip.check(lib.rsg_nchw_f32_to_nhwc16(src, dst, B, 3, H, W, 16, dt, stream), "nchw_to_nhwc16")
+            return launch
+
+        self.custom("input_to_nhwc16", [], [x16], make)
+        return x16
+
+    def _unit(self: Plan, x: VT, conv: nn.Conv2d, bn, **kw) -> VT:
+        return self.conv(x, conv.weight, bn, conv.bias, stride=conv.stride[0], **kw)
+
+    def _residual_block(self: Plan, x: VT, blk, name: str) -> VT:
+        """BasicBlock / Bottleneck (pose_hrnet.py:30-101)."""
+        res = x
+        if blk.downsample is not None:
+            res = self._unit(x, blk.downsample[0], blk.downsample[1], name=name + ".downsample")
+        y = self._unit(x, blk.conv1, blk.bn1, relu=True, name=name + ".conv1")
+        if hasattr(blk, "conv3"):
+            y = self._unit(y, blk.conv2, blk.bn2, relu=True, name=name + ".conv2")
+            return self._unit(y, blk.conv3, blk.bn3, relu=True, residual=res, name=name + ".conv3")
+        return self._unit(y, blk.conv2, blk.bn2, relu=True, residual=res, name=name + ".conv2")
+
+    def _hr_module(self: Plan, xs: List[VT], mod, name: str) -> List[VT]:
+        """HighResolutionModule.forward (pose_hrnet.py:250-268)."""
+        xs = list(xs)
+        for b, branch in enumerate(mod.branches):
+            for k, blk in enumerate(branch):
+                xs[b] = self._residual_block(xs[b], blk, f"{name}.branches.{b}.{k}")
+        if mod.fuse_layers is None:
+            return xs
+        outs = []
+        for i, row in enumerate(mod.fuse_layers):
+            same, low = [], []
+            for j, fl in enumerate(row):
+                if j == i:
+                    same.append(xs[j])
+                elif j > i:
+                    z = self._unit(xs[j], fl[0], fl[1], name=f"{name}.fuse.{i}.{j}")
+                    low.append((z, j - i))
+                else:
+                    t = xs[j]
+                    for k, step in enumerate(fl):
+                        t = self._unit(t, step[0], step[1], relu=(k != len(fl) - 1),
+                                       name=f"{name}.fuse.{i}.{j}.{k}")
+                    same.append(t)
+            outs.append(self.fuse(same, low, name=f"{name}.fuse.{i}"))
+        return outs
+
+    def _record_backbone(self: Plan, m, H: int, W: int) -> List[VT]:
+        x = self._record_input(H, W)
+        x = self._unit(x, m.conv1, m.bn1, relu=True, name="conv1")
+        x = self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
+        for k, blk in enumerate(m.layer1):
+            x = self._residual_block(x, blk, f"layer1.{k}")
+        ys = [x]
+        for s in (2, 3, 4):
+            trans = getattr(m, f"transition{s - 1}")
+            xs = []
+            for i, tr in enumerate(trans):
+                if i < len(ys):
+                    xs.append(ys[i] if tr is None else self._unit(ys[i], tr[0], tr[1], relu=True,
+                                                                  name=f"transition{s - 1}.{i}"))
+                else:
+                    t = ys[-1]
+                    for j, step in enumerate(tr):
+                        t = self._unit(t, step[0], step[1], relu=True, name=f"transition{s - 1}.{i}.{j}")
+                    xs.append(t)
+            for k, mod in enumerate(getattr(m, f"stage{s}")):
+                xs = self._hr_module(xs, mod, f"stage{s}.{k}")
+            ys = xs
+        return ys
+
+
+class HRNetPlan(Plan, _BackboneMixin):
+    """pose_hrnet.PoseHighResolutionNet.forward (pose_hrnet.py:428-463)."""
+
+    def __init__(self, model, batch, device, dtype):
+        super().__init__(model, batch, device, dtype)
+        W, H = model.cfg.MODEL.IMAGE_SIZE
+        self.H, self.W = H, W
+        J = model.cfg.MODEL.NUM_JOINTS
+        ys = self._record_backbone(model, H, W)
+        self.heat = torch.zeros(batch, J, H // 4, W // 4, dtype=torch.float32, device=device)
+        fl = model.final_layer
+        if fl.kernel_size != (1, 1):
+            raise NotImplementedError("FINAL_CONV_KERNEL=3")
+        self.conv(ys[0], fl.weight, None, fl.bias, out_f32=self.heat, want16=False, name="final_layer")
+        self.finalize()
+
+    def run(self, x: torch.Tensor, clone: bool = True) -> torch.Tensor:
+        if x.shape != self.x_static.shape:
+            raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_static.shape)} "
+                             "(H, W must equal cfg.MODEL.IMAGE_SIZE)")
+        self.x_static.copy_(x)
+        self._replay()
+        return self.heat.clone() if clone else self.heat
+
+
+class RSGNetPlan(Plan, _BackboneMixin):
+    """RSGNet.forward (pose_rsgnet.py:955-1021) — filled in by rsgnet_amd/plan_rsgnet.py."""
+
+    def __init__(self, model, batch, device, dtype):
+        super().__init__(model, batch, device, dtype)
+        from .plan_rsgnet import record_rsgnet
+        record_rsgnet(self, model)
+        self.finalize()
+
+    def run(self, x: torch.Tensor, clone: bool = True):
+        if x.shape != self.x_static.shape:
+            raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_static.shape)}")
+        self.x_static.copy_(x)
+        self._replay()
+        outs = (self.multi_up, self.kpt, self.limbs)
+        return tuple(o.clone() for o in outs) if clone else outs

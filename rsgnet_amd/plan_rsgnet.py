@@ -1,0 +1,201 @@
+"""Recorder for RSGNet's head (pose_rsgnet.py:955-1021) on top of the shared HRNet backbone recorder.
+
+Weight-only sub-graphs are folded at plan-build time (they do not depend on the input in eval mode,
+SURVEY §0): ``type_fc(type_features)`` and its product with ``type_conv`` (an exact 3x3 conv J->C0),
+``loc_conv(loc_features)`` (a constant map written once into the concat buffer) and
+``kt_machine(final_layer.weight)`` (the SGM limb classifier).  These folds are fp32 tensor algebra on
+the *parameters*; every per-crop operation runs in librsgnet_hip.so.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .plan import BN_EPS, VT, Plan
+
+
+def _bn_affine(bn):
+    s = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    return s, bn.bias.detach().double() - bn.running_mean.detach().double() * s
+
+
+def type_templates(model) -> torch.Tensor:
+    """ReLU(BN1d(Linear(type_features)))  [J,T]  (pose_rsgnet.py:679-683,971-972), fp64."""
+    t = model.type_features.detach().double().cpu() @ model.type_fc[0].weight.detach().double().cpu().t()
+    s, sh = _bn_affine(model.type_fc[1])
+    return torch.relu(t * s.cpu() + sh.cpu())
+
+
+def folded_type_conv_weight(model) -> torch.Tensor:
+    """W'[o,j,ky,kx] = sum_c type_conv.W[o,c,ky,kx] * Tm[j,c]  (the [B,600,H,W] map never exists)."""
+    tm = type_templates(model)
+    w = model.type_conv[0].weight.detach().double().cpu()
+    return torch.einsum("ocyx,jc->ojyx", w, tm).float()
+
+
+def limb_classifier(model) -> torch.Tensor:
+    """KTMachine.forward(final_layer.weight) -> [L,C0,1,1]  (pose_rsgnet.py:576-600,1004)."""
+    kt = model.kt_machine
+    wk = model.final_layer.weight.detach().double().cpu()
+    n_out, n_in, h, w = wk.shape
+    k = kt.matrix_limb.detach().double().cpu() * kt.real_matrix_limb.detach().double().cpu()
+    t = k @ wk.reshape(n_out, n_in * h * w)
+    l0, l2 = kt.kpt_transformer[0], kt.kpt_transformer[2]
+    t = F.linear(t, l0.weight.detach().double().cpu(), l0.bias.detach().double().cpu())
+    t = F.leaky_relu(t, 0.02)
+    t = F.linear(t, l2.weight.detach().double().cpu(), l2.bias.detach().double().cpu())
+    return t.reshape(t.shape[0], n_in, h, w).float()
+
+
+def location_features(model) -> torch.Tensor:
+    """ReLU(BN(conv1x1(loc_features)))  [1,C0,H4,W4] (pose_rsgnet.py:693-697,979), fp64 -> fp32."""
+    x = model.loc_features.detach().double().cpu()
+    y = F.conv2d(x, model.loc_conv[0].weight.detach().double().cpu())
+    s, sh = _bn_affine(model.loc_conv[1])
+    return torch.relu(y * s.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)).float()
+
+
+def deconv_phase_weights(wt: torch.Tensor):
+    """ConvTranspose2d(k=4,s=2,p=1) weight [I,O,4,4] -> four 2x2 convs (sub-pixel form).
+
+    out[2y+py, 2x+px] = sum_{a,b in {0,1}} W[i,o,ky(py,a),kx(px,b)] * in[y+a-pad_y, x+b-pad_x]
+    with ky(0,a) = 3-2a, pad 1 (rows y-1, y) and ky(1,a) = 2-2a, pad 0 (rows y, y+1)
+    (nn.ConvTranspose2d semantics).  Yields (py, px, pad_y, pad_x, W_phase[O,I,2,2]).
+    """
+    wt = wt.detach().float().cpu()
+    for py in (0, 1):
+        kys = [3, 1] if py == 0 else [2, 0]
+        for px in (0, 1):
+            kxs = [3, 1] if px == 0 else [2, 0]
+            w = wt[:, :, kys, :][:, :, :, kxs]            # [I,O,2,2]
+            yield py, px, 1 - py, 1 - px, w.permute(1, 0, 2, 3).contiguous()
+
+
+def record_rsgnet(p: Plan, model) -> None:
+    cfg = model.cfg.MODEL
+    W, H = cfg.IMAGE_SIZE
+    J, L = cfg.NUM_JOINTS, cfg.NUM_LIMBS
+    c0 = cfg.EXTRA["OUTPUT_CONVS"][0]
+    if c0 != 32:
+        raise NotImplementedError(f"RSGNet head with C0={c0}: only the W32 head (C0=32) is built so far")
+    if model.scale_factor != 2:
+        raise NotImplementedError("UP_SCALE=1")
+    B, dev, lib, dt = p.batch, p.device, p.lib, p.dtype
+    H4, W4 = H // 4, W // 4
+    S = H4 * W4
+    p.H, p.W, p.S, p.C0 = H, W, S, c0
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    vis = p._record_backbone(model, H, W)[0]
+
+    # ---- multi-joint scores: fp32 NCHW for the output path, 16-bit NHWC (J padded to 32) for the type conv
+    p.multi_lo = torch.zeros(B, J, H4, W4, **f32)
+    mfl = model.multi_final_layer
+    scores16 = p.conv(vis, mfl.weight, None, mfl.bias, out_f32=p.multi_lo, name="multi_final_layer")
+
+    # ---- the three clues land in one [.,96] buffer (torch.cat at :982 becomes a channel offset)
+    cat = p.new(H4, W4, 3 * c0, pinned=True, name="clues")
+    p._unit(vis, model.vis_conv[0], model.vis_conv[1], relu=True, out=cat.view(0, c0), name="vis_conv")
+    p.conv(scores16, folded_type_conv_weight(model), model.type_conv[1], None, relu=True,
+           out=cat.view(c0, c0), name="type_conv(folded)")
+    loc = location_features(model)                               # constant: written once, below
+
+    t = p._unit(cat, model.contact_conv[0], model.contact_conv[1], relu=True, name="contact_conv")
+    cat2 = p.new(H4, W4, 2 * c0, name="rel|vis")
+    fvis = cat2.view(c0, c0)
+    p._unit(t, model.predict_contact_net[0], model.predict_contact_net[1], relu=True, out=fvis,
+            name="predict_contact_net")
+    p.fvis = fvis
+
+    # ---- TRP (association.py:280-301)
+    rh = model.relation_head
+    gT = p.new(c0, S, 1, name="gT")
+    p.e32 = torch.zeros(B, S, c0, **f32)
+    wg = p._dev(rh.g.weight.detach().float().cpu().reshape(c0, c0).numpy())
+    bg = p._dev(rh.g.bias.detach().float().cpu().numpy())
+    ww = p._dev(rh.W[0].weight.detach().float().cpu().reshape(c0, c0).numpy())
+    bw = p._dev(rh.W[0].bias.detach().float().cpu().numpy())
+    gam = p._dev(rh.W[1].weight.detach().float().cpu().numpy())
+    bet = p._dev(rh.W[1].bias.detach().float().cpu().numpy())
+    if abs(rh.W[1].eps - BN_EPS) > 0:
+        raise NotImplementedError("GroupNorm eps != 1e-5")
+
+    def make_g():
+        a = (fvis.ptr(), fvis.ld, wg.data_ptr(), bg.data_ptr(), gT.ptr(), None, B, S, c0, dt)
+        return lambda s: hip.check(lib.rsg_trp_project_g(*a, s), "trp_project_g")
+
+    def make_attn():
+        a = (fvis.ptr(), fvis.ld, gT.ptr(), None, p.e32.data_ptr(), B, S, c0, dt)
+        return lambda s: hip.check(lib.rsg_trp_attention(*a, s), "trp_attention")
+
+    rel = cat2.view(0, c0)
+
+    def make_tail():
+        a = (p.e32.data_ptr(), ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
+             rel.ld, B, S, c0, dt)
+        return lambda s: hip.check(lib.rsg_trp_tail(*a, s), "trp_tail")
+
+    p.custom("trp_project_g", [fvis], [gT], make_g)
+    p.custom("trp_attention", [fvis, gT], [], make_attn)
+    p.custom("trp_tail", [], [rel], make_tail)
+    p.flops += B * (2 * 2 * S * S * c0 + 2 * 2 * S * c0 * c0)
+
+    # ---- joints-of-target branch (:991-1000)
+    k = p._unit(cat2, model.kpt_net[0], model.kpt_net[1], relu=True, name="kpt_net")
+    dc, dbn = model.predict_convtranspose[0], model.predict_convtranspose[1]
+    k2 = p.new(2 * H4, 2 * W4, c0, name="deconv")
+    for py, px, pad_y, pad_x, wph in deconv_phase_weights(dc.weight):
+        p.conv(k, wph, dbn, None, relu=True, out=k2, pad=(pad_y, pad_x), up=(2, py, px),
+               out_hw=(H4, W4), phys_hw=(2 * H4, 2 * W4), name=f"deconv.phase{py}{px}")
+    k3 = p._unit(k2, model.predict_net[0], model.predict_net[1], relu=True, name="predict_net")
+    p.kpt = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
+    fl = model.final_layer
+    p.conv(k3, fl.weight, None, fl.bias, out_f32=p.kpt, want16=False, name="final_layer")
+
+    # ---- limbs branch = SGM (:1003-1013)
+    lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net")
+    p.limbs_lo = torch.zeros(B, L, H4, W4, **f32)
+    p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
+
+    p.multi_up = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
+    p.limbs = torch.zeros(B, L, 2 * H4, 2 * W4, **f32)
+
+    def make_up(src, dst, planes, sig):
+        a = (src.data_ptr(), dst.data_ptr(), planes, H4, W4, sig)
+        return lambda: (lambda s: hip.check(lib.rsg_bilinear2x_nchw_f32(*a, s), "bilinear2x"))
+
+    p.custom("bilinear2x(multi)", [], [], make_up(p.multi_lo, p.multi_up, B * J, 0))
+    p.custom("bilinear2x+sigmoid(limbs)", [], [], make_up(p.limbs_lo, p.limbs, B * L, 1))
+
+    # the constant location clue: filled once, right after allocation, for every crop slot
+    orig_finalize = p.finalize
+
+    def finalize_with_loc():
+        orig_finalize()
+        dst = cat.tensor(B)[..., 2 * c0: 3 * c0]
+        dst.copy_(loc[0].permute(1, 2, 0).to(dev).to(p.tdtype).unsqueeze(0).expand(B, -1, -1, -1))
+
+    p.finalize = finalize_with_loc
+
+    # ---- on-demand relation outputs -----------------------------------------------------------------
+    def relation_scores() -> torch.Tensor:
+        out = torch.empty(B, S, S, **f32)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        hip.check(lib.rsg_trp_scores(fvis.ptr(), fvis.ld, out.data_ptr(), B, S, c0, dt, st), "trp_scores")
+        return out
+
+    def relation_mse(target: torch.Tensor) -> torch.Tensor:
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if target.dim() == 2:          # factored target p (T = p p^T): fused, nothing materialised
+            pv = target.to(dev, torch.float32).contiguous()
+            out = torch.empty(B, **f32)
+            hip.check(lib.rsg_trp_relation_mse(fvis.ptr(), fvis.ld, pv.data_ptr(), out.data_ptr(), B, S, c0,
+                                               dt, st), "trp_relation_mse")
+            return out
+        # reference-shaped [B,S,S] target (lib/core/function.py:269): compatibility path, materialises R
+        r = relation_scores()
+        return ((target.to(dev, torch.float32) - r) ** 2).mean(dim=(1, 2))
+
+    p.relation_scores = relation_scores
+    p.relation_mse = relation_mse

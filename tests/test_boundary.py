@@ -1,0 +1,89 @@
+"""Drop-in boundary: constructor surface, cfg handling, state_dict names, loud failure off-GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from rsgnet_amd import as_cfg, hip, make_cfg, models
+from tests.util import ROOT, TAGS, manifest
+
+
+@pytest.mark.parametrize("tag", list(TAGS))
+def test_state_dict_matches_reference_manifest(tag):
+    name, width, wh, joints = TAGS[tag]
+    m = getattr(models, name).get_pose_net(make_cfg(name, width, wh, joints), is_train=False)
+    want = manifest(tag)["state_dict"]
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert list(got) == list(want)            # same names, same order
+    assert got == want
+
+
+def test_w48_builds_with_list_valued_num_type_vector():
+    cfg = make_cfg("pose_rsgnet", 48, (288, 384))
+    raw = {"MODEL": dict(cfg.MODEL)}
+    raw["MODEL"]["NUM_TYPE_VECTOR"] = [600]          # the malformed shipped yaml
+    m = models.pose_rsgnet.get_pose_net(raw, is_train=False)
+    assert m.type_fc[0].weight.shape == (600, 600)
+    assert m.relation_head.W[1].num_groups == 8 and m.relation_head.W[1].num_channels == 48
+
+
+def test_cfg_item_and_attr_access():
+    cfg = as_cfg({"MODEL": {"NAME": "pose_hrnet", "EXTRA": make_cfg().MODEL.EXTRA}})
+    assert cfg.MODEL.EXTRA.STAGE2.NUM_CHANNELS == cfg["MODEL"]["EXTRA"]["STAGE2"]["NUM_CHANNELS"] == [32, 64]
+    assert cfg.MODEL.NUM_JOINTS == 17 and cfg.MODEL.UDP_POSE_ON is False
+
+
+def test_branch_mismatch_raises_value_error():
+    cfg = make_cfg()
+    cfg.MODEL.EXTRA.STAGE3.NUM_BLOCKS = [4, 4]
+    with pytest.raises(ValueError):
+        models.pose_hrnet.get_pose_net(cfg, False)
+
+
+def test_missing_pretrained_raises_value_error(tmp_path):
+    cfg = make_cfg()
+    cfg.MODEL.PRETRAINED = str(tmp_path / "nope.pth")
+    with pytest.raises(ValueError):
+        models.pose_hrnet.get_pose_net(cfg, is_train=True)
+
+
+def test_init_weights_partial_load(tmp_path):
+    cfg = make_cfg("pose_rsgnet")
+    src = models.pose_rsgnet.get_pose_net(cfg, False)
+    path = tmp_path / "w.pth"
+    torch.save(src.state_dict(), path)
+    cfg.MODEL.PRETRAINED = str(path)
+    m = models.pose_rsgnet.get_pose_net(cfg, is_train=True)
+    assert torch.equal(m.stage3[1].branches[2][0].conv1.weight, src.stage3[1].branches[2][0].conv1.weight)
+    assert not torch.equal(m.vis_conv[0].weight, src.vis_conv[0].weight)     # head is not in PRETRAINED_LAYERS
+    assert float(m.vis_conv[0].weight.std()) < 2e-3                           # N(0, 1e-3) init
+
+
+def test_forward_off_gpu_fails_loudly():
+    m = models.pose_hrnet.get_pose_net(make_cfg(), False).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 256, 192))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = hip.lib()
+    header = open(os.path.join(ROOT, "include", "rsgnet_hip.h")).read()
+    declared = set(re.findall(r"\b(rsg_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
+    raw = ctypes.CDLL(hip.lib_path())
+    for name in declared:
+        assert getattr(raw, name) is not None
+    assert lib.rsg_version() >= 1
+
+
+def test_product_package_never_imports_oracle():
+    bad = []
+    for dp, _d, files in os.walk(os.path.join(ROOT, "rsgnet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle", src, re.M):
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,258 @@
+"""GPU parity of every HIP kernel family against torch-CPU fp32 restatements, through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from rsgnet_amd import hip
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def run_conv(x_nchw, w, scale=None, shift=None, bias=None, *, stride=1, relu=False, residual=None,
+             want_f32=False, tile_hint=0, in_pad_extra=0, dtype="fp16"):
+    """x_nchw fp32 [B,Cin,H,W] (CPU) -> (out16 as fp32 NCHW, out32) computed by rsg_conv_igemm."""
+    lib = hip.lib()
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    B, Cin, H, W = x_nchw.shape
+    O, _, kh, kw = w.shape
+    cin_pad = lib.rsg_conv_padded_cin(Cin)
+    ld = cin_pad + in_pad_extra
+    xin = torch.zeros(B, H, W, ld, dtype=tdt)
+    xin[..., :Cin] = x_nchw.permute(0, 2, 3, 1).to(tdt)
+    xin = xin.to(DEV)
+    wp = np.zeros(lib.rsg_conv_packed_bytes(Cin, O, kh, kw), np.uint8)
+    cpad = (O + 31) // 32 * 32
+    bo = np.zeros(cpad, np.float32)
+    ptr = lambda a: None if a is None else a.ctypes.data
+    wn = np.ascontiguousarray(w.numpy())
+    sn = None if scale is None else np.ascontiguousarray(scale.numpy())
+    hn = None if shift is None else np.ascontiguousarray(shift.numpy())
+    bn = None if bias is None else np.ascontiguousarray(bias.numpy())
+    hip.check(lib.rsg_pack_conv_weights_host(wn.ctypes.data, ptr(sn), ptr(hn), ptr(bn), Cin, O, kh, kw,
+                                             hip.DTYPES[dtype], wp.ctypes.data, bo.ctypes.data))
+    wpd, bod = torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+    pad = (kh - 1) // 2
+    Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    out = torch.full((B, Ho, Wo, cpad), float("nan"), dtype=tdt, device=DEV)
+    out32 = torch.full((B, O, Ho, Wo), float("nan"), dtype=torch.float32, device=DEV) if want_f32 else None
+    res = None
+    if residual is not None:
+        res = torch.zeros(B, Ho, Wo, cpad, dtype=tdt)
+        res[..., :O] = residual.permute(0, 2, 3, 1).to(tdt)
+        res = res.to(DEV)
+    d = hip.ConvDesc()
+    d.inp, d.w_packed, d.bias = xin.data_ptr(), wpd.data_ptr(), bod.data_ptr()
+    d.residual = res.data_ptr() if res is not None else None
+    d.out16 = out.data_ptr()
+    d.out_nchw_f32 = out32.data_ptr() if want_f32 else None
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, H, W, cin_pad, ld
+    d.out_h, d.out_w, d.out_c, d.out_ld, d.res_ld = Ho, Wo, O, cpad, cpad
+    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = kh, kw, stride, pad, pad
+    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, Ho, Wo
+    d.relu, d.dtype, d.tile_hint = int(relu), hip.DTYPES[dtype], tile_hint
+    hip.check(lib.rsg_conv_igemm(C.byref(d), _stream()), "conv")
+    torch.cuda.synchronize()
+    o16 = out.float().cpu().permute(0, 3, 1, 2)
+    return o16, (out32.cpu() if want_f32 else None)
+
+
+def ref_conv(x, w, scale, shift, bias, stride, relu, residual, dtype=torch.float16):
+    """What the kernel computes, in fp64 on the CPU: 16-bit-rounded inputs and folded weights."""
+    xq = x.to(dtype).double()
+    wf = w.double() * (scale.double().view(-1, 1, 1, 1) if scale is not None else 1.0)
+    wq = wf.float().to(dtype).double()
+    b = torch.zeros(w.shape[0], dtype=torch.float64)
+    if bias is not None:
+        b = b + bias.double() * (scale.double() if scale is not None else 1.0)
+    if shift is not None:
+        b = b + shift.double()
+    y = F.conv2d(xq, wq, b, stride=stride, padding=(w.shape[-1] - 1) // 2)
+    if residual is not None:
+        y = y + residual.to(dtype).double()
+    return F.relu(y) if relu else y
+
+
+CONV_CASES = [
+    # B, Cin, Cout, H, W, k, stride, relu, residual        -- the HRNet-W32 256x192 shapes ...
+    (2, 3, 64, 32, 24, 3, 2, True, False),       # stem conv1 (3 -> padded 16)
+    (2, 64, 64, 32, 24, 3, 2, True, False),      # stem conv2
+    (2, 64, 64, 64, 48, 1, 1, True, False),      # layer1 1x1
+    (2, 64, 256, 16, 12, 1, 1, True, True),      # layer1 expand + residual
+    (2, 256, 64, 16, 12, 1, 1, True, False),     # layer1 reduce (4 channel blocks)
+    (1, 256, 32, 64, 48, 3, 1, True, False),     # transition1.0
+    (2, 32, 32, 64, 48, 3, 1, True, True),       # branch 0 BasicBlock conv2
+    (2, 64, 64, 32, 24, 3, 1, True, True),       # branch 1
+    (2, 128, 128, 16, 12, 3, 1, True, True),     # branch 2
+    (3, 256, 256, 8, 6, 3, 1, True, True),       # branch 3
+    (2, 32, 64, 64, 48, 3, 2, False, False),     # fuse down, last step (no ReLU)
+    (2, 128, 32, 16, 12, 1, 1, False, False),    # fuse up 1x1
+    (2, 96, 96, 16, 12, 3, 1, True, False),      # contact_conv
+    (2, 17, 32, 16, 12, 3, 1, True, False),      # folded type conv (17 -> padded 32)
+    (2, 32, 32, 128, 96, 3, 1, True, False),     # predict_net
+    # ... and ragged / odd tails
+    (1, 32, 32, 7, 5, 3, 1, True, True),
+    (2, 64, 64, 13, 9, 3, 2, True, False),
+    (1, 48, 48, 12, 9, 3, 1, True, True),        # W48 width (CINB=16 path)
+    (2, 32, 32, 1, 1, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_igemm_matches_cpu(case):
+    B, Cin, Cout, H, W, k, stride, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+    got16, got32 = run_conv(x, w, scale, shift, None, stride=stride, relu=relu, residual=res, want_f32=True)
+    want = ref_conv(x, w, scale, shift, None, stride, relu, res)
+    tol32 = 1e-4 * float(want.abs().max()) + 1e-5          # fp32 accumulation-order differences only
+    assert float((got32.double() - want).abs().max()) <= tol32, "fp32 NCHW output"
+    err16 = (got16[:, :Cout].double() - want).abs()
+    assert float((err16 - want.abs() * 2.0 ** -10).max()) <= tol32, "16-bit NHWC output"
+    if got16.shape[1] > Cout:
+        assert float(got16[:, Cout:].abs().max()) == 0.0, "padding channels must be written as zeros"
+
+
+def test_conv_bias_only_classifier_and_bf16():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 16, 12, generator=g)
+    w = torch.randn(17, 32, 1, 1, generator=g) * 0.2
+    b = torch.randn(17, generator=g)
+    _o16, o32 = run_conv(x, w, None, None, b, want_f32=True)
+    want = ref_conv(x, w, None, None, b, 1, False, None)
+    assert float((o32.double() - want).abs().max()) < 1e-4
+    _o16, o32 = run_conv(x, w, None, None, b, want_f32=True, dtype="bf16")
+    want = ref_conv(x, w, None, None, b, 1, False, None, dtype=torch.bfloat16)
+    assert float((o32.double() - want).abs().max()) < 1e-4
+
+
+def test_conv_reads_channel_slice_of_wider_buffer():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 32, 16, 12, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    o16, _ = run_conv(x, w, in_pad_extra=64)
+    want = ref_conv(x, w, None, None, None, 1, False, None)
+    assert float((o16.double() - want).abs().max()) < 2e-3 * float(want.abs().max())
+
+
+def test_conv_rejects_bad_descriptors():
+    lib = hip.lib()
+    d = hip.ConvDesc()
+    assert lib.rsg_conv_igemm(C.byref(d), None) != 0
+    assert b"null" in lib.rsg_last_error()
+
+
+def test_nchw_to_nhwc16():
+    lib = hip.lib()
+    x = torch.randn(3, 3, 10, 6)
+    out = torch.full((3, 10, 6, 16), float("nan"), dtype=torch.float16, device=DEV)
+    xd = x.to(DEV)
+    hip.check(lib.rsg_nchw_f32_to_nhwc16(xd.data_ptr(), out.data_ptr(), 3, 3, 10, 6, 16, 0, _stream()))
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert torch.equal(o[..., :3], x.permute(0, 2, 3, 1).half()) and not o[..., 3:].any()
+
+
+def test_hr_fuse_sum():
+    lib = hip.lib()
+    B, H, W, Cc = 2, 16, 8, 32
+    g = torch.Generator().manual_seed(5)
+    same = [torch.randn(B, H, W, Cc, generator=g).half() for _ in range(2)]
+    low = [torch.randn(B, H >> s, W >> s, Cc, generator=g).half() for s in (1, 2, 3)]
+    want = sum(t.float() for t in same)
+    for s, t in zip((1, 2, 3), low):
+        want = want + F.interpolate(t.float().permute(0, 3, 1, 2), scale_factor=2 ** s, mode="nearest").permute(0, 2, 3, 1)
+    want = F.relu(want).half()
+    sd, ld_ = [t.to(DEV) for t in same], [t.to(DEV) for t in low]
+    out = torch.empty(B, H, W, Cc, dtype=torch.float16, device=DEV)
+    sp = (C.c_void_p * 4)(*[t.data_ptr() for t in sd])
+    lp = (C.c_void_p * 3)(*[t.data_ptr() for t in ld_])
+    sh = (C.c_int32 * 3)(1, 2, 3)
+    hip.check(lib.rsg_hr_fuse_sum(sp, 2, lp, sh, 3, out.data_ptr(), B, H, W, Cc, 0, _stream()))
+    torch.cuda.synchronize()
+    assert float((out.cpu().float() - want.float()).abs().max()) <= 2 ** -9 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("sig", [0, 1])
+def test_bilinear2x(sig):
+    lib = hip.lib()
+    x = torch.randn(2, 5, 16, 12)
+    want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    if sig:
+        want = torch.sigmoid(want)
+    xd = x.to(DEV)
+    out = torch.empty(2, 5, 32, 24, device=DEV)
+    hip.check(lib.rsg_bilinear2x_nchw_f32(xd.data_ptr(), out.data_ptr(), 10, 16, 12, sig, _stream()))
+    torch.cuda.synchronize()
+    assert float((out.cpu() - want).abs().max()) < 2e-6
+
+
+def _trp_inputs(B=2, S=256, C_=32, ld=64, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = F.relu(torch.randn(B, S, C_, generator=g)) * 0.35          # post-ReLU features, affinity O(1)
+    buf = torch.zeros(B, S, ld, dtype=torch.float16)
+    buf[..., ld - C_:] = x.half()                                   # slice of a wider (concat) buffer
+    return buf, buf[..., ld - C_:].float()
+
+
+def test_trp_attention_project_tail_scores_mse():
+    lib = hip.lib()
+    B, S, Cc, ld = 2, 256, 32, 64
+    buf, xq = _trp_inputs(B, S, Cc, ld)
+    g = torch.Generator().manual_seed(1)
+    wg, bg = torch.randn(Cc, Cc, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1
+    ww, bw = torch.randn(Cc, Cc, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1
+    gam, bet = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    bufd = buf.to(DEV)
+    xptr = bufd.data_ptr() + (ld - Cc) * 2
+    dev = lambda t: t.contiguous().to(DEV)
+    wgd, bgd, wwd, bwd, gd, bd = map(dev, (wg, bg, ww, bw, gam, bet))
+    gT = torch.zeros(B, Cc, S, dtype=torch.float16, device=DEV)
+    e = torch.zeros(B, S, Cc, device=DEV)
+    out = torch.zeros(B, S, ld, dtype=torch.float16, device=DEV)
+    scores = torch.zeros(B, S, S, device=DEV)
+    st = _stream()
+    hip.check(lib.rsg_trp_project_g(xptr, ld, wgd.data_ptr(), bgd.data_ptr(), gT.data_ptr(), None, B, S, Cc, 0, st))
+    hip.check(lib.rsg_trp_attention(xptr, ld, gT.data_ptr(), None, e.data_ptr(), B, S, Cc, 0, st))
+    hip.check(lib.rsg_trp_tail(e.data_ptr(), wwd.data_ptr(), bwd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                               out.data_ptr(), ld, B, S, Cc, 0, st))
+    hip.check(lib.rsg_trp_scores(xptr, ld, scores.data_ptr(), B, S, Cc, 0, st))
+    p = torch.rand(B, S, generator=g)
+    pd = p.to(DEV)
+    mse = torch.zeros(B, device=DEV)
+    hip.check(lib.rsg_trp_relation_mse(xptr, ld, pd.data_ptr(), mse.data_ptr(), B, S, Cc, 0, st))
+    torch.cuda.synchronize()
+    # CPU restatement (association.py:288-300) in fp64 on the same 16-bit-rounded x
+    xd = xq.double()
+    gref = xd @ wg.double().t() + bg.double()
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    g_unperm = gT.cpu().float().view(B, Cc, S // 16, 16)
+    g_back = torch.empty_like(g_unperm)
+    g_back[..., perm] = g_unperm                      # storage position j holds key perm[j]
+    g_back = g_back.view(B, Cc, S).permute(0, 2, 1)
+    assert float((g_back.double() - gref).abs().max()) < 2 ** -10 * float(gref.abs().max()) + 1e-6
+    R = torch.sigmoid(xd @ xd.transpose(1, 2))
+    assert float((scores.cpu().double() - R).abs().max()) < 2e-6
+    eref = R @ g_back.double()                        # with the 16-bit g the kernel actually used
+    assert float((e.cpu().double() - eref).abs().max()) < 3e-4 * float(eref.abs().max())
+    y = e.cpu().double() @ ww.double().t() + bw.double()
+    y = F.group_norm(y.permute(0, 2, 1).reshape(B, Cc, S, 1), 8, gam.double(), bet.double(), 1e-5)
+    y = y.reshape(B, Cc, S).permute(0, 2, 1)
+    got = out.cpu()[..., :Cc].double()
+    assert float((got - y).abs().max()) < 2 ** -9 * float(y.abs().max())
+    assert not out.cpu()[..., Cc:].any()              # the neighbouring slice is untouched
+    mref = ((p.double()[:, :, None] * p.double()[:, None, :] - R) ** 2).mean(dim=(1, 2))
+    assert float((mse.cpu().double() - mref).abs().max()) < 1e-5
