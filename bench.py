@@ -46,9 +46,10 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0):
     """The CPU oracle (port of the reference's torch-CPU forward) timed on this box's host cores."""
     from oracle import pose_oracle as po
     from rsgnet_amd.weights import synth_input
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+    # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only thrash)
+    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
     torch.set_num_threads(cores)
-    b = 8
+    b = 4
     x = synth_input(b, wh, 1)
     fwd = (lambda: po.hrnet_forward(sd, cfg, x)) if cfg.MODEL.NAME == "pose_hrnet" else \
           (lambda: po.rsgnet_forward(sd, cfg, x, want_scores=True))
@@ -153,7 +154,7 @@ def main():
         gflop = GFLOP_PER_IMG[a.workload]
         # roofline of the dominant kernel family (conv_igemm_kernel: >95% of device time): algorithmic
         # FLOPs of one step / device time of one step measured with HIP events on the launch stream
-        ach = gflop * batch / (dev_ms / a.steps) / 1e3 * 1e0   # GFLOP / ms = TFLOP/s
+        ach = gflop * batch / (dev_ms / a.steps)                 # GFLOP / ms = TFLOP/s
         line = {
             "metric": "images/sec HRNet-W32 256x192 bs64 fwd" if a.workload.startswith("hrnet") else
                       "images/sec RSGNet-W32 256x192 bs64 fwd",

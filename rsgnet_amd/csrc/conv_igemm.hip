@@ -241,7 +241,8 @@ static int choose_tile(const rsg_conv_desc* d, TilePlan& best) {
     static const int nts[3][3] = {{3, 1, 0}, {3, 1, 0}, {2, 0, 0}};   // per WM = 1, 2, 4
     const int* ntl = nts[WM == 1 ? 0 : (WM == 2 ? 1 : 2)];
     static const int tws[] = {0, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4};
-    double best_score = -1;
+    double best_score = -1e30;
+    bool found = false;
     for (int i = 0; i < 3 && ntl[i]; ++i) {
         const int NT = ntl[i], cap = 32 * NT * WN;
         for (int tw : tws) {
@@ -262,10 +263,10 @@ static int choose_tile(const rsg_conv_desc* d, TilePlan& best) {
             // MFMA utilisation, with a mild preference for less halo re-read and conflict-free widths
             const double halo = (double)(t.TIH * t.TIW) / (t.TH * t.TW * d->stride * d->stride);
             double score = useful / spent - 0.02 * halo + (t.TW >= 16 ? 0.01 : 0.0);
-            if (score > best_score) { best_score = score; best = t; }
+            if (score > best_score) { best_score = score; best = t; found = true; }
         }
     }
-    if (best_score < 0) RSG_FAIL("conv: no tile fits (cin=%d cout=%d %dx%d k%d s%d)", d->in_c, d->out_c,
+    if (!found) RSG_FAIL("conv: no tile fits (cin=%d cout=%d %dx%d k%d s%d)", d->in_c, d->out_c,
                                  d->out_h, d->out_w, d->kh, d->stride);
     return 0;
 }

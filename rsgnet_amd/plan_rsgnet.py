@@ -97,7 +97,8 @@ def record_rsgnet(p: Plan, model) -> None:
     # ---- the three clues land in one [.,96] buffer (torch.cat at :982 becomes a channel offset)
     cat = p.new(H4, W4, 3 * c0, pinned=True, name="clues")
     p._unit(vis, model.vis_conv[0], model.vis_conv[1], relu=True, out=cat.view(0, c0), name="vis_conv")
-    p.conv(scores16, folded_type_conv_weight(model), model.type_conv[1], None, relu=True,
+    # the conv reads the first padded_cin(J) channels of the 32-wide score map (14 -> 16, 17 -> 32)
+    p.conv(scores16.view(0, lib.rsg_conv_padded_cin(J)), folded_type_conv_weight(model), model.type_conv[1], None, relu=True,
            out=cat.view(c0, c0), name="type_conv(folded)")
     loc = location_features(model)                               # constant: written once, below
 

@@ -1,11 +1,13 @@
 """End-to-end parity on the GPU: the drop-in models against the reference-captured goldens."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import pose_oracle as po
 from oracle.make_goldens import sample_index
-from tests.util import TAGS, load_case, maxabs
+from tests.util import ROOT, TAGS, load_case, maxabs
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +23,14 @@ ABS_TOL = 1e-3
 
 def _stats(name, got, ref):
     e = maxabs(got, ref)
-    print(f"   {name}: max-abs {e:.3e}  |ref|max {float(np.abs(ref).max()):.3f}  std {float(np.std(ref)):.3f}")
+    line = f"{name}: max-abs {e:.3e}  |ref|max {float(np.abs(ref).max()):.3f}  std {float(np.std(ref)):.3f}"
+    print("   " + line)
+    try:       # keep the numbers of a GPU-box visit (gpurun_out/ is merged back)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
     return e
 
 
@@ -93,7 +102,8 @@ def test_rsgnet_w32_golden(tag):
     idx = sample_index(3072)
     e = _stats("relation_scores samples", R[:, idx[:, 0], idx[:, 1]].cpu(), gold["relation_scores_samples"])
     assert e < 2e-2
-    assert maxabs(R.sum(dim=2).cpu(), gold["relation_scores_rowsum"]) < 2e-2 * 3072 ** 0.5 * 4
+    rs = gold["relation_scores_rowsum"]                       # sums of 3072 correlated terms
+    assert maxabs(R.sum(dim=2).cpu(), rs) < 1e-2 * float(np.abs(rs).max())
     # training tail with the factored target
     p = torch.from_numpy(gold["relation_target_vec"]).cuda()
     with torch.no_grad():
