@@ -57,7 +57,7 @@ typedef struct rsg_conv_desc {
     int32_t up, up_y, up_x, phys_h, phys_w;
     int32_t relu;
     int32_t dtype;             /* RSG_F16 | RSG_BF16 */
-    int32_t tile_hint;         /* 0 = auto; else (WM<<16)|(NT<<8)|TH<<4.. see rsg_conv_plan */
+    int32_t tile_hint;         /* 0 = auto; else WM | NT<<4 | TH<<8 | TW<<16 (tuning/tests) */
     int32_t reserved;
 } rsg_conv_desc;
 
@@ -76,6 +76,20 @@ size_t rsg_conv_packed_bytes(int32_t cin, int32_t cout, int32_t kh, int32_t kw);
 int rsg_pack_conv_weights_host(const float* w_oihw_host, const float* scale_host, const float* shift_host,
                                const float* conv_bias_host, int32_t cin, int32_t cout, int32_t kh,
                                int32_t kw, int32_t dtype, void* w_packed_host, float* bias_host);
+
+/* ---- fused BasicBlock chain -----------------------------------------------------------------
+ * x = branches[i](x) of a HighResolutionModule (pose_hrnet.py:254-255): nlayers = 2*nblocks 3x3 convs
+ * C->C (BatchNorm folded, ReLU after each, block input added before every second ReLU), with the
+ * activation tile resident in LDS for the whole chain.  in/out: dense NHWC 16-bit [batch,h,w,c],
+ * in != out.  w_packed[l], bias[l]: per-layer device pointers from rsg_pack_conv_weights_host
+ * (HOST arrays of nlayers device pointers).  c in {32,64,128,256}.
+ * rsg_basic_chain_supported returns 1 when (c,h,w,nlayers) can run and fills
+ * info4 = {tile rows, images per workgroup, LDS bytes, workgroups}. */
+int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, const float* const* bias,
+                    int32_t nlayers, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t dtype,
+                    void* stream);
+int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
+                              int32_t* info4);
 
 /* ---- layout / elementwise -------------------------------------------------------------------- */
 /* x.float NCHW -> NHWC 16-bit with channels zero-padded to c_pad (input of the stem conv,

@@ -1,0 +1,259 @@
+// LDS-resident chain of BasicBlocks for gfx950 (MI355X).
+//
+// Replaces  x = branches[i](x)  of HighResolutionModule.forward
+// (/root/reference/lib/models/pose_hrnet.py:254-255; BasicBlock :30-59): L = 2*nblocks 3x3 convs C->C
+// with BatchNorm folded, ReLU after every conv and the block input added before the second ReLU.
+//
+// The per-conv kernel (conv_igemm.hip) pays an HBM round trip per conv: ~38 MB moved for 3.6 GFLOP.
+// Here a workgroup keeps its activation tile in ONE LDS image for the whole chain:
+//   * whole-image mode (rows == H): `ni` complete images per workgroup, no halo, any chain length
+//     (64x24x32 ... 8x6x256 maps of HRNet branches 1-3 fit: 127 / 69 / 84 KB);
+//   * row-tile mode: `rows` output rows + L halo rows each side (branch 0: 64x48x32 does not fit), the
+//     outer rows are recomputed by the neighbouring tile.
+// Each layer runs IN PLACE: all waves accumulate their output tiles from the image (k-loop), barrier,
+// write the 16-bit results back over it, barrier.  The residual of a block never leaves registers: a
+// wave owns the same (32 couts x 32 pixels) tiles in every layer, so it reads them once at the start
+// of the block.  Rows outside the image are re-zeroed after every layer (zero padding of each conv).
+// MFMA mapping, weight packing and LDS pixel layout are those of conv_igemm.hip.
+#include "common.h"
+
+#define RSG_CHAIN_MAX_LAYERS 8
+
+struct ChainArgs {
+    const char* in;
+    char* out;
+    const uint4* wpk[RSG_CHAIN_MAX_LAYERS];
+    const float* bias[RSG_CHAIN_MAX_LAYERS];
+    int nlayers;
+    int B, H, W;
+    int TH;       // output rows per tile
+    int R;        // rows held per image slot = TH + 2*halo
+    int halo;     // = nlayers in row-tile mode, 0 in whole-image mode
+    int NI;       // images per workgroup (whole-image mode), else 1
+    int tiles_y;
+};
+
+template <class DT, int C, int WM, int WN, int NT>
+__global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int CINB = (C % 64 == 0) ? 64 : 32;      // same k order as rsg_pack_conv_weights_host
+    constexpr int NCH = C / CINB, KPT = CINB / 16;
+    constexpr int KS = NCH * 9 * KPT;
+    constexpr int PS = 2 * C + 16;                       // LDS bytes per pixel
+    constexpr int CPP = C / 8;                           // 16-byte chunks per pixel
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int n = lane & 31, hh = lane >> 5;
+    const int W = p.W, R = p.R;
+    const int RP = (W + 2) * PS;                         // LDS row pitch (one zero pixel left and right)
+    const int slot_rows = R + 2;                         // + one zero row above and below
+
+    const int tile = blockIdx.x % p.tiles_y;
+    const int b0 = (blockIdx.x / p.tiles_y) * p.NI;      // first image of this workgroup
+    const int y_first = tile * p.TH - p.halo;            // image row held in slot row 0 (+1 border)
+
+    // ---- zero the whole image (borders, rows outside the picture), then stage the input ------------
+    const int lds_bytes = p.NI * slot_rows * RP;
+    for (int o = tid * 16; o < lds_bytes; o += NTHR * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int chunks_per_img = R * W * CPP;
+    for (int id = tid; id < p.NI * chunks_per_img; id += NTHR) {
+        const int i = id / chunks_per_img, rem = id - i * chunks_per_img;
+        const int pix = rem / CPP, cg = rem - pix * CPP;
+        const int r = pix / W, x = pix - r * W;
+        const int y = y_first + r, b = b0 + i;
+        if (y >= 0 && y < p.H && b < p.B) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p.in + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2);
+            *reinterpret_cast<uint4*>(smem + ((i * slot_rows + r + 1) * (W + 2) + x + 1) * PS + cg * 16) = v;
+        }
+    }
+
+    // ---- this lane's pixels ---------------------------------------------------------------------------
+    int pixoff[NT];     // LDS byte address of the pixel (centre tap), + lane-half offset
+    bool live[NT];      // pixel exists in this workgroup's tile
+    bool inside[NT];    // ... and lies inside the picture (else it must stay zero)
+    const int npix = p.NI * R * W;
+#pragma unroll
+    for (int g = 0; g < NT; ++g) {
+        const int q = (wn * NT + g) * 32 + n;
+        live[g] = q < npix;
+        const int qq = live[g] ? q : 0;
+        const int i = qq / (R * W), rem = qq - i * (R * W);
+        const int r = rem / W, x = rem - r * W;
+        const int y = y_first + r;
+        inside[g] = live[g] && y >= 0 && y < p.H && (b0 + i) < p.B;
+        pixoff[g] = ((i * slot_rows + r + 1) * (W + 2) + x + 1) * PS + hh * 16;
+    }
+    const int cbase = wm * 32 + hh * 16;                 // this lane's 16 output channels
+    __syncthreads();
+
+    uint4 res[NT][2];                                    // block input at this lane's pixels/channels
+    for (int l = 0; l < p.nlayers; ++l) {
+        if ((l & 1) == 0) {
+#pragma unroll
+            for (int g = 0; g < NT; ++g) {
+                res[g][0] = *reinterpret_cast<const uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2);
+                res[g][1] = *reinterpret_cast<const uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2 + 16);
+            }
+        }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int g = 0; g < NT; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+
+        const uint4* ap = p.wpk[l] + (size_t)wm * KS * 64 + lane;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int tapoff = (t / 3 - 1) * RP + (t % 3 - 1) * PS + ch * CINB * 2;
+#pragma unroll
+                for (int c = 0; c < KPT; ++c) {
+                    const uint4 av = ap[((ch * 9 + t) * KPT + c) * 64];
+                    const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, av);
+#pragma unroll
+                    for (int g = 0; g < NT; ++g) {
+                        const uint4 bv = *reinterpret_cast<const uint4*>(smem + pixoff[g] + tapoff + c * 32);
+                        acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc[g]);
+                    }
+                }
+            }
+        }
+
+        // ---- bias (+ block input) + ReLU, zero outside the picture, pack to 16 bit --------------------
+        float bias[16];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias[l] + cbase + r4 * 4);
+            bias[r4 * 4 + 0] = bv.x; bias[r4 * 4 + 1] = bv.y; bias[r4 * 4 + 2] = bv.z; bias[r4 * 4 + 3] = bv.w;
+        }
+        uint4 o[NT][2];
+#pragma unroll
+        for (int g = 0; g < NT; ++g) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const typename DT::vec8 rh = __builtin_bit_cast(typename DT::vec8, res[g][k]);
+                typename DT::vec8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = acc[g][k * 8 + e] + bias[k * 8 + e];
+                    if (l & 1) v += (float)rh[e];
+                    v = inside[g] ? fmaxf(v, 0.f) : 0.f;
+                    ov[e] = (typename DT::elem)v;
+                }
+                o[g][k] = __builtin_bit_cast(uint4, ov);
+            }
+        }
+        __syncthreads();                                 // every wave has finished reading the image
+#pragma unroll
+        for (int g = 0; g < NT; ++g) {
+            if (live[g]) {
+                *reinterpret_cast<uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2) = o[g][0];
+                *reinterpret_cast<uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2 + 16) = o[g][1];
+            }
+        }
+        __syncthreads();                                 // the new image is complete
+    }
+
+    // ---- store the TH output rows of every image slot -----------------------------------------------------
+    const int out_chunks = p.TH * W * CPP;
+    for (int id = tid; id < p.NI * out_chunks; id += NTHR) {
+        const int i = id / out_chunks, rem = id - i * out_chunks;
+        const int pix = rem / CPP, cg = rem - pix * CPP;
+        const int r = pix / W, x = pix - r * W;
+        const int y = tile * p.TH + r, b = b0 + i;
+        if (y < p.H && b < p.B) {
+            const uint4 v = *reinterpret_cast<const uint4*>(
+                smem + ((i * slot_rows + r + p.halo + 1) * (W + 2) + x + 1) * PS + cg * 16);
+            *reinterpret_cast<uint4*>(p.out + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct ChainCfg { int C, WM, WN, NT; };
+static const ChainCfg kChainCfgs[] = {{32, 1, 8, 5}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
+static const int CHAIN_LDS_LIMIT = 160 * 1024;
+
+typedef void (*chain_fn)(const ChainArgs);
+template <class DT>
+static chain_fn chain_lookup(int C) {
+    switch (C) {
+        case 32: return chain_kernel<DT, 32, 1, 8, 5>;
+        case 64: return chain_kernel<DT, 64, 2, 4, 6>;
+        case 128: return chain_kernel<DT, 128, 4, 1, 6>;
+        case 256: return chain_kernel<DT, 256, 8, 1, 3>;
+    }
+    return nullptr;
+}
+
+// Picks (tile rows, images per workgroup) for a chain; returns 0 when the shape is supported.
+static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs& a, int& lds, int& nthr) {
+    const ChainCfg* cfg = nullptr;
+    for (const ChainCfg& c : kChainCfgs) if (c.C == C) cfg = &c;
+    if (!cfg) return 1;
+    const int cap = 32 * cfg->NT * cfg->WN;              // pixels a workgroup can own
+    const int PS = 2 * C + 16;
+    nthr = 64 * cfg->WM * cfg->WN;
+    auto bytes = [&](int ni, int R) { return ni * (R + 2) * (W + 2) * PS; };
+    if (H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
+        int ni = cap / (H * W);
+        while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch)) --ni;
+        a.TH = H; a.R = H; a.halo = 0; a.NI = ni; a.tiles_y = 1;
+        lds = bytes(ni, H);
+        return 0;
+    }
+    // row tiles with halo recompute: the largest R = TH + 2L that fits the pixel capacity and the LDS
+    int R = cap / W;
+    while (R > 2 * nlayers && bytes(1, R) > CHAIN_LDS_LIMIT) --R;
+    int TH = R - 2 * nlayers;
+    if (TH < 4) return 1;
+    const int tiles = ceil_div(H, TH);
+    TH = ceil_div(H, tiles);                              // even the tiles out
+    a.TH = TH; a.R = TH + 2 * nlayers; a.halo = nlayers; a.NI = 1; a.tiles_y = tiles;
+    lds = bytes(1, a.R);
+    return 0;
+}
+
+extern "C" int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
+                                         int32_t* info4) {
+    ChainArgs a;
+    int lds = 0, nthr = 0;
+    if (nlayers < 2 || nlayers > RSG_CHAIN_MAX_LAYERS || (nlayers & 1)) return 0;
+    if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr)) return 0;
+    if (info4) { info4[0] = a.TH; info4[1] = a.NI; info4[2] = lds; info4[3] = ceil_div(batch, a.NI) * a.tiles_y; }
+    return 1;
+}
+
+extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, const float* const* bias,
+                               int32_t nlayers, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t dtype,
+                               void* stream) {
+    if (!in || !out || !w_packed || !bias) RSG_FAIL("basic_chain: null pointer");
+    if (in == out) RSG_FAIL("basic_chain: in-place operation is not supported (row tiles read neighbours' halos)");
+    if (nlayers < 2 || nlayers > RSG_CHAIN_MAX_LAYERS || (nlayers & 1))
+        RSG_FAIL("basic_chain: nlayers=%d must be even and <= %d", nlayers, RSG_CHAIN_MAX_LAYERS);
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    int lds = 0, nthr = 0;
+    if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr))
+        RSG_FAIL("basic_chain: unsupported shape C=%d %dx%d L=%d", c, h, w, nlayers);
+    a.in = (const char*)in; a.out = (char*)out; a.nlayers = nlayers; a.B = batch; a.H = h; a.W = w;
+    for (int l = 0; l < nlayers; ++l) {
+        if (!w_packed[l] || !bias[l]) RSG_FAIL("basic_chain: null weights for layer %d", l);
+        a.wpk[l] = (const uint4*)w_packed[l];
+        a.bias[l] = bias[l];
+    }
+    chain_fn fn = dtype == RSG_BF16 ? chain_lookup<BF16>(c) : chain_lookup<F16>(c);
+    if (!fn) RSG_FAIL("basic_chain: no kernel for C=%d", c);
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        RSG_FAIL("basic_chain: cannot reserve %d B of LDS", lds);
+    dim3 grid(ceil_div(batch, a.NI) * a.tiles_y);
+    hipLaunchKernelGGL(fn, grid, dim3(nthr), lds, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH("basic_chain");
+    return 0;
+}

@@ -79,6 +79,7 @@ class Plan:
         self._vts: List[VT] = []
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.use_graph = os.environ.get("RSGNET_HIP_GRAPH", "1") != "0"
+        self.use_chain = os.environ.get("RSGNET_HIP_CHAIN", "1") != "0"
         self.conv_log: List[dict] = []
         self.flops = 0
 
@@ -175,6 +176,33 @@ class Plan:
         self._rec.append(dict(kind="fuse", same=list(same), low=list(low), out=out, name=name))
         return out
 
+    def chain(self, x: VT, blocks, name="") -> VT:
+        """Record a fused BasicBlock chain (rsg_basic_chain): every conv of ``blocks`` in one launch."""
+        layers = []
+        for blk in blocks:
+            for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
+                scale, shift = self.bn_fold(bn)
+                wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
+                layers.append((wp, bo))
+        out = self.new(x.H, x.W, x.C, name=name)
+        idx = len(self._rec)
+        self._touch(idx, x, out)
+        self._rec.append(dict(kind="chain", x=x, out=out, layers=layers, name=name))
+        self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
+        return out
+
+    def chain_mode(self, C_, H, W, nblocks) -> int:
+        """How many BasicBlocks one rsg_basic_chain launch should take for this map: all of them when
+        whole images fit in LDS, one when the map needs row tiles (halo grows with the chain), 0 = no."""
+        if not self.use_chain:
+            return 0
+        info = (C.c_int32 * 4)()
+        if self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nblocks, self.batch, info) and info[0] == H:
+            return nblocks
+        if self.lib.rsg_basic_chain_supported(C_, H, W, 2, self.batch, info):
+            return 1
+        return 0
+
     def custom(self, name: str, reads: Sequence[VT], writes: Sequence[VT], make: Callable[[], Callable[[int], None]]):
         """Record an op whose launcher is created by ``make()`` after buffers have addresses."""
         idx = len(self._rec)
@@ -264,6 +292,28 @@ class Plan:
 
         self.ops.append((r["name"], launch))
 
+    def _lower_chain(self, r):
+        x, out, layers = r["x"], r["out"], r["layers"]
+        if x.ld != x.C or x.coff or out.ld != out.C or out.coff:
+            raise ValueError("chain operands must be dense tensors")
+        n = len(layers)
+        wps = (C.c_void_p * n)(*[w.data_ptr() for w, _ in layers])
+        bps = (C.c_void_p * n)(*[b.data_ptr() for _, b in layers])
+        self._keep += [wps, bps]
+        args = (x.ptr(), out.ptr(), wps, bps, n, self.batch, x.H, x.W, x.C, self.dtype)
+        fn, nm = self.lib.rsg_basic_chain, r["name"]
+        info = (C.c_int32 * 4)()
+        self.lib.rsg_basic_chain_supported(x.C, x.H, x.W, n, self.batch, info)
+        self.conv_log.append(dict(name=nm, cin=x.C, cout=x.C, k=3, s=1, hw=(x.H, x.W), layers=n,
+                                  chain=list(info)))
+
+        def launch(stream):
+            rc = fn(*args, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((nm, launch))
+
     def _lower_custom(self, r):
         self.ops.append((r["name"], r["make"]()))
 
@@ -326,7 +376,14 @@ class _BackboneMixin:
         """HighResolutionModule.forward (pose_hrnet.py:250-268)."""
         xs = list(xs)
         for b, branch in enumerate(mod.branches):
-            for k, blk in enumerate(branch):
+            blocks = list(branch)
+            plain = all(not hasattr(blk, "conv3") and blk.downsample is None for blk in blocks)
+            step = self.chain_mode(xs[b].C, xs[b].H, xs[b].W, len(blocks)) if plain else 0
+            if step:
+                for k in range(0, len(blocks), step):
+                    xs[b] = self.chain(xs[b], blocks[k:k + step], f"{name}.branches.{b}.chain{k}")
+                continue
+            for k, blk in enumerate(blocks):
                 xs[b] = self._residual_block(xs[b], blk, f"{name}.branches.{b}.{k}")
         if mod.fuse_layers is None:
             return xs
