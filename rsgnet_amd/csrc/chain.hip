@@ -61,15 +61,29 @@ __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) 
     for (int o = tid * 16; o < lds_bytes; o += NTHR * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int chunks_per_img = R * W * CPP;
-    for (int id = tid; id < p.NI * chunks_per_img; id += NTHR) {
-        const int i = id / chunks_per_img, rem = id - i * chunks_per_img;
-        const int pix = rem / CPP, cg = rem - pix * CPP;
-        const int r = pix / W, x = pix - r * W;
-        const int y = y_first + r, b = b0 + i;
-        if (y >= 0 && y < p.H && b < p.B) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p.in + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2);
-            *reinterpret_cast<uint4*>(smem + ((i * slot_rows + r + 1) * (W + 2) + x + 1) * PS + cg * 16) = v;
+    constexpr int NLD = 8;                               // staging loads in flight per thread
+    for (int base = 0; base < p.NI * chunks_per_img; base += NTHR * NLD) {
+        uint4 v[NLD];
+        int lo[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int id = base + j * NTHR + tid;
+            lo[j] = -1;
+            v[j] = make_uint4(0, 0, 0, 0);
+            if (id < p.NI * chunks_per_img) {
+                const int i = id / chunks_per_img, rem = id - i * chunks_per_img;
+                const int pix = rem / CPP, cg = rem - pix * CPP;
+                const int r = pix / W, x = pix - r * W;
+                const int y = y_first + r, b = b0 + i;
+                if (y >= 0 && y < p.H && b < p.B) {
+                    v[j] = *reinterpret_cast<const uint4*>(p.in + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2);
+                    lo[j] = ((i * slot_rows + r + 1) * (W + 2) + x + 1) * PS + cg * 16;
+                }
+            }
         }
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (lo[j] >= 0) *reinterpret_cast<uint4*>(smem + lo[j]) = v[j];
     }
 
     // ---- this lane's pixels ---------------------------------------------------------------------------
@@ -92,6 +106,9 @@ __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) 
     __syncthreads();
 
     uint4 res[NT][2];                                    // block input at this lane's pixels/channels
+    constexpr int NPF = (C >= 128) ? 9 : 6;            // ring depth; must divide KS (18, 36, 72, 144)
+    static_assert(KS % NPF == 0, "prefetch ring must wrap at the layer boundary");
+    uint4 aq[NPF];
     for (int l = 0; l < p.nlayers; ++l) {
         if ((l & 1) == 0) {
 #pragma unroll
@@ -106,23 +123,35 @@ __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
 
+        // A operands: an NPF-deep prefetch ring that keeps running across the layer boundary
         const uint4* ap = p.wpk[l] + (size_t)wm * KS * 64 + lane;
+        const uint4* apn = p.wpk[l + 1 < p.nlayers ? l + 1 : l] + (size_t)wm * KS * 64 + lane;
+        if (l == 0) {
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
+            for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
+        }
+        // k-loop, one scheduling region per k-step (the compiler otherwise sinks the prefetches next to
+        // their uses): issue the A load NPF steps ahead and the B reads one step ahead, then the MFMAs.
+        auto boff = [&](int ks) {
+            const int ch = ks / (9 * KPT), t = (ks / KPT) % 9, c = ks % KPT;
+            return (t / 3 - 1) * RP + (t % 3 - 1) * PS + ch * CINB * 2 + c * 32;
+        };
+        uint4 bq[2][NT];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int tapoff = (t / 3 - 1) * RP + (t % 3 - 1) * PS + ch * CINB * 2;
+        for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
 #pragma unroll
-                for (int c = 0; c < KPT; ++c) {
-                    const uint4 av = ap[((ch * 9 + t) * KPT + c) * 64];
-                    const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, av);
+        for (int ks = 0; ks < KS; ++ks) {
+            const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+            if (ks + 1 < KS) {
 #pragma unroll
-                    for (int g = 0; g < NT; ++g) {
-                        const uint4 bv = *reinterpret_cast<const uint4*>(smem + pixoff[g] + tapoff + c * 32);
-                        acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc[g]);
-                    }
-                }
+                for (int g = 0; g < NT; ++g)
+                    bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
             }
+            aq[ks % NPF] = (ks + NPF < KS) ? ap[(ks + NPF) * 64] : apn[(ks + NPF - KS) * 64];
+#pragma unroll
+            for (int g = 0; g < NT; ++g)
+                acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), acc[g]);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         // ---- bias (+ block input) + ReLU, zero outside the picture, pack to 16 bit --------------------
