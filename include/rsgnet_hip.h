@@ -77,6 +77,20 @@ int rsg_pack_conv_weights_host(const float* w_oihw_host, const float* scale_host
                                const float* conv_bias_host, int32_t cin, int32_t cout, int32_t kh,
                                int32_t kw, int32_t dtype, void* w_packed_host, float* bias_host);
 
+/* ---- HIP graph of a launch list -----------------------------------------------------------------
+ * Between rsg_graph_begin and rsg_graph_end every rsg_* launch made by the calling thread becomes a
+ * kernel node of `*graph` instead of being enqueued (the stream argument is ignored); node ids count
+ * the launches from 0.  rsg_graph_next_deps names the nodes the NEXT launch depends on (none = root).
+ * rsg_graph_end instantiates; rsg_graph_launch replays the whole forward on a stream with one call.
+ * This replaces the reference's per-operator dispatch from Python (lib/core/function.py:121,389). */
+int rsg_graph_begin(void** graph);
+int rsg_graph_next_deps(void* graph, const int32_t* node_ids, int32_t n);
+int rsg_graph_node_count(void* graph);
+int rsg_graph_end(void* graph);
+int rsg_graph_abort(void* graph);
+int rsg_graph_launch(void* graph, void* stream);
+int rsg_graph_destroy(void* graph);
+
 /* ---- fused BasicBlock chain -----------------------------------------------------------------
  * x = branches[i](x) of a HighResolutionModule (pose_hrnet.py:254-255): nlayers = 2*nblocks 3x3 convs
  * C->C (BatchNorm folded, ReLU after each, block input added before every second ReLU), with the

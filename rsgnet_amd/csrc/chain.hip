@@ -282,7 +282,7 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         RSG_FAIL("basic_chain: cannot reserve %d B of LDS", lds);
     dim3 grid(ceil_div(batch, a.NI) * a.tiles_y);
-    hipLaunchKernelGGL(fn, grid, dim3(nthr), lds, (hipStream_t)stream, a);
+    RSG_LAUNCH(fn, grid, dim3(nthr), lds, (hipStream_t)stream, a);
     RSG_CHECK_LAUNCH("basic_chain");
     return 0;
 }

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <tuple>
+#include <utility>
 #include "../../include/rsgnet_hip.h"
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
@@ -19,10 +21,33 @@ extern thread_local char g_rsg_err[512];
         return 1;                                            \
     } while (0)
 
-#define RSG_CHECK_LAUNCH(what)                                                            \
-    do {                                                                                  \
-        hipError_t e__ = hipGetLastError();                                               \
-        if (e__ != hipSuccess) RSG_FAIL("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+// Every kernel launch goes through rsg_launch_raw (graph.hip): a plain hipLaunchKernel, or a kernel node
+// of the HIP graph that is open on this thread.
+extern thread_local int g_rsg_launch_status;
+int rsg_launch_raw(const void* fn, dim3 grid, dim3 block, unsigned lds, hipStream_t stream, void** params);
+
+template <class Tuple, size_t... I>
+static inline void rsg_fill_params(void** p, Tuple& t, std::index_sequence<I...>) {
+    ((p[I] = (void*)&std::get<I>(t)), ...);
+}
+template <class... KArgs, class... Args>
+static inline int rsg_launch(void (*fn)(KArgs...), dim3 grid, dim3 block, unsigned lds, hipStream_t stream,
+                             Args... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+    std::tuple<KArgs...> t{static_cast<KArgs>(args)...};
+    void* params[sizeof...(KArgs)];
+    rsg_fill_params(params, t, std::index_sequence_for<KArgs...>{});
+    return rsg_launch_raw((const void*)fn, grid, block, lds, stream, params);
+}
+#define RSG_LAUNCH(fn, grid, block, lds, stream, ...) rsg_launch(fn, grid, block, lds, stream, __VA_ARGS__)
+
+#define RSG_CHECK_LAUNCH(what)                                                     \
+    do {                                                                           \
+        if (g_rsg_launch_status) {                                                 \
+            char m__[400];                                                         \
+            snprintf(m__, sizeof(m__), "%s", g_rsg_err);                           \
+            RSG_FAIL("%s: launch failed: %s", what, m__);                          \
+        }                                                                          \
     } while (0)
 
 // 16-bit storage types: one struct per dtype so kernels can be templated on it.

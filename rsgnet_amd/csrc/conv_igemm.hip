@@ -341,7 +341,7 @@ extern "C" int rsg_conv_igemm(const rsg_conv_desc* d, void* stream) {
     a.nchunks = d->in_c / t.CINB;
     a.KS = a.nchunks * d->kh * d->kw * (t.CINB / 16);
     dim3 grid(d->batch * t.tiles_y * t.tiles_x, cout_pad / (32 * t.WM));
-    hipLaunchKernelGGL(fn, grid, dim3(256), t.lds, (hipStream_t)stream, a);
+    RSG_LAUNCH(fn, grid, dim3(256), t.lds, (hipStream_t)stream, a);
     RSG_CHECK_LAUNCH("conv_igemm");
     return 0;
 }

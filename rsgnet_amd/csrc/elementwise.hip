@@ -33,10 +33,10 @@ extern "C" int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch,
     const long total = (long)batch * h * w;
     const int grid = (int)((total + 255) / 256);
     if (dtype == RSG_BF16)
-        hipLaunchKernelGGL((nchw_to_nhwc16_kernel<BF16, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        RSG_LAUNCH((nchw_to_nhwc16_kernel<BF16, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            in, (char*)out, c, h * w, total);
     else
-        hipLaunchKernelGGL((nchw_to_nhwc16_kernel<F16, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        RSG_LAUNCH((nchw_to_nhwc16_kernel<F16, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            in, (char*)out, c, h * w, total);
     RSG_CHECK_LAUNCH("nchw_to_nhwc16");
     return 0;
@@ -108,9 +108,9 @@ extern "C" int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const vo
     long blocks = (a.total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (dtype == RSG_BF16)
-        hipLaunchKernelGGL(hr_fuse_kernel<BF16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        RSG_LAUNCH(hr_fuse_kernel<BF16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(hr_fuse_kernel<F16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        RSG_LAUNCH(hr_fuse_kernel<F16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
     RSG_CHECK_LAUNCH("hr_fuse_sum");
     return 0;
 }
@@ -161,7 +161,7 @@ extern "C" int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t plan
     const long total4 = (long)planes * (2 * h) * (2 * w / 4);
     long blocks = (total4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(bilinear2x_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, out, h, w,
+    RSG_LAUNCH(bilinear2x_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, out, h, w,
                        total4, sigmoid);
     RSG_CHECK_LAUNCH("bilinear2x");
     return 0;

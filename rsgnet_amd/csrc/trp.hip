@@ -134,9 +134,9 @@ template <int MODE>
 static int trp_launch(const TrpArgs& a, int batch, int dtype, void* stream) {
     dim3 grid(ceil_div(a.S, 128), batch);
     if (dtype == RSG_BF16)
-        hipLaunchKernelGGL((trp_kernel<BF16, MODE>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        RSG_LAUNCH((trp_kernel<BF16, MODE>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL((trp_kernel<F16, MODE>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        RSG_LAUNCH((trp_kernel<F16, MODE>), grid, dim3(256), 0, (hipStream_t)stream, a);
     RSG_CHECK_LAUNCH("trp");
     return 0;
 }
@@ -220,10 +220,10 @@ extern "C" int rsg_trp_project_g(const void* x, int32_t ld_x, const float* w, co
     const long total = (long)batch * S;
     const int grid = (int)((total + 255) / 256);
     if (dtype == RSG_BF16)
-        hipLaunchKernelGGL(trp_project_g_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        RSG_LAUNCH(trp_project_g_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const char*)x, ld_x, w, bias, (char*)gT_hi, S, total);
     else
-        hipLaunchKernelGGL(trp_project_g_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+        RSG_LAUNCH(trp_project_g_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const char*)x, ld_x, w, bias, (char*)gT_hi, S, total);
     RSG_CHECK_LAUNCH("trp_project_g");
     return 0;
@@ -311,10 +311,10 @@ extern "C" int rsg_trp_tail(const float* e, const float* w, const float* bias, c
     if (out_ld < C || out_ld % 4) RSG_FAIL("trp_tail: out_ld=%d", out_ld);
     dim3 grid(8, batch);
     if (dtype == RSG_BF16)
-        hipLaunchKernelGGL(trp_tail_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, gn_gamma,
+        RSG_LAUNCH(trp_tail_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, gn_gamma,
                            gn_beta, (char*)out, out_ld, S);
     else
-        hipLaunchKernelGGL(trp_tail_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, gn_gamma,
+        RSG_LAUNCH(trp_tail_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, gn_gamma,
                            gn_beta, (char*)out, out_ld, S);
     RSG_CHECK_LAUNCH("trp_tail");
     return 0;

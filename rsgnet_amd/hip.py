@@ -37,6 +37,13 @@ SYMBOLS = {
     "rsg_conv_padded_cin": (C.c_int32, [_i]),
     "rsg_conv_packed_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "rsg_pack_conv_weights_host": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rsg_graph_begin": (C.c_int, [C.POINTER(_vp)]),
+    "rsg_graph_next_deps": (C.c_int, [_vp, C.POINTER(C.c_int32), _i]),
+    "rsg_graph_node_count": (C.c_int, [_vp]),
+    "rsg_graph_end": (C.c_int, [_vp]),
+    "rsg_graph_abort": (C.c_int, [_vp]),
+    "rsg_graph_launch": (C.c_int, [_vp, _vp]),
+    "rsg_graph_destroy": (C.c_int, [_vp]),
     "rsg_basic_chain": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp]),
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_nchw_f32_to_nhwc16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -78,10 +78,40 @@ class Plan:
         self._keep: List[object] = []       # ctypes structs / tensors that must outlive the plan
         self._vts: List[VT] = []
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.use_graph = os.environ.get("RSGNET_HIP_GRAPH", "1") != "0"
+        self.graph_mode = os.environ.get("RSGNET_HIP_GRAPH", "1")
+        self.use_graph = self.graph_mode != "0"
         self.use_chain = os.environ.get("RSGNET_HIP_CHAIN", "1") != "0"
         self.conv_log: List[dict] = []
         self.flops = 0
+        # lanes = HIP streams the launches are spread over (independent HRNet branches run concurrently);
+        # cross-lane ordering comes from events derived from each op's buffer reads/writes
+        self.n_lanes = max(1, min(4, int(os.environ.get("RSGNET_HIP_LANES", "4"))))
+        self._lane = 0
+        self._streams: List[torch.cuda.Stream] = []
+
+    class _LaneCtx:
+        def __init__(self, plan, lane):
+            self.plan, self.lane, self.prev = plan, lane, 0
+
+        def __enter__(self):
+            self.prev = self.plan._lane
+            self.plan._lane = self.lane % self.plan.n_lanes
+            return self
+
+        def __exit__(self, *a):
+            self.plan._lane = self.prev
+
+    def on_lane(self, lane: int) -> "Plan._LaneCtx":
+        return Plan._LaneCtx(self, lane)
+
+    def _record(self, rec: dict, reads, writes) -> int:
+        idx = len(self._rec)
+        rec["lane"] = self._lane
+        rec["reads"] = [v for v in reads if v is not None]
+        rec["writes"] = [v for v in writes if v is not None]
+        self._touch(idx, *[v for v in rec["reads"] + rec["writes"] if isinstance(v, VT)])
+        self._rec.append(rec)
+        return idx
 
     # ------------------------------------------------------------------ recording
     def new(self, H, W, C_, ld=None, pinned=False, name="") -> VT:
@@ -160,20 +190,17 @@ class Plan:
             out = self.new(phys_hw[0], phys_hw[1], cpad, name=name)
         if out is not None and (out.H, out.W) != tuple(phys_hw):
             raise ValueError(f"{name}: output buffer is {out.H}x{out.W}, conv writes {phys_hw}")
-        idx = len(self._rec)
-        self._touch(idx, x, residual, out)
-        self._rec.append(dict(kind="conv", x=x, wp=wp, bias=bo, res=residual, out=out, out_f32=out_f32,
-                              I=cin_pad, O=O, kh=kh, kw=kw, stride=stride, pad=pad, up=up, out_hw=out_hw,
-                              phys_hw=phys_hw, relu=relu, name=name))
+        self._record(dict(kind="conv", x=x, wp=wp, bias=bo, res=residual, out=out, out_f32=out_f32,
+                          I=cin_pad, O=O, kh=kh, kw=kw, stride=stride, pad=pad, up=up, out_hw=out_hw,
+                          phys_hw=phys_hw, relu=relu, name=name), [x, residual], [out, out_f32])
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
 
     def fuse(self, same: Sequence[VT], low: Sequence[Tuple[VT, int]], name="") -> VT:
         ref = same[0]
         out = self.new(ref.H, ref.W, ref.C, name=name)
-        idx = len(self._rec)
-        self._touch(idx, out, *same, *[v for v, _ in low])
-        self._rec.append(dict(kind="fuse", same=list(same), low=list(low), out=out, name=name))
+        self._record(dict(kind="fuse", same=list(same), low=list(low), out=out, name=name),
+                     list(same) + [v for v, _ in low], [out])
         return out
 
     def chain(self, x: VT, blocks, name="") -> VT:
@@ -185,9 +212,7 @@ class Plan:
                 wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
                 layers.append((wp, bo))
         out = self.new(x.H, x.W, x.C, name=name)
-        idx = len(self._rec)
-        self._touch(idx, x, out)
-        self._rec.append(dict(kind="chain", x=x, out=out, layers=layers, name=name))
+        self._record(dict(kind="chain", x=x, out=out, layers=layers, name=name), [x], [out])
         self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
         return out
 
@@ -205,9 +230,7 @@ class Plan:
 
     def custom(self, name: str, reads: Sequence[VT], writes: Sequence[VT], make: Callable[[], Callable[[int], None]]):
         """Record an op whose launcher is created by ``make()`` after buffers have addresses."""
-        idx = len(self._rec)
-        self._touch(idx, *reads, *writes)
-        self._rec.append(dict(kind="custom", make=make, name=name))
+        self._record(dict(kind="custom", make=make, name=name), list(reads), list(writes))
 
     # ------------------------------------------------------------------ allocation + lowering
     def finalize(self):
@@ -234,9 +257,50 @@ class Plan:
             for v in expiring.get(idx, []):
                 free.setdefault(v.nbytes(B) // 2, []).append(v.storage)
         self.arena_bytes = total
+        self._derive_dependencies()
         for r in self._rec:
             getattr(self, "_lower_" + r["kind"])(r)
         self._rec = []
+
+    def _derive_dependencies(self):
+        """Per op: which earlier ops on OTHER lanes it must wait for.  Tracked per physical buffer, so
+        read-after-write, write-after-read and the allocator's buffer reuse are all covered."""
+        def key(v):
+            return v.base.storage.data_ptr() if isinstance(v, VT) else v.data_ptr()
+
+        last_writer: Dict[int, int] = {}
+        readers: Dict[int, List[int]] = {}
+        self._lanes: List[int] = []
+        self._waits: List[List[int]] = []
+        self._all_deps: List[List[int]] = []
+        for i, r in enumerate(self._rec):
+            deps = set()
+            for v in r["reads"]:
+                k = key(v)
+                if k in last_writer:
+                    deps.add(last_writer[k])
+            for v in r["writes"]:
+                k = key(v)
+                if k in last_writer:
+                    deps.add(last_writer[k])
+                deps.update(readers.get(k, ()))
+            for v in r["writes"]:
+                k = key(v)
+                last_writer[k] = i
+                readers[k] = []
+            for v in r["reads"]:
+                readers.setdefault(key(v), []).append(i)
+            deps.discard(i)
+            lane = r["lane"]
+            self._lanes.append(lane)
+            self._all_deps.append(sorted(deps))
+            # same-lane order is implicit; keep only the latest dependency per foreign lane
+            latest: Dict[int, int] = {}
+            for d in deps:
+                ld = self._lanes[d]
+                if ld != lane:
+                    latest[ld] = max(latest.get(ld, -1), d)
+            self._waits.append(sorted(latest.values()))
 
     def _lower_conv(self, r):
         d = hip.ConvDesc()
@@ -318,24 +382,98 @@ class Plan:
         self.ops.append((r["name"], r["make"]()))
 
     # ------------------------------------------------------------------ execution
-    def launch_all(self, stream: Optional[int] = None):
-        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
-        for _, op in self.ops:
-            op(s)
+    def launch_all(self):
+        """Enqueue every op: lane 0 is the caller's current stream, lanes 1.. are side streams that fork
+        from it and join it again (so the whole thing can be captured into one HIP graph)."""
+        main = torch.cuda.current_stream(self.device)
+        if self.n_lanes == 1 or max(self._lanes, default=0) == 0:
+            s = main.cuda_stream
+            for _, op in self.ops:
+                op(s)
+            return
+        while len(self._streams) < self.n_lanes - 1:
+            self._streams.append(torch.cuda.Stream(self.device))
+        streams = [main] + self._streams
+        need_event = set(d for w in self._waits for d in w)
+        keep: List[torch.cuda.Event] = []       # events must outlive a stream capture that uses them
+        self._events_keep = keep
+        fork = torch.cuda.Event()
+        keep.append(fork)
+        fork.record(main)
+        for st in self._streams:
+            st.wait_event(fork)
+        events: Dict[int, torch.cuda.Event] = {}
+        last_on_lane: Dict[int, int] = {}
+        for i, (_, op) in enumerate(self.ops):
+            st = streams[self._lanes[i]]
+            for d in self._waits[i]:
+                st.wait_event(events[d])
+            op(st.cuda_stream)
+            if i in need_event:
+                ev = torch.cuda.Event()
+                keep.append(ev)
+                ev.record(st)
+                events[i] = ev
+            last_on_lane[self._lanes[i]] = i
+        for lane, st in enumerate(streams):
+            if lane:                         # join every side stream (also the ones that only forked)
+                ev = torch.cuda.Event()
+                keep.append(ev)
+                ev.record(st)
+                main.wait_event(ev)
+
+    def _build_hip_graph(self):
+        """One kernel node per op, edges = the data dependencies (librsgnet_hip's explicit graph API)."""
+        g = C.c_void_p()
+        hip.check(self.lib.rsg_graph_begin(C.byref(g)), "graph_begin")
+        try:
+            for i, (name, op) in enumerate(self.ops):
+                deps = self._all_deps[i]
+                arr = (C.c_int32 * max(len(deps), 1))(*deps)
+                hip.check(self.lib.rsg_graph_next_deps(g, arr, len(deps)), "graph_next_deps")
+                op(None)
+                if self.lib.rsg_graph_node_count(g) != i + 1:
+                    raise RuntimeError(f"op {name} did not add exactly one graph node")
+            hip.check(self.lib.rsg_graph_end(g), "graph_end")
+        except Exception:
+            self.lib.rsg_graph_abort(g)
+            self.lib.rsg_graph_destroy(g)
+            raise
+        return g
+
+    def __del__(self):
+        g = getattr(self, "_hipgraph", None)
+        if g is not None:
+            try:
+                self.lib.rsg_graph_destroy(g)
+            except Exception:
+                pass
 
     def _replay(self):
-        if not self.use_graph:
+        """RSGNET_HIP_GRAPH = 1 (default): explicit HIP graph with data-dependency edges;
+        'capture': torch stream capture of the single-stream order; 0: eager launches (lanes = streams)."""
+        mode = self.graph_mode
+        if mode == "0":
             self.launch_all()
             return
-        if self.graph is None:
-            # warm-up launches outside capture (lazy module loading), then capture
-            self.launch_all()
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+        if mode == "capture":
+            if self.graph is None:
+                lanes, self._lanes = self._lanes, [0] * len(self._lanes)   # capture needs one stream
                 self.launch_all()
-            self.graph = g
-        self.graph.replay()
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.launch_all()
+                self._lanes = lanes
+                self.graph = g
+            self.graph.replay()
+            return
+        if getattr(self, "_hipgraph", None) is None:
+            self.launch_all()                      # first touch outside the graph (module loading)
+            torch.cuda.synchronize(self.device)
+            self._hipgraph = self._build_hip_graph()
+        hip.check(self.lib.rsg_graph_launch(self._hipgraph, torch.cuda.current_stream(self.device).cuda_stream),
+                  "graph_launch")
 
 
 # ====================================================================================================
@@ -379,30 +517,32 @@ class _BackboneMixin:
             blocks = list(branch)
             plain = all(not hasattr(blk, "conv3") and blk.downsample is None for blk in blocks)
             step = self.chain_mode(xs[b].C, xs[b].H, xs[b].W, len(blocks)) if plain else 0
-            if step:
-                for k in range(0, len(blocks), step):
-                    xs[b] = self.chain(xs[b], blocks[k:k + step], f"{name}.branches.{b}.chain{k}")
-                continue
-            for k, blk in enumerate(blocks):
-                xs[b] = self._residual_block(xs[b], blk, f"{name}.branches.{b}.{k}")
+            with self.on_lane(b):                 # branches are independent: one stream each
+                if step:
+                    for k in range(0, len(blocks), step):
+                        xs[b] = self.chain(xs[b], blocks[k:k + step], f"{name}.branches.{b}.chain{k}")
+                    continue
+                for k, blk in enumerate(blocks):
+                    xs[b] = self._residual_block(xs[b], blk, f"{name}.branches.{b}.{k}")
         if mod.fuse_layers is None:
             return xs
         outs = []
         for i, row in enumerate(mod.fuse_layers):
             same, low = [], []
-            for j, fl in enumerate(row):
-                if j == i:
-                    same.append(xs[j])
-                elif j > i:
-                    z = self._unit(xs[j], fl[0], fl[1], name=f"{name}.fuse.{i}.{j}")
-                    low.append((z, j - i))
-                else:
-                    t = xs[j]
-                    for k, step in enumerate(fl):
-                        t = self._unit(t, step[0], step[1], relu=(k != len(fl) - 1),
-                                       name=f"{name}.fuse.{i}.{j}.{k}")
-                    same.append(t)
-            outs.append(self.fuse(same, low, name=f"{name}.fuse.{i}"))
+            with self.on_lane(i):                 # one stream per output branch
+                for j, fl in enumerate(row):
+                    if j == i:
+                        same.append(xs[j])
+                    elif j > i:
+                        z = self._unit(xs[j], fl[0], fl[1], name=f"{name}.fuse.{i}.{j}")
+                        low.append((z, j - i))
+                    else:
+                        t = xs[j]
+                        for k, step in enumerate(fl):
+                            t = self._unit(t, step[0], step[1], relu=(k != len(fl) - 1),
+                                           name=f"{name}.fuse.{i}.{j}.{k}")
+                        same.append(t)
+                outs.append(self.fuse(same, low, name=f"{name}.fuse.{i}"))
         return outs
 
     def _record_backbone(self: Plan, m, H: int, W: int) -> List[VT]:
@@ -421,8 +561,9 @@ class _BackboneMixin:
                                                                   name=f"transition{s - 1}.{i}"))
                 else:
                     t = ys[-1]
-                    for j, step in enumerate(tr):
-                        t = self._unit(t, step[0], step[1], relu=True, name=f"transition{s - 1}.{i}.{j}")
+                    with self.on_lane(i):
+                        for j, step in enumerate(tr):
+                            t = self._unit(t, step[0], step[1], relu=True, name=f"transition{s - 1}.{i}.{j}")
                     xs.append(t)
             for k, mod in enumerate(getattr(m, f"stage{s}")):
                 xs = self._hr_module(xs, mod, f"stage{s}.{k}")

@@ -103,7 +103,7 @@ def record_rsgnet(p: Plan, model) -> None:
     loc = location_features(model)                               # constant: written once, below
 
     t = p._unit(cat, model.contact_conv[0], model.contact_conv[1], relu=True, name="contact_conv")
-    cat2 = p.new(H4, W4, 2 * c0, name="rel|vis")
+    cat2 = p.new(H4, W4, 2 * c0, pinned=True, name="rel|vis")   # read on demand after the run
     fvis = cat2.view(c0, c0)
     p._unit(t, model.predict_contact_net[0], model.predict_contact_net[1], relu=True, out=fvis,
             name="predict_contact_net")
@@ -138,8 +138,8 @@ def record_rsgnet(p: Plan, model) -> None:
         return lambda s: hip.check(lib.rsg_trp_tail(*a, s), "trp_tail")
 
     p.custom("trp_project_g", [fvis], [gT], make_g)
-    p.custom("trp_attention", [fvis, gT], [], make_attn)
-    p.custom("trp_tail", [], [rel], make_tail)
+    p.custom("trp_attention", [fvis, gT], [p.e32], make_attn)
+    p.custom("trp_tail", [p.e32], [rel], make_tail)
     p.flops += B * (2 * 2 * S * S * c0 + 2 * 2 * S * c0 * c0)
 
     # ---- joints-of-target branch (:991-1000)
@@ -155,19 +155,20 @@ def record_rsgnet(p: Plan, model) -> None:
     p.conv(k3, fl.weight, None, fl.bias, out_f32=p.kpt, want16=False, name="final_layer")
 
     # ---- limbs branch = SGM (:1003-1013)
-    lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net")
-    p.limbs_lo = torch.zeros(B, L, H4, W4, **f32)
-    p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
-
     p.multi_up = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
     p.limbs = torch.zeros(B, L, 2 * H4, 2 * W4, **f32)
+    p.limbs_lo = torch.zeros(B, L, H4, W4, **f32)
 
     def make_up(src, dst, planes, sig):
         a = (src.data_ptr(), dst.data_ptr(), planes, H4, W4, sig)
         return lambda: (lambda s: hip.check(lib.rsg_bilinear2x_nchw_f32(*a, s), "bilinear2x"))
 
-    p.custom("bilinear2x(multi)", [], [], make_up(p.multi_lo, p.multi_up, B * J, 0))
-    p.custom("bilinear2x+sigmoid(limbs)", [], [], make_up(p.limbs_lo, p.limbs, B * L, 1))
+    with p.on_lane(1):      # independent of TRP and the joints-of-target branch: its own stream
+        lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net")
+        p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
+        p.custom("bilinear2x+sigmoid(limbs)", [p.limbs_lo], [p.limbs], make_up(p.limbs_lo, p.limbs, B * L, 1))
+    with p.on_lane(2):
+        p.custom("bilinear2x(multi)", [p.multi_lo], [p.multi_up], make_up(p.multi_lo, p.multi_up, B * J, 0))
 
     # the constant location clue: filled once, right after allocation, for every crop slot
     orig_finalize = p.finalize
