@@ -47,6 +47,8 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     constexpr int PS = 2 * CINB + 16;    // LDS bytes per pixel (odd number of 16-B slots)
     constexpr int CPP = CINB / 8;        // 16-byte chunks per pixel
     constexpr int NLD = 8;               // staging loads in flight per thread
+    constexpr int KSB = NTAPS * KPT;     // k-steps per channel block
+    constexpr int NPF = KSB < 6 ? KSB : 6;   // A-operand prefetch depth
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -86,6 +88,11 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
     const size_t img = (size_t)b * p.Hin * p.Win;
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
+        // first weight fragments of this channel block: issued before the staging so they land under it
+        const uint4* apc = ap + (size_t)ch * KSB * 64;
+        uint4 aq[NPF];
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) aq[k] = apc[k * 64];
         // ---- stage CINB channels of the input tile (+halo) into LDS, zero outside the image ------
         for (int base = 0; base < total; base += NTHR * NLD) {
             uint4 r[NLD];
@@ -112,21 +119,28 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
         }
         __syncthreads();
 
-        // ---- MFMA over the taps of this channel block -------------------------------------------------
-        const uint4* apc = ap + (size_t)ch * NTAPS * KPT * 64;
+        // ---- MFMA over the taps of this channel block: one scheduling region per k-step (A loads NPF
+        // steps ahead, LDS reads one step ahead), else the compiler sinks the loads next to their uses
+        auto boff = [&](int ks) {
+            const int t = ks / KPT, c = ks % KPT;
+            return (t / TAPW) * p.RP + (t % TAPW) * PS + c * 32;
+        };
+        uint4 bq[2][NT];
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t) {
-            const int tapoff = (t / TAPW) * p.RP + (t % TAPW) * PS;
+        for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
 #pragma unroll
-            for (int c = 0; c < KPT; ++c) {
-                const uint4 av = apc[(t * KPT + c) * 64];
-                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, av);
+        for (int ks = 0; ks < KSB; ++ks) {
+            const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+            if (ks + 1 < KSB) {
 #pragma unroll
-                for (int g = 0; g < NT; ++g) {
-                    const uint4 bv = *reinterpret_cast<const uint4*>(smem + pixoff[g] + tapoff + c * 32);
-                    acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc[g]);
-                }
+                for (int g = 0; g < NT; ++g)
+                    bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
             }
+            if (ks + NPF < KSB) aq[ks % NPF] = apc[(ks + NPF) * 64];
+#pragma unroll
+            for (int g = 0; g < NT; ++g)
+                acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), acc[g]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (ch + 1 < p.nchunks) __syncthreads();
     }

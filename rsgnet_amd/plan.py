@@ -224,6 +224,9 @@ class Plan:
         info = (C.c_int32 * 4)()
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nblocks, self.batch, info) and info[0] == H:
             return nblocks
+        # row tiles: two blocks per launch when the halo recompute stays moderate (tile rows >= 2x halo)
+        if nblocks % 2 == 0 and self.lib.rsg_basic_chain_supported(C_, H, W, 4, self.batch, info) and info[0] >= 8:
+            return 2
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2, self.batch, info):
             return 1
         return 0
