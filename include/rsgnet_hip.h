@@ -104,6 +104,16 @@ int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, cons
                     void* stream);
 int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
                               int32_t* info4);
+/* Up to 4 chains (the branches of one HighResolutionModule, pose_hrnet.py:254-255) in ONE launch; the
+ * workgroups of items[0] are dispatched first, so put the longest chain there. */
+typedef struct rsg_chain_item {
+    const void* in;
+    void* out;
+    const void* const* w_packed;   /* HOST array of nlayers device pointers */
+    const float* const* bias;      /* HOST array of nlayers device pointers */
+    int32_t nlayers, batch, h, w, c, reserved;
+} rsg_chain_item;
+int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
 
 /* ---- layout / elementwise -------------------------------------------------------------------- */
 /* x.float NCHW -> NHWC 16-bit with channels zero-padded to c_pad (input of the stem conv,
@@ -118,6 +128,25 @@ int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch, int32_t c,
 int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const void* const* low,
                     const int32_t* low_shift, int32_t n_low, void* out, int32_t batch, int32_t h,
                     int32_t w, int32_t c, int32_t dtype, void* stream);
+
+/* One launch for several INDEPENDENT ops of a module's fuse layers (pose_hrnet.py:190-268): up to 12
+ * convolutions (descriptors as for rsg_conv_igemm; rsg_conv_groupable tells whether one can join a
+ * group) and up to 4 fuse-sums (arguments as for rsg_hr_fuse_sum). */
+typedef struct rsg_fuse_item {
+    const void* same[4];
+    const void* low[3];
+    int32_t low_shift[3];
+    int32_t n_same, n_low;
+    void* out;
+    int32_t batch, h, w, c;
+} rsg_fuse_item;
+int rsg_conv_groupable(const rsg_conv_desc* d);
+/* two steps: _plan (HOST) writes the launch table (rsg_group_table_bytes bytes) and launch2 = {grid
+ * blocks, LDS bytes}; the caller copies the table to the device once; _run enqueues the launch. */
+size_t rsg_group_table_bytes(void);
+int rsg_conv_fuse_group_plan(const rsg_conv_desc* convs, int32_t n_convs, const rsg_fuse_item* fuses,
+                             int32_t n_fuses, int32_t dtype, void* table_host, int32_t* launch2);
+int rsg_conv_fuse_group_run(const void* table_dev, int32_t blocks, int32_t lds, int32_t dtype, void* stream);
 
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) [+ sigmoid] on fp32 NCHW
  * (pose_rsgnet.py:1009-1013) */

@@ -34,8 +34,7 @@ struct ChainArgs {
 };
 
 template <class DT, int C, int WM, int WN, int NT>
-__global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_id, char* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int CINB = (C % 64 == 0) ? 64 : 32;      // same k order as rsg_pack_conv_weights_host
     constexpr int NCH = C / CINB, KPT = CINB / 16;
@@ -52,8 +51,8 @@ __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) 
     const int RP = (W + 2) * PS;                         // LDS row pitch (one zero pixel left and right)
     const int slot_rows = R + 2;                         // + one zero row above and below
 
-    const int tile = blockIdx.x % p.tiles_y;
-    const int b0 = (blockIdx.x / p.tiles_y) * p.NI;      // first image of this workgroup
+    const int tile = block_id % p.tiles_y;
+    const int b0 = (block_id / p.tiles_y) * p.NI;      // first image of this workgroup
     const int y_first = tile * p.TH - p.halo;            // image row held in slot row 0 (+1 border)
 
     // ---- zero the whole image (borders, rows outside the picture), then stage the input ------------
@@ -204,6 +203,36 @@ __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) 
     }
 }
 
+template <class DT, int C, int WM, int WN, int NT>
+__global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    chain_body<DT, C, WM, WN, NT>(p, blockIdx.x, smem);
+}
+
+// Grouped launch: up to 4 chains (different branches of one HighResolutionModule) in ONE grid; the
+// workgroups of item 0 come first (put the longest chain there).  Every variant runs 512 threads.
+#define RSG_CHAIN_GROUP_MAX 4
+struct ChainGroupArgs {
+    int n;
+    int first[RSG_CHAIN_GROUP_MAX + 1];   // first[i] = first block of item i, first[n] = grid size
+    int c[RSG_CHAIN_GROUP_MAX];
+    ChainArgs a[RSG_CHAIN_GROUP_MAX];
+};
+
+template <class DT>
+__global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    const int bid = blockIdx.x - g.first[i];
+    switch (g.c[i]) {
+        case 32: chain_body<DT, 32, 1, 8, 5>(g.a[i], bid, smem); break;
+        case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem); break;
+        case 128: chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem); break;
+        case 256: chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct ChainCfg { int C, WM, WN, NT; };
 static const ChainCfg kChainCfgs[] = {{32, 1, 8, 5}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
@@ -284,5 +313,39 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
     dim3 grid(ceil_div(batch, a.NI) * a.tiles_y);
     RSG_LAUNCH(fn, grid, dim3(nthr), lds, (hipStream_t)stream, a);
     RSG_CHECK_LAUNCH("basic_chain");
+    return 0;
+}
+
+extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream) {
+    if (!items || n < 1 || n > RSG_CHAIN_GROUP_MAX) RSG_FAIL("chain_group: 1..%d items", RSG_CHAIN_GROUP_MAX);
+    ChainGroupArgs g;
+    memset(&g, 0, sizeof(g));
+    g.n = n;
+    int lds_max = 0, blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const rsg_chain_item& it = items[i];
+        if (!it.in || !it.out || !it.w_packed || !it.bias || it.in == it.out) RSG_FAIL("chain_group: bad pointers in item %d", i);
+        if (it.nlayers < 2 || it.nlayers > RSG_CHAIN_MAX_LAYERS || (it.nlayers & 1)) RSG_FAIL("chain_group: nlayers=%d", it.nlayers);
+        ChainArgs& a = g.a[i];
+        int lds = 0, nthr = 0;
+        if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr))
+            RSG_FAIL("chain_group: unsupported shape C=%d %dx%d L=%d", it.c, it.h, it.w, it.nlayers);
+        a.in = (const char*)it.in; a.out = (char*)it.out; a.nlayers = it.nlayers; a.B = it.batch; a.H = it.h; a.W = it.w;
+        for (int l = 0; l < it.nlayers; ++l) {
+            if (!it.w_packed[l] || !it.bias[l]) RSG_FAIL("chain_group: null weights (item %d layer %d)", i, l);
+            a.wpk[l] = (const uint4*)it.w_packed[l];
+            a.bias[l] = it.bias[l];
+        }
+        g.c[i] = it.c;
+        g.first[i] = blocks;
+        blocks += ceil_div(it.batch, a.NI) * a.tiles_y;
+        if (lds > lds_max) lds_max = lds;
+    }
+    g.first[n] = blocks;
+    void (*fn)(const ChainGroupArgs) = dtype == RSG_BF16 ? chain_group_kernel<BF16> : chain_group_kernel<F16>;
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess)
+        RSG_FAIL("chain_group: cannot reserve %d B of LDS", lds_max);
+    RSG_LAUNCH(fn, dim3(blocks), dim3(512), lds_max, (hipStream_t)stream, g);
+    RSG_CHECK_LAUNCH("basic_chain_group");
     return 0;
 }

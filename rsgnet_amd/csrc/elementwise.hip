@@ -1,5 +1,6 @@
 // Bandwidth-bound helpers around the convolution kernels (gfx950): 16 bytes per lane everywhere.
 #include "common.h"
+#include "fuse_body.h"
 
 // ---- NCHW fp32 -> NHWC 16-bit, channels zero-padded (stem input; pose_hrnet.py:429) ---------------
 // One thread per pixel: reads c planes (coalesced across the wave along W), writes c_pad*2 bytes.
@@ -43,57 +44,15 @@ extern "C" int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch,
 }
 
 // ---- HighResolutionModule fuse (pose_hrnet.py:259-266) ------------------------------------------------
-struct FuseArgs {
-    const char* same[4];
-    const char* low[3];
-    int shift[3];
-    int n_same, n_low;
-    char* out;
-    int h, w, c8;   // c8 = channels / 8
-    long total;     // batch*h*w*c8 16-byte vectors
-};
-
 template <class DT>
 __global__ void __launch_bounds__(256) hr_fuse_kernel(const FuseArgs a) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        for (int k = 0; k < a.n_same; ++k) {
-            const typename DT::vec8 v =
-                __builtin_bit_cast(typename DT::vec8, reinterpret_cast<const uint4*>(a.same[k])[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
-        }
-        if (a.n_low) {
-            const int cg = (int)(i % a.c8);
-            long pix = i / a.c8;
-            const int x = (int)(pix % a.w);
-            pix /= a.w;
-            const int y = (int)(pix % a.h);
-            const long b = pix / a.h;
-            for (int k = 0; k < a.n_low; ++k) {
-                const int s = a.shift[k];
-                const long src = ((b * (a.h >> s) + (y >> s)) * (a.w >> s) + (x >> s)) * a.c8 + cg;
-                const typename DT::vec8 v =
-                    __builtin_bit_cast(typename DT::vec8, reinterpret_cast<const uint4*>(a.low[k])[src]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
-            }
-        }
-        typename DT::vec8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (typename DT::elem)fmaxf(acc[e], 0.f);
-        reinterpret_cast<uint4*>(a.out)[i] = __builtin_bit_cast(uint4, o);
-    }
+    fuse_body<DT>(a, blockIdx.x, gridDim.x);
 }
 
-extern "C" int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const void* const* low,
-                               const int32_t* low_shift, int32_t n_low, void* out, int32_t batch,
-                               int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
+int rsg_fuse_prepare(const void* const* same, int n_same, const void* const* low, const int32_t* low_shift,
+                     int n_low, void* out, int batch, int h, int w, int c, FuseArgs& a, int& blocks) {
     if (n_same < 1 || n_same > 4 || n_low < 0 || n_low > 3 || !out) RSG_FAIL("hr_fuse: bad operand count");
     if (c % 8) RSG_FAIL("hr_fuse: channels %d not a multiple of 8", c);
-    FuseArgs a;
     memset(&a, 0, sizeof(a));
     for (int k = 0; k < n_same; ++k) a.same[k] = (const char*)same[k];
     for (int k = 0; k < n_low; ++k) {
@@ -105,12 +64,22 @@ extern "C" int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const vo
     a.n_same = n_same; a.n_low = n_low; a.out = (char*)out;
     a.h = h; a.w = w; a.c8 = c / 8;
     a.total = (long)batch * h * w * a.c8;
-    long blocks = (a.total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    long b = (a.total + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    blocks = (int)b;
+    return 0;
+}
+
+extern "C" int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const void* const* low,
+                               const int32_t* low_shift, int32_t n_low, void* out, int32_t batch,
+                               int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
+    FuseArgs a;
+    int blocks = 0;
+    if (rsg_fuse_prepare(same, n_same, low, low_shift, n_low, out, batch, h, w, c, a, blocks)) return 1;
     if (dtype == RSG_BF16)
-        RSG_LAUNCH(hr_fuse_kernel<BF16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        RSG_LAUNCH(hr_fuse_kernel<BF16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     else
-        RSG_LAUNCH(hr_fuse_kernel<F16>, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        RSG_LAUNCH(hr_fuse_kernel<F16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     RSG_CHECK_LAUNCH("hr_fuse_sum");
     return 0;
 }

@@ -103,8 +103,8 @@ extern "C" int rsg_graph_destroy(void* graph) {
     RsgGraph* g = (RsgGraph*)graph;
     if (!g) return 0;
     if (g == tl_open) tl_open = nullptr;
-    if (g->exec) hipGraphExecDestroy(g->exec);
-    if (g->graph) hipGraphDestroy(g->graph);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
     return 0;
 }

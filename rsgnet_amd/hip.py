@@ -27,6 +27,20 @@ class ConvDesc(C.Structure):
     ]
 
 
+class FuseItem(C.Structure):
+    """struct rsg_fuse_item (include/rsgnet_hip.h)."""
+    _fields_ = [("same", C.c_void_p * 4), ("low", C.c_void_p * 3), ("low_shift", C.c_int32 * 3),
+                ("n_same", C.c_int32), ("n_low", C.c_int32), ("out", C.c_void_p), ("batch", C.c_int32),
+                ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32)]
+
+
+class ChainItem(C.Structure):
+    """struct rsg_chain_item (include/rsgnet_hip.h)."""
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
+                ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
+                ("w", C.c_int32), ("c", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/rsgnet_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _fp = C.c_void_p, C.c_int32, C.c_void_p
 SYMBOLS = {
@@ -45,7 +59,13 @@ SYMBOLS = {
     "rsg_graph_launch": (C.c_int, [_vp, _vp]),
     "rsg_graph_destroy": (C.c_int, [_vp]),
     "rsg_basic_chain": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp]),
+    "rsg_basic_chain_group": (C.c_int, [C.POINTER(ChainItem), _i, _i, _vp]),
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
+    "rsg_conv_groupable": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rsg_group_table_bytes": (C.c_size_t, []),
+    "rsg_conv_fuse_group_plan": (C.c_int, [C.POINTER(ConvDesc), _i, C.POINTER(FuseItem), _i, _i, _vp,
+                                           C.POINTER(C.c_int32)]),
+    "rsg_conv_fuse_group_run": (C.c_int, [_vp, _i, _i, _i, _vp]),
     "rsg_nchw_f32_to_nhwc16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsg_hr_fuse_sum": (C.c_int, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _vp,
                                   _i, _i, _i, _i, _i, _vp]),

@@ -78,9 +78,10 @@ class Plan:
         self._keep: List[object] = []       # ctypes structs / tensors that must outlive the plan
         self._vts: List[VT] = []
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.graph_mode = os.environ.get("RSGNET_HIP_GRAPH", "1")
+        self.graph_mode = os.environ.get("RSGNET_HIP_GRAPH", "capture")
         self.use_graph = self.graph_mode != "0"
         self.use_chain = os.environ.get("RSGNET_HIP_CHAIN", "1") != "0"
+        self.use_group = os.environ.get("RSGNET_HIP_GROUP", "1") != "0"
         self.conv_log: List[dict] = []
         self.flops = 0
         # lanes = HIP streams the launches are spread over (independent HRNet branches run concurrently);
@@ -104,11 +105,44 @@ class Plan:
     def on_lane(self, lane: int) -> "Plan._LaneCtx":
         return Plan._LaneCtx(self, lane)
 
+    def begin_group(self):
+        """Ops recorded until end_group() are INDEPENDENT of each other and go into one launch."""
+        self._group = [] if self.use_group else None
+
+    def end_group(self, name=""):
+        subs, self._group = self._group, None
+        if not subs:
+            return
+        convs = [r for r in subs if r["kind"] == "conv"]
+        fuses = [r for r in subs if r["kind"] == "fuse"]
+        while convs or fuses:               # respect the per-launch limits of rsg_conv_fuse_group
+            c, convs = convs[:12], convs[12:]
+            f, fuses = fuses[:4], fuses[4:]
+            part = c + f
+            if len(part) == 1:
+                self._record(part[0], part[0]["reads"], part[0]["writes"])
+            else:
+                reads = [v for r in part for v in r["reads"]]
+                writes = [v for r in part for v in r["writes"]]
+                self._record(dict(kind="group", subs=part, name=name), reads, writes)
+
+    def _groupable(self, rec: dict) -> bool:
+        if rec["kind"] == "fuse":
+            return True
+        if rec["kind"] != "conv":
+            return False
+        d = self._conv_desc(rec, fake_ptrs=True)
+        return bool(self.lib.rsg_conv_groupable(C.byref(d)))
+
     def _record(self, rec: dict, reads, writes) -> int:
-        idx = len(self._rec)
-        rec["lane"] = self._lane
         rec["reads"] = [v for v in reads if v is not None]
         rec["writes"] = [v for v in writes if v is not None]
+        if getattr(self, "_group", None) is not None and "lane" not in rec and self._groupable(rec):
+            rec["lane"] = 0
+            self._group.append(rec)
+            return -1
+        idx = len(self._rec)
+        rec.setdefault("lane", self._lane)
         self._touch(idx, *[v for v in rec["reads"] + rec["writes"] if isinstance(v, VT)])
         self._rec.append(rec)
         return idx
@@ -216,6 +250,23 @@ class Plan:
         self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
         return out
 
+    def chain_group(self, items, name="") -> List[VT]:
+        """Record ONE launch that runs several chains (rsg_basic_chain_group).  items: [(x, blocks)]."""
+        subs, outs = [], []
+        for x, blocks in items:
+            layers = []
+            for blk in blocks:
+                for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
+                    scale, shift = self.bn_fold(bn)
+                    wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
+                    layers.append((wp, bo))
+            out = self.new(x.H, x.W, x.C, name=name)
+            subs.append(dict(x=x, out=out, layers=layers))
+            outs.append(out)
+            self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
+        self._record(dict(kind="chain_group", subs=subs, name=name), [d["x"] for d in subs], outs)
+        return outs
+
     def chain_mode(self, C_, H, W, nblocks) -> int:
         """How many BasicBlocks one rsg_basic_chain launch should take for this map: all of them when
         whole images fit in LDS, one when the map needs row tiles (halo grows with the chain), 0 = no."""
@@ -305,14 +356,15 @@ class Plan:
                     latest[ld] = max(latest.get(ld, -1), d)
             self._waits.append(sorted(latest.values()))
 
-    def _lower_conv(self, r):
+    def _conv_desc(self, r, fake_ptrs=False) -> "hip.ConvDesc":
         d = hip.ConvDesc()
         x: VT = r["x"]
-        d.inp = x.ptr()
+        fake = 0x10000
+        d.inp = fake if fake_ptrs else x.ptr()
         d.w_packed = r["wp"].data_ptr()
         d.bias = r["bias"].data_ptr()
-        d.residual = r["res"].ptr() if r["res"] is not None else None
-        d.out16 = r["out"].ptr() if r["out"] is not None else None
+        d.residual = (fake if fake_ptrs else r["res"].ptr()) if r["res"] is not None else None
+        d.out16 = (fake if fake_ptrs else r["out"].ptr()) if r["out"] is not None else None
         d.out_nchw_f32 = r["out_f32"].data_ptr() if r["out_f32"] is not None else None
         d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = self.batch, x.H, x.W, r["I"], x.ld
         d.out_h, d.out_w, d.out_c = r["out_hw"][0], r["out_hw"][1], r["O"]
@@ -325,11 +377,18 @@ class Plan:
         d.relu = 1 if r["relu"] else 0
         d.dtype = self.dtype
         d.tile_hint = 0
-        self._keep.append(d)
+        return d
+
+    def _log_conv(self, r, d):
         info = (C.c_int32 * 8)()
         hip.check(self.lib.rsg_conv_plan(C.byref(d), info), r["name"])
         self.conv_log.append(dict(name=r["name"], cin=r["I"], cout=r["O"], k=r["kh"], s=r["stride"],
                                   hw=r["out_hw"], tile=list(info)))
+
+    def _lower_conv(self, r):
+        d = self._conv_desc(r)
+        self._keep.append(d)
+        self._log_conv(r, d)
         fn, ref = self.lib.rsg_conv_igemm, C.byref(d)
         nm = r["name"]
 
@@ -339,6 +398,47 @@ class Plan:
                 hip.check(rc, nm)
 
         self.ops.append((r["name"], launch))
+
+    def _fuse_item(self, r) -> "hip.FuseItem":
+        same, low, out = r["same"], r["low"], r["out"]
+        for v in list(same) + [v for v, _ in low]:
+            if v.ld != v.C or v.coff:
+                raise ValueError("fuse operands must be dense tensors")
+        it = hip.FuseItem()
+        for k, v in enumerate(same):
+            it.same[k] = v.ptr()
+        for k, (v, sh) in enumerate(low):
+            it.low[k] = v.ptr()
+            it.low_shift[k] = sh
+        it.n_same, it.n_low, it.out = len(same), len(low), out.ptr()
+        it.batch, it.h, it.w, it.c = self.batch, out.H, out.W, out.C
+        return it
+
+    def _lower_group(self, r):
+        convs = [x for x in r["subs"] if x["kind"] == "conv"]
+        fuses = [x for x in r["subs"] if x["kind"] == "fuse"]
+        cd = (hip.ConvDesc * max(len(convs), 1))()
+        for i, x in enumerate(convs):
+            d = self._conv_desc(x)
+            self._log_conv(x, d)
+            cd[i] = d
+        fi = (hip.FuseItem * max(len(fuses), 1))()
+        for i, x in enumerate(fuses):
+            fi[i] = self._fuse_item(x)
+        nm, dt = r["name"], self.dtype
+        table = np.zeros(self.lib.rsg_group_table_bytes(), np.uint8)
+        launch2 = (C.c_int32 * 2)()
+        hip.check(self.lib.rsg_conv_fuse_group_plan(cd, len(convs), fi, len(fuses), dt, table.ctypes.data, launch2), nm)
+        tdev = self._dev(table)
+        fn, tptr, blocks, lds = self.lib.rsg_conv_fuse_group_run, tdev.data_ptr(), launch2[0], launch2[1]
+        self.conv_log.append(dict(name=nm, group=[x["name"] for x in r["subs"]], blocks=blocks))
+
+        def launch(stream):
+            rc = fn(tptr, blocks, lds, dt, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((nm, launch))
 
     def _lower_fuse(self, r):
         same, low, out = r["same"], r["low"], r["out"]
@@ -376,6 +476,34 @@ class Plan:
 
         def launch(stream):
             rc = fn(*args, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((nm, launch))
+
+    def _lower_chain_group(self, r):
+        subs = r["subs"]
+        items = (hip.ChainItem * len(subs))()
+        log = []
+        for it, d in zip(items, subs):
+            x, out, layers = d["x"], d["out"], d["layers"]
+            if x.ld != x.C or x.coff or out.ld != out.C or out.coff:
+                raise ValueError("chain operands must be dense tensors")
+            n = len(layers)
+            wps = (C.c_void_p * n)(*[w.data_ptr() for w, _ in layers])
+            bps = (C.c_void_p * n)(*[b.data_ptr() for _, b in layers])
+            self._keep += [wps, bps]
+            it.inp, it.out = x.ptr(), out.ptr()
+            it.w_packed = C.cast(wps, C.POINTER(C.c_void_p))
+            it.bias = C.cast(bps, C.POINTER(C.c_void_p))
+            it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, x.C
+            log.append((x.C, x.H, x.W, n))
+        self._keep.append(items)
+        fn, nm, n_items, dt = self.lib.rsg_basic_chain_group, r["name"], len(subs), self.dtype
+        self.conv_log.append(dict(name=nm, group=log))
+
+        def launch(stream):
+            rc = fn(items, n_items, dt, stream)
             if rc:
                 hip.check(rc, nm)
 
@@ -453,8 +581,9 @@ class Plan:
                 pass
 
     def _replay(self):
-        """RSGNET_HIP_GRAPH = 1 (default): explicit HIP graph with data-dependency edges;
-        'capture': torch stream capture of the single-stream order; 0: eager launches (lanes = streams)."""
+        """RSGNET_HIP_GRAPH = 'capture' (default): stream capture of the single-stream launch order (the
+        grouped launches already overlap independent work inside each grid); 'dag': explicit HIP graph with
+        data-dependency edges (librsgnet_hip's graph API); '0': eager launches, lanes = streams."""
         mode = self.graph_mode
         if mode == "0":
             self.launch_all()
@@ -516,36 +645,66 @@ class _BackboneMixin:
     def _hr_module(self: Plan, xs: List[VT], mod, name: str) -> List[VT]:
         """HighResolutionModule.forward (pose_hrnet.py:250-268)."""
         xs = list(xs)
+        # branches: LDS-resident chains, grouped so that ONE launch runs every branch of the module
+        # (longest chain first); a branch that needs row tiles contributes its blocks slice by slice
+        slices: List[List[Tuple[int, list]]] = []      # slices[k] = [(branch, blocks)] of the k-th launch
         for b, branch in enumerate(mod.branches):
             blocks = list(branch)
             plain = all(not hasattr(blk, "conv3") and blk.downsample is None for blk in blocks)
             step = self.chain_mode(xs[b].C, xs[b].H, xs[b].W, len(blocks)) if plain else 0
-            with self.on_lane(b):                 # branches are independent: one stream each
-                if step:
-                    for k in range(0, len(blocks), step):
-                        xs[b] = self.chain(xs[b], blocks[k:k + step], f"{name}.branches.{b}.chain{k}")
-                    continue
-                for k, blk in enumerate(blocks):
-                    xs[b] = self._residual_block(xs[b], blk, f"{name}.branches.{b}.{k}")
+            if not step:
+                with self.on_lane(b):
+                    for k, blk in enumerate(blocks):
+                        xs[b] = self._residual_block(xs[b], blk, f"{name}.branches.{b}.{k}")
+                continue
+            for k in range(0, len(blocks), step):
+                while len(slices) <= k // step:
+                    slices.append([])
+                slices[k // step].append((b, blocks[k:k + step]))
+        for k, sl in enumerate(slices):
+            sl.sort(key=lambda e: (-len(e[1]), -xs[e[0]].C))     # whole-branch chains first, widest first
+            if self.use_group and len(sl) > 1:
+                outs = self.chain_group([(xs[b], blks) for b, blks in sl], f"{name}.chains{k}")
+                for (b, _), o in zip(sl, outs):
+                    xs[b] = o
+            else:
+                for b, blks in sl:
+                    with self.on_lane(b):
+                        xs[b] = self.chain(xs[b], blks, f"{name}.branches.{b}.chain{k}")
         if mod.fuse_layers is None:
             return xs
-        outs = []
-        for i, row in enumerate(mod.fuse_layers):
-            same, low = [], []
-            with self.on_lane(i):                 # one stream per output branch
-                for j, fl in enumerate(row):
-                    if j == i:
-                        same.append(xs[j])
-                    elif j > i:
-                        z = self._unit(xs[j], fl[0], fl[1], name=f"{name}.fuse.{i}.{j}")
-                        low.append((z, j - i))
+        # fuse layers, level by level: level k holds the k-th conv of every path (all 1x1 "up" convs and
+        # the first strided conv of every "down" chain are level 0); the sum of output i can run once
+        # its longest chain (i convs, from branch 0) is done.  One grouped launch per level.
+        rows = mod.fuse_layers
+        n_out = len(rows)
+        cur = {}                                         # (i, j) -> tensor produced so far on that path
+        depth = {}                                       # (i, j) -> number of convs on that path
+        for i, row in enumerate(rows):
+            for j, fl in enumerate(row):
+                if j != i:
+                    depth[(i, j)] = 1 if j > i else len(fl)
+                    cur[(i, j)] = xs[j]
+        max_depth = max(depth.values()) if depth else 0
+        outs: List[Optional[VT]] = [None] * n_out
+        ready = {i: max([d for (ii, _), d in depth.items() if ii == i], default=0) for i in range(n_out)}
+        for level in range(max_depth + 1):
+            self.begin_group()
+            for (i, j), dep in depth.items():
+                if level < dep:
+                    fl = rows[i][j]
+                    if j > i:
+                        cur[(i, j)] = self._unit(cur[(i, j)], fl[0], fl[1], name=f"{name}.fuse.{i}.{j}")
                     else:
-                        t = xs[j]
-                        for k, step in enumerate(fl):
-                            t = self._unit(t, step[0], step[1], relu=(k != len(fl) - 1),
-                                           name=f"{name}.fuse.{i}.{j}.{k}")
-                        same.append(t)
-                outs.append(self.fuse(same, low, name=f"{name}.fuse.{i}"))
+                        step = fl[level]
+                        cur[(i, j)] = self._unit(cur[(i, j)], step[0], step[1], relu=(level != dep - 1),
+                                                 name=f"{name}.fuse.{i}.{j}.{level}")
+            for i in range(n_out):
+                if ready[i] == level:                    # every addend was finished by the previous level
+                    same = [cur[(i, j)] for j in range(i)] + [xs[i]]
+                    low = [(cur[(i, j)], j - i) for j in range(i + 1, len(xs))]
+                    outs[i] = self.fuse(same, low, name=f"{name}.fuse.{i}")
+            self.end_group(f"{name}.fuse.level{level}")
         return outs
 
     def _record_backbone(self: Plan, m, H: int, W: int) -> List[VT]:

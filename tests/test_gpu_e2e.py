@@ -50,7 +50,7 @@ def test_hrnet_w32_golden():
     assert e2 < 0.5 * REL_TOL * float(ref.std())
     # intermediate taps exist for triage
     plan = model.plan_for(x.cuda())
-    assert plan.arena_bytes > 0 and len(plan.ops) > 100
+    assert plan.arena_bytes > 0 and len(plan.ops) > 30
 
 
 def test_hrnet_w32_random_init_regime_meets_1e3():
