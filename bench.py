@@ -24,6 +24,22 @@ import torch  # noqa: E402
 
 GFLOP_PER_IMG = {"hrnet_w32_256x192": 15.29, "rsgnet_w32_256x192_coco": 17.80}
 PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/*_pmc_summary.json:
+    FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f).get(kernel_key)
+    if not d:
+        return None
+    return {"bytes_per_launch": int((d["fetch_mb_per_launch"] + d["write_mb_per_launch"]) * 1e6),
+            "fetch_mb": d["fetch_mb_per_launch"], "write_mb": d["write_mb_per_launch"],
+            "source": os.path.basename(files[-1])}
 WORKLOADS = {
     "hrnet_w32_256x192": ("pose_hrnet", 32, (192, 256), 17, 64),
     "rsgnet_w32_256x192_coco": ("pose_rsgnet", 32, (192, 256), 17, 64),
@@ -62,6 +78,89 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0):
         n += 1
     return {"value": round(b / best, 2), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{n} forwards of batch {b} (best), {tag}, torch {torch.__version__} CPU fp32, eval"}
+
+
+def timed_steps(step, steps, dist, dev):
+    """The contract's timed region: barrier + synchronize on both sides of EXACTLY `steps` steps; returns
+    (max wall seconds over ranks, this rank's device ms between HIP events on the launch stream)."""
+    on_gpu = dev is not None and dev.type == "cuda"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+
+    e0 = e1 = None
+    if on_gpu:
+        stream = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    if on_gpu:
+        e0.record(stream)
+    for _ in range(steps):
+        step()
+    if on_gpu:
+        e1.record(stream)
+        torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    barrier()
+    dev_ms = e0.elapsed_time(e1) if on_gpu else wall * 1e3
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev if on_gpu else "cpu")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), dev_ms
+
+
+def family_table(plan, per_op):
+    """Group the launch list by kernel family; FLOPs are the algorithmic conv FLOPs each launch covers."""
+    flops = {}
+    for e in plan.conv_log:
+        if "tile" in e:      # a single convolution
+            flops[e["name"]] = 2.0 * plan.batch * e["hw"][0] * e["hw"][1] * e["cin"] * e["cout"] * e["k"] ** 2
+    chain = {}
+    for e in plan.conv_log:
+        if "chain" in e:
+            chain[e["name"]] = 2.0 * plan.batch * e["hw"][0] * e["hw"][1] * e["cin"] * e["cout"] * 9 * e["layers"]
+        elif "group" in e and e["group"] and isinstance(e["group"][0], (list, tuple)):
+            chain[e["name"]] = sum(2.0 * plan.batch * h * w * c * c * 9 * n for c, h, w, n in e["group"])
+        elif "group" in e:
+            flops[e["name"]] = sum(flops.get(n, 0.0) for n in e["group"])
+    fams = {}
+    for o in per_op:
+        n = o["op"]
+        if n in chain:
+            k, f = "chain_group_kernel/chain_kernel (LDS-resident BasicBlock chains)", chain[n]
+        elif ".fuse" in n:
+            k, f = "conv_group_kernel (fuse layers)", flops.get(n, 0.0)
+        elif n in flops:
+            k, f = "conv_igemm_kernel (stem, layer1, transitions, heads)", flops[n]
+        else:
+            k, f = "other (layout, TRP, bilinear)", 0.0
+        d = fams.setdefault(k, {"launches": 0, "us": 0.0, "gflop": 0.0})
+        d["launches"] += 1
+        d["us"] += o["us"]
+        d["gflop"] += f / 1e9
+    for d in fams.values():
+        d["us"] = round(d["us"], 1)
+        d["gflop"] = round(d["gflop"], 1)
+        d["tflops"] = round(d["gflop"] / d["us"] * 1e3, 1) if d["us"] else 0.0
+    # algorithmic HBM bytes of the chain launches: every chain reads its input once and writes its output
+    # once (16-bit), plus one pass over its weights
+    ck = "chain_group_kernel/chain_kernel (LDS-resident BasicBlock chains)"
+    if ck in fams:
+        tot = 0.0
+        for e in plan.conv_log:
+            items = []
+            if "chain" in e:
+                items = [(e["cin"], e["hw"][0], e["hw"][1], e["layers"])]
+            elif "group" in e and e["group"] and isinstance(e["group"][0], (list, tuple)):
+                items = e["group"]
+            for c, h, w, n in items:
+                tot += 2 * plan.batch * h * w * c * 2 + n * c * c * 9 * 2
+        fams[ck]["alg_mb_per_launch"] = round(tot / fams[ck]["launches"] / 1e6, 1)
+    return fams
 
 
 def main():
@@ -108,53 +207,38 @@ def main():
     o0 = out if torch.is_tensor(out) else out[1]
     assert torch.isfinite(o0).all(), "non-finite heatmaps"
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    stream = torch.cuda.current_stream(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier()
-    t0 = time.perf_counter()
-    e0.record(stream)
-    for _ in range(a.steps):
-        step()
-    e1.record(stream)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    barrier()
-    dev_ms = e0.elapsed_time(e1)
-    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax.item())
+    wall, dev_ms = timed_steps(step, a.steps, dist, dev)
 
     plan = model.plan_for(x)
-    per_op = None
-    if a.per_op and rank == 0:
-        per_op = []
+    # per-launch timing pass (outside the timed region, rank 0): every op of the launch list is re-run back
+    # to back between HIP events on the launch stream; gives the per-kernel-family table and the roofline
+    # of the dominant kernel
+    fam = None
+    if rank == 0:
         st = torch.cuda.current_stream(dev).cuda_stream
+        per_op = []
         for name, op in plan.ops:
             s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(2):
-                op(st)
+            op(st)
             s0.record()
-            for _ in range(5):
+            for _ in range(3):
                 op(st)
             s1.record()
             torch.cuda.synchronize()
-            per_op.append({"op": name, "us": round(s0.elapsed_time(s1) / 5 * 1e3, 2)})
-        with open(a.per_op, "w") as f:
-            json.dump({"workload": a.workload, "batch": batch, "ops": per_op, "convs": plan.conv_log}, f)
+            per_op.append({"op": name, "us": round(s0.elapsed_time(s1) / 3 * 1e3, 2)})
+        fam = family_table(plan, per_op)
+        if a.per_op:
+            with open(a.per_op, "w") as f:
+                json.dump({"workload": a.workload, "batch": batch, "ops": per_op, "convs": plan.conv_log,
+                           "families": fam}, f)
 
     if rank == 0:
         ms = wall / a.steps * 1e3
         imgs = world * batch * a.steps / wall
         gflop = GFLOP_PER_IMG[a.workload]
-        # roofline of the dominant kernel family (conv_igemm_kernel: >95% of device time): algorithmic
-        # FLOPs of one step / device time of one step measured with HIP events on the launch stream
-        ach = gflop * batch / (dev_ms / a.steps)                 # GFLOP / ms = TFLOP/s
+        whole = gflop * batch / (dev_ms / a.steps)               # GFLOP / ms = TFLOP/s over the whole step
+        dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["us"])
+        ach = dom["gflop"] / (dom["us"] / 1e3)                   # GFLOP / ms = TFLOP/s
         line = {
             "metric": "images/sec HRNet-W32 256x192 bs64 fwd" if a.workload.startswith("hrnet") else
                       "images/sec RSGNet-W32 256x192 bs64 fwd",
@@ -163,13 +247,20 @@ def main():
             "dtype": model.compute_dtype, "data": "synthetic",
             "config": {"workload": a.workload, "per_gpu_batch": batch, "global_batch": batch * world,
                        "image": f"{wh[1]}x{wh[0]}", "parallelism": f"dp{world} (independent shards)",
-                       "weights": "synthetic name-keyed rule + calibrated BN stats", "hip_graph": plan.use_graph,
+                       "weights": "synthetic name-keyed rule + calibrated BN stats", "graph": plan.graph_mode,
                        "launches_per_step": len(plan.ops)},
-            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel (all launches of one forward)",
-                         "device_ms_per_step": round(dev_ms / a.steps, 4),
-                         "algorithmic_gflop_per_image": gflop},
+            # dominant kernel family: algorithmic FLOPs of its launches / their summed durations (HIP events
+            # on the launch stream, per-launch pass after the timed region)
+            "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_TFLOPS, 4),
+                         "traffic": pmc_traffic("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel"),
+                         "algorithmic_mb_per_launch": dom.get("alg_mb_per_launch"),
+                         "kernel": dom_name, "launches": dom["launches"], "kernel_us_per_step": dom["us"],
+                         "kernel_gflop_per_step": dom["gflop"],
+                         "whole_step": {"achieved": round(whole, 1), "frac": round(whole / PEAK_TFLOPS, 4),
+                                        "device_ms_per_step": round(dev_ms / a.steps, 4),
+                                        "algorithmic_gflop_per_image": gflop},
+                         "families": fam},
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh)

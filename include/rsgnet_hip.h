@@ -24,6 +24,8 @@ enum { RSG_F16 = 0, RSG_BF16 = 1 };
 
 const char* rsg_last_error(void);
 int rsg_version(void);
+/* tuning knobs for experiments (process-wide): "chain_max_ni" = images per workgroup cap of the chain kernel */
+int rsg_tune(const char* key, int32_t value);
 
 /* ---- convolution family ---------------------------------------------------------------------
  * One implicit-GEMM kernel family covers

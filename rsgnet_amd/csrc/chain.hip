@@ -60,7 +60,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     for (int o = tid * 16; o < lds_bytes; o += NTHR * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int chunks_per_img = R * W * CPP;
-    constexpr int NLD = 8;                               // staging loads in flight per thread
+    constexpr int NLD = 12;                              // staging loads in flight per thread
     for (int base = 0; base < p.NI * chunks_per_img; base += NTHR * NLD) {
         uint4 v[NLD];
         int lo[NLD];
@@ -116,6 +116,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
                 res[g][1] = *reinterpret_cast<const uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2 + 16);
             }
         }
+        float bias[16];                                 // issued now, consumed after the k-loop
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias[l] + cbase + r4 * 4);
+            bias[r4 * 4 + 0] = bv.x; bias[r4 * 4 + 1] = bv.y; bias[r4 * 4 + 2] = bv.z; bias[r4 * 4 + 3] = bv.w;
+        }
         f32x16 acc[NT];
 #pragma unroll
         for (int g = 0; g < NT; ++g)
@@ -154,12 +160,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         }
 
         // ---- bias (+ block input) + ReLU, zero outside the picture, pack to 16 bit --------------------
-        float bias[16];
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.bias[l] + cbase + r4 * 4);
-            bias[r4 * 4 + 0] = bv.x; bias[r4 * 4 + 1] = bv.y; bias[r4 * 4 + 2] = bv.z; bias[r4 * 4 + 3] = bv.w;
-        }
         uint4 o[NT][2];
 #pragma unroll
         for (int g = 0; g < NT; ++g) {
@@ -237,6 +237,12 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
 struct ChainCfg { int C, WM, WN, NT; };
 static const ChainCfg kChainCfgs[] = {{32, 1, 8, 5}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
 static const int CHAIN_LDS_LIMIT = 160 * 1024;
+// measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
+static int g_chain_max_ni = 1;   // rsg_tune("chain_max_ni", n): images per workgroup cap in whole-image mode
+extern "C" int rsg_tune(const char* key, int32_t value) {
+    if (key && !strcmp(key, "chain_max_ni") && value >= 1) { g_chain_max_ni = value; return 0; }
+    RSG_FAIL("tune: unknown key or bad value");
+}
 
 typedef void (*chain_fn)(const ChainArgs);
 template <class DT>
@@ -261,7 +267,7 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     auto bytes = [&](int ni, int R) { return ni * (R + 2) * (W + 2) * PS; };
     if (H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
         int ni = cap / (H * W);
-        while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch)) --ni;
+        while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > g_chain_max_ni)) --ni;
         a.TH = H; a.R = H; a.halo = 0; a.NI = ni; a.tiles_y = 1;
         lds = bytes(ni, H);
         return 0;

@@ -46,6 +46,7 @@ _vp, _i, _fp = C.c_void_p, C.c_int32, C.c_void_p
 SYMBOLS = {
     "rsg_last_error": (C.c_char_p, []),
     "rsg_version": (C.c_int, []),
+    "rsg_tune": (C.c_int, [C.c_char_p, _i]),
     "rsg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "rsg_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     "rsg_conv_padded_cin": (C.c_int32, [_i]),
@@ -98,6 +99,9 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
+        ni = os.environ.get("RSGNET_HIP_CHAIN_MAX_NI")
+        if ni:
+            l.rsg_tune(b"chain_max_ni", int(ni))
         _lib = l
     return _lib
 

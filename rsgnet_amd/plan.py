@@ -205,9 +205,11 @@ class Plan:
     def conv(self, x: VT, weight: torch.Tensor, bn: Optional[nn.Module] = None, bias=None, *, stride=1,
              relu=False, residual: Optional[VT] = None, out: Optional[VT] = None,
              out_f32: Optional[torch.Tensor] = None, want16=True, pad=None, up=(1, 0, 0),
-             out_hw=None, phys_hw=None, name="") -> Optional[VT]:
+             out_hw=None, phys_hw=None, name="", extra_shift=None) -> Optional[VT]:
         """Record conv(+BN)(+bias)(+residual)(+ReLU).  ``x.C`` must be the padded input channels."""
         scale, shift = self.bn_fold(bn)
+        if extra_shift is not None:
+            shift = extra_shift if shift is None else shift + extra_shift
         wp, bo, I, O = self.pack_conv(weight, scale, shift, bias)
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         cin_pad = self.lib.rsg_conv_padded_cin(I)
@@ -275,9 +277,14 @@ class Plan:
         info = (C.c_int32 * 4)()
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nblocks, self.batch, info) and info[0] == H:
             return nblocks
-        # row tiles: two blocks per launch when the halo recompute stays moderate (tile rows >= 2x halo)
-        if nblocks % 2 == 0 and self.lib.rsg_basic_chain_supported(C_, H, W, 4, self.batch, info) and info[0] >= 8:
-            return 2
+        # row tiles: the MFMAs are far from busy on these wide, thin maps, so halo recompute is cheap;
+        # RSGNET_HIP_ROWTILE_BLOCKS blocks per launch (default 2: measured best; 4 makes the 2.6x halo
+        # recompute and the second wave of workgroups cost more than the saved launch), then 1
+        want = int(os.environ.get("RSGNET_HIP_ROWTILE_BLOCKS", "2"))
+        for nb in (want, 2):
+            if 0 < nb <= nblocks and nblocks % nb == 0 and \
+                    self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nb, self.batch, info) and info[0] >= 8:
+                return nb
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2, self.batch, info):
             return 1
         return 0
@@ -710,8 +717,33 @@ class _BackboneMixin:
     def _record_backbone(self: Plan, m, H: int, W: int) -> List[VT]:
         x = self._record_input(H, W)
         x = self._unit(x, m.conv1, m.bn1, relu=True, name="conv1")
-        x = self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
-        for k, blk in enumerate(m.layer1):
+        b0 = m.layer1[0]
+        fold = (os.environ.get("RSGNET_HIP_L1CAT", "1") != "0" and b0.downsample is not None
+                and hasattr(b0, "conv3") and b0.downsample[0].kernel_size == (1, 1)
+                and b0.downsample[0].stride == (1, 1) and b0.conv3.in_channels % 16 == 0
+                and m.conv2.out_channels % 16 == 0)
+        if fold:
+            # layer1.0: relu(bn3(conv3(t)) + bn_d(conv_d(x))) is ONE 1x1 conv over the channel concat [t | x]
+            # with weights [s3*W3 | sd*Wd]: the projected residual (100 MB at batch 64) is never stored.
+            # The stem's conv2 writes x straight into its half of the concat buffer.
+            cm, cx = b0.conv3.in_channels, m.conv2.out_channels
+            cat = self.new(x.H // 2, x.W // 2, cm + cx, name="layer1.0.cat")
+            xv = cat.view(cm, cx)
+            self._unit(x, m.conv2, m.bn2, relu=True, out=xv, name="conv2")
+            t = self._unit(xv, b0.conv1, b0.bn1, relu=True, name="layer1.0.conv1")
+            self._unit(t, b0.conv2, b0.bn2, relu=True, out=cat.view(0, cm), name="layer1.0.conv2")
+            s3, h3 = self.bn_fold(b0.bn3)
+            sd, hd = self.bn_fold(b0.downsample[1])
+            w3 = b0.conv3.weight.detach().float().cpu() * s3.view(-1, 1, 1, 1)
+            wd = b0.downsample[0].weight.detach().float().cpu() * sd.view(-1, 1, 1, 1)
+            x = self.conv(cat, torch.cat([w3, wd], dim=1), None, None, relu=True, name="layer1.0.conv3+downsample",
+                          extra_shift=h3 + hd)
+            rest = list(m.layer1)[1:]
+            k0 = 1
+        else:
+            x = self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
+            rest, k0 = list(m.layer1), 0
+        for k, blk in enumerate(rest, k0):
             x = self._residual_block(x, blk, f"layer1.{k}")
         ys = [x]
         for s in (2, 3, 4):
