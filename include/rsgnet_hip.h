@@ -166,10 +166,12 @@ int rsg_trp_attention(const void* x, int32_t ld_x, const void* gT_hi, const void
 int rsg_trp_project_g(const void* x, int32_t ld_x, const float* w, const float* bias, void* gT_hi,
                       void* gT_lo, int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
 /* W: conv1x1(+bias) then GroupNorm(8,C) on E, written 16-bit into out[b,s, 0:C] of a buffer with
- * channel stride out_ld (association.py:298-300) */
+ * channel stride out_ld (association.py:298-300).  workspace: rsg_trp_tail_workspace_bytes() of device
+ * memory (the fp32 projection and the per-workgroup GroupNorm partials).  S % 256 == 0. */
+size_t rsg_trp_tail_workspace_bytes(int32_t batch, int32_t S, int32_t C);
 int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,
                  const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
-                 int32_t dtype, void* stream);
+                 int32_t dtype, void* workspace, void* stream);
 /* optional materialisation of relation_score [batch,S,S] fp32 (association.py:294-295) */
 int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S, int32_t C,
                    int32_t dtype, void* stream);

@@ -40,10 +40,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+    # per-file extras.  trp.hip: MFMA results are consumed by VALU code (sigmoid) every tile, so keep the
+    # accumulators in VGPRs (gfx950 has a unified file); the default AGPR form costs 64 v_accvgpr moves/tile
+    extra = {"trp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, *extra.get(os.path.basename(src), []), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")

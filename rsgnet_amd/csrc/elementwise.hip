@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256) bilinear2x_kernel(const float* __restrict
             const float top = r0[xa] * (1.f - wx) + r0[xb] * wx;
             const float bot = r1[xa] * (1.f - wx) + r1[xb] * wx;
             float v = top * (1.f - wy) + bot * wy;
-            if (sigmoid) v = 1.f / (1.f + __expf(-v));
+            if (sigmoid) v = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
             o[k] = v;
         }
         reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);

@@ -14,6 +14,7 @@ struct RsgGraph {
     hipGraphExec_t exec = nullptr;
     std::vector<hipGraphNode_t> nodes;
     std::vector<hipGraphNode_t> deps;
+    size_t op_begin = 0;     // nodes.size() when the current op's dependencies were announced
 };
 
 static thread_local RsgGraph* tl_open = nullptr;
@@ -30,6 +31,11 @@ int rsg_launch_raw(const void* fn, dim3 grid, dim3 block, unsigned lds, hipStrea
         np.kernelParams = params;
         np.extra = nullptr;
         hipGraphNode_t node;
+        // second and later launches of one op (e.g. rsg_trp_tail) follow the op's previous node
+        if (tl_open->nodes.size() > tl_open->op_begin) {
+            tl_open->deps.clear();
+            tl_open->deps.push_back(tl_open->nodes.back());
+        }
         hipError_t e = hipGraphAddKernelNode(&node, tl_open->graph, tl_open->deps.data(), tl_open->deps.size(), &np);
         tl_open->deps.clear();
         if (e != hipSuccess) {
@@ -64,6 +70,7 @@ extern "C" int rsg_graph_next_deps(void* graph, const int32_t* node_ids, int32_t
     RsgGraph* g = (RsgGraph*)graph;
     if (!g || g != tl_open) RSG_FAIL("graph_next_deps: graph is not open on this thread");
     g->deps.clear();
+    g->op_begin = g->nodes.size();
     for (int i = 0; i < n; ++i) {
         if (node_ids[i] < 0 || (size_t)node_ids[i] >= g->nodes.size())
             RSG_FAIL("graph_next_deps: node id %d out of range (have %zu nodes)", node_ids[i], g->nodes.size());

@@ -21,8 +21,10 @@
 
 enum { TRP_ATTN = 0, TRP_SCORES = 1, TRP_MSE = 2 };
 
+// 1/(1 + 2^(-a*log2 e)) on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each); the libm
+// forms (__expf / __frcp_rn) expand to ~20 instructions per element and made the kernel 3x VALU-bound
 __device__ __forceinline__ float sigmoid_f32(float a) {
-    return __frcp_rn(1.f + __expf(-a));
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(a * -1.4426950408889634f));
 }
 
 struct TrpArgs {
@@ -44,7 +46,6 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
     const int n = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;          // this wave's 32 queries
-    if (q0 >= a.S) return;
     const char* xb = a.x + (size_t)b * a.S * a.ldx * 2;
 
     // query fragments (B operand of X = K.Q^T): lane (i=n, hh) holds x[q0+i][16s+8hh .. +8]
@@ -59,22 +60,32 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
     for (int r = 0; r < 16; ++r) y[r] = 0.f;
     float pq = 0.f, part = 0.f;
     if (MODE == TRP_MSE) pq = a.p[(size_t)b * a.S + q0 + n];
-    const char* gb = a.gT + ((size_t)b * C + n) * a.S * 2 + 16 * hh;   // row c = n of g^T, + lane-half offset
 
-    for (int j0 = 0; j0 < a.S; j0 += 32) {
-        // key fragments (A operand): lane (j=n, hh) holds x[j0+j][16s+8hh .. +8]
-        typename DT::vec8 kf[2];
+    // K / G^T tiles of 32 keys are shared by the 4 waves of the workgroup: each thread fetches ONE 16-byte
+    // piece (threads 0-127: keys x 64 B of x, threads 128-255: 32 channel rows x 64 B of g^T), coalesced,
+    // into a double-buffered LDS tile with 80-byte rows (5 slots: the 16-lane ds_read_b128 groups hit 16
+    // different banks).  Per-wave scattered global loads of the same data saturated the address path.
+    __shared__ uint4 tiles[2][2][32 * 5];
+    const int trow = (threadIdx.x & 127) >> 2, tpiece = threadIdx.x & 3;
+    const bool is_g = threadIdx.x >= 128;
+    const bool loader = !is_g || MODE == TRP_ATTN;
+    auto fetch = [&](int j0) -> uint4 {
+        if (!loader) return make_uint4(0, 0, 0, 0);
+        const char* src = is_g ? a.gT + (((size_t)b * C + trow) * a.S + j0 + tpiece * 8) * 2
+                               : xb + ((size_t)(j0 + trow) * a.ldx + tpiece * 8) * 2;
+        return *reinterpret_cast<const uint4*>(src);
+    };
+    auto stash = [&](int buf, uint4 v) {
+        if (loader) tiles[buf][is_g ? 1 : 0][trow * 5 + tpiece] = v;
+    };
+    auto load_tile = [&](int buf, typename DT::vec8 (&kf)[2], typename DT::vec8 (&gf)[2]) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-            kf[s] = __builtin_bit_cast(typename DT::vec8,
-                                       *reinterpret_cast<const uint4*>(xb + ((size_t)(j0 + n) * a.ldx + 16 * s + 8 * hh) * 2));
-        typename DT::vec8 gf[2];
-        if (MODE == TRP_ATTN) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                gf[s] = __builtin_bit_cast(typename DT::vec8,
-                                           *reinterpret_cast<const uint4*>(gb + (size_t)(j0 + 16 * s) * 2));
+        for (int s = 0; s < 2; ++s) {
+            kf[s] = __builtin_bit_cast(typename DT::vec8, tiles[buf][0][n * 5 + 2 * s + hh]);
+            if (MODE == TRP_ATTN) gf[s] = __builtin_bit_cast(typename DT::vec8, tiles[buf][1][n * 5 + 2 * s + hh]);
         }
+    };
+    auto do_tile = [&](int j0, const typename DT::vec8 (&kf)[2], const typename DT::vec8 (&gf)[2]) {
         f32x16 xacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
@@ -84,7 +95,6 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
         float pr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) pr[r] = sigmoid_f32(xacc[r]);
-
         if (MODE == TRP_ATTN) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -107,6 +117,20 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
                 part += d * d;
             }
         }
+    };
+    // one barrier per tile: fetch tile t+1 into registers, compute tile t from LDS, stash, barrier
+    const int ntiles = a.S / 32;
+    stash(0, fetch(0));
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (more) nxt = fetch((t + 1) * 32);
+        typename DT::vec8 kf[2], gf[2];
+        load_tile(t & 1, kf, gf);
+        do_tile(t * 32, kf, gf);
+        if (more) stash((t + 1) & 1, nxt);
+        __syncthreads();
     }
 
     if (MODE == TRP_ATTN) {
@@ -125,7 +149,7 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
 static int trp_check(const void* x, int ld_x, int batch, int S, int C) {
     if (!x || batch < 1) RSG_FAIL("trp: null input");
     if (C != 32) RSG_FAIL("trp: C=%d (only 32 is built)", C);
-    if (S % 32 || S < 32) RSG_FAIL("trp: S=%d must be a multiple of 32", S);
+    if (S % 128 || S < 128) RSG_FAIL("trp: S=%d must be a multiple of 128", S);
     if (ld_x < C || ld_x % 8) RSG_FAIL("trp: ld_x=%d", ld_x);
     return 0;
 }
@@ -230,92 +254,123 @@ extern "C" int rsg_trp_project_g(const void* x, int32_t ld_x, const float* w, co
 }
 
 // ---- W: conv1x1 + bias, GroupNorm(8, C) (association.py:298-300; eps 1e-5, biased variance) -----------
-// One workgroup per (crop, group).  Three passes over E (L2 resident): mean, centred variance, write.
-template <class DT>
-__global__ void __launch_bounds__(256) trp_tail_kernel(const float* __restrict__ e, const float* __restrict__ w,
-                                                      const float* __restrict__ bias,
-                                                      const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, char* __restrict__ out,
-                                                      int out_ld, int S) {
-    constexpr int C = 32, CG = 4;
-    __shared__ float ws[CG * C + CG];
-    __shared__ float red[8];
-    __shared__ float stat[2];
-    const int b = blockIdx.y, g = blockIdx.x;
-    for (int i = threadIdx.x; i < CG * C + CG; i += 256)
-        ws[i] = i < CG * C ? w[(g * CG) * C + i] : bias[g * CG + i - CG * C];
-    __syncthreads();
-    const float* eb = e + (size_t)b * S * C;
-
-    auto project = [&](int s, float (&yv)[CG]) {
-        float xv[C];
+// Two launches.  (1) y = W.E + b per position (fp32, written to the workspace) and, per workgroup of 256
+// positions, the (mean, M2) of each of the 8 channel groups.  (2) every workgroup merges its crop's
+// partials with Chan's formula (no E[x^2]-E[x]^2 cancellation), normalises its positions and writes 16 bit.
+__device__ __forceinline__ float block_sum256(float v, float* red) {
 #pragma unroll
-        for (int k = 0; k < C / 4; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(eb + (size_t)s * C + 4 * k);
-            xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) trp_w_project_kernel(const float* __restrict__ e, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y,
+                                                           float* __restrict__ part, int S) {
+    constexpr int C = 32, G = 8, CG = 4;
+    __shared__ float ws[C * C + C];
+    __shared__ float red[4];
+    for (int i = threadIdx.x; i < C * C + C; i += 256) ws[i] = i < C * C ? w[i] : bias[i - C * C];
+    __syncthreads();
+    const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)b * S + s) * C;
+    float xv[C], yv[C];
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(e + row + 4 * k);
+        xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int co = 0; co < C; ++co) {
+        float acc = ws[C * C + co];
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) acc = fmaf(ws[co * C + ci], xv[ci], acc);
+        yv[co] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k)
+        *reinterpret_cast<float4*>(y + row + 4 * k) = make_float4(yv[4 * k], yv[4 * k + 1], yv[4 * k + 2], yv[4 * k + 3]);
+    float* po = part + (((size_t)b * gridDim.x + blockIdx.x) * G) * 2;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float sum = (yv[4 * g] + yv[4 * g + 1]) + (yv[4 * g + 2] + yv[4 * g + 3]);
+        const float mean = block_sum256(sum, red) * (1.f / (256 * CG));
+        float m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) m2 += (yv[4 * g + c] - mean) * (yv[4 * g + c] - mean);
+        m2 = block_sum256(m2, red);
+        if (threadIdx.x == 0) { po[2 * g] = mean; po[2 * g + 1] = m2; }
+    }
+}
+
+template <class DT>
+__global__ void __launch_bounds__(256) trp_gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ part,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, char* __restrict__ out,
+                                                          int out_ld, int S) {
+    constexpr int C = 32, G = 8, CG = 4;
+    __shared__ float scale[C], shift[C];
+    const int b = blockIdx.y, nb = gridDim.x;
+    if (threadIdx.x < G) {
+        const int g = threadIdx.x;
+        const float* pi = part + ((size_t)b * nb * G + g) * 2;
+        const float nk = 256.f * CG;
+        float mean = 0.f;
+        for (int k = 0; k < nb; ++k) mean += pi[(size_t)k * G * 2];
+        mean /= (float)nb;                               // equal-sized parts
+        float m2 = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            const float d = pi[(size_t)k * G * 2] - mean;
+            m2 += pi[(size_t)k * G * 2 + 1] + nk * d * d;
         }
+        const float rstd = rsqrtf(m2 / (nk * (float)nb) + 1e-5f);
 #pragma unroll
         for (int c = 0; c < CG; ++c) {
-            float acc = ws[CG * C + c];
-#pragma unroll
-            for (int ci = 0; ci < C; ++ci) acc = fmaf(ws[c * C + ci], xv[ci], acc);
-            yv[c] = acc;
+            const float ga = gamma[g * CG + c] * rstd;
+            scale[g * CG + c] = ga;
+            shift[g * CG + c] = beta[g * CG + c] - mean * ga;
         }
-    };
-    auto block_sum = [&](float v) -> float {
+    }
+    __syncthreads();
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const float* yr = y + ((size_t)b * S + s) * C;
+    typename DT::elem* orow = reinterpret_cast<typename DT::elem*>(out) + ((size_t)b * S + s) * out_ld;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        return red[0] + red[1] + red[2] + red[3];
-    };
+    for (int k = 0; k < C / 8; ++k) {
+        const float4 v0 = *reinterpret_cast<const float4*>(yr + 8 * k);
+        const float4 v1 = *reinterpret_cast<const float4*>(yr + 8 * k + 4);
+        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        typename DT::vec8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (typename DT::elem)(vv[j] * scale[8 * k + j] + shift[8 * k + j]);
+        *reinterpret_cast<uint4*>(orow + 8 * k) = __builtin_bit_cast(uint4, o);
+    }
+}
 
-    const float inv_n = 1.f / (float)(S * CG);
-    float acc = 0.f;
-    for (int s = threadIdx.x; s < S; s += 256) {
-        float yv[CG];
-        project(s, yv);
-        acc += (yv[0] + yv[1]) + (yv[2] + yv[3]);
-    }
-    const float mean = block_sum(acc) * inv_n;
-    acc = 0.f;
-    for (int s = threadIdx.x; s < S; s += 256) {
-        float yv[CG];
-        project(s, yv);
-#pragma unroll
-        for (int c = 0; c < CG; ++c) acc += (yv[c] - mean) * (yv[c] - mean);
-    }
-    const float rstd = rsqrtf(block_sum(acc) * inv_n + 1e-5f);
-    float ga[CG], be[CG];
-#pragma unroll
-    for (int c = 0; c < CG; ++c) { ga[c] = gamma[g * CG + c] * rstd; be[c] = beta[g * CG + c]; }
-    typename DT::elem* ob = reinterpret_cast<typename DT::elem*>(out) + (size_t)b * S * out_ld + g * CG;
-    for (int s = threadIdx.x; s < S; s += 256) {
-        float yv[CG];
-        project(s, yv);
-        typedef typename DT::elem E4 __attribute__((ext_vector_type(4)));
-        E4 o;
-#pragma unroll
-        for (int c = 0; c < CG; ++c) o[c] = (typename DT::elem)((yv[c] - mean) * ga[c] + be[c]);
-        *reinterpret_cast<E4*>(ob + (size_t)s * out_ld) = o;
-    }
-    (void)stat;
+extern "C" size_t rsg_trp_tail_workspace_bytes(int32_t batch, int32_t S, int32_t C) {
+    return ((size_t)batch * S * C + (size_t)batch * (S / 256 + 1) * 8 * 2) * sizeof(float);
 }
 
 extern "C" int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,
                             const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S,
-                            int32_t C, int32_t dtype, void* stream) {
-    if (!e || !w || !bias || !gn_gamma || !gn_beta || !out) RSG_FAIL("trp_tail: null pointer");
+                            int32_t C, int32_t dtype, void* workspace, void* stream) {
+    if (!e || !w || !bias || !gn_gamma || !gn_beta || !out || !workspace) RSG_FAIL("trp_tail: null pointer");
     if (C != 32) RSG_FAIL("trp_tail: C=%d (only 32 is built)", C);
-    if (out_ld < C || out_ld % 4) RSG_FAIL("trp_tail: out_ld=%d", out_ld);
-    dim3 grid(8, batch);
+    if (S % 256) RSG_FAIL("trp_tail: S=%d must be a multiple of 256", S);
+    if (out_ld < C || out_ld % 8 || ((uintptr_t)out & 15)) RSG_FAIL("trp_tail: out_ld=%d / alignment", out_ld);
+    float* y = (float*)workspace;
+    float* part = y + (size_t)batch * S * C;
+    dim3 grid(S / 256, batch);
+    RSG_LAUNCH(trp_w_project_kernel, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, y, part, S);
+    RSG_CHECK_LAUNCH("trp_tail(project)");
     if (dtype == RSG_BF16)
-        RSG_LAUNCH(trp_tail_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, gn_gamma,
-                           gn_beta, (char*)out, out_ld, S);
+        RSG_LAUNCH(trp_gn_apply_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y,
+                   (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S);
     else
-        RSG_LAUNCH(trp_tail_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, gn_gamma,
-                           gn_beta, (char*)out, out_ld, S);
-    RSG_CHECK_LAUNCH("trp_tail");
+        RSG_LAUNCH(trp_gn_apply_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y,
+                   (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S);
+    RSG_CHECK_LAUNCH("trp_tail(groupnorm)");
     return 0;
 }

@@ -73,7 +73,8 @@ SYMBOLS = {
     "rsg_bilinear2x_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_attention": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_project_g": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsg_trp_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsg_trp_tail_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "rsg_trp_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rsg_trp_scores": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }

@@ -565,13 +565,17 @@ class Plan:
         g = C.c_void_p()
         hip.check(self.lib.rsg_graph_begin(C.byref(g)), "graph_begin")
         try:
+            last_node: List[int] = []                   # op index -> id of the op's last kernel node
             for i, (name, op) in enumerate(self.ops):
-                deps = self._all_deps[i]
+                deps = [last_node[d] for d in self._all_deps[i]]
                 arr = (C.c_int32 * max(len(deps), 1))(*deps)
                 hip.check(self.lib.rsg_graph_next_deps(g, arr, len(deps)), "graph_next_deps")
+                before = self.lib.rsg_graph_node_count(g)
                 op(None)
-                if self.lib.rsg_graph_node_count(g) != i + 1:
-                    raise RuntimeError(f"op {name} did not add exactly one graph node")
+                after = self.lib.rsg_graph_node_count(g)
+                if after <= before:
+                    raise RuntimeError(f"op {name} added no graph node")
+                last_node.append(after - 1)
             hip.check(self.lib.rsg_graph_end(g), "graph_end")
         except Exception:
             self.lib.rsg_graph_abort(g)

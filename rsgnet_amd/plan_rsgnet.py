@@ -132,9 +132,11 @@ def record_rsgnet(p: Plan, model) -> None:
 
     rel = cat2.view(0, c0)
 
+    p.tail_ws = torch.zeros(lib.rsg_trp_tail_workspace_bytes(B, S, c0) // 4, **f32)
+
     def make_tail():
         a = (p.e32.data_ptr(), ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
-             rel.ld, B, S, c0, dt)
+             rel.ld, B, S, c0, dt, p.tail_ws.data_ptr())
         return lambda s: hip.check(lib.rsg_trp_tail(*a, s), "trp_tail")
 
     p.custom("trp_project_g", [fvis], [gT], make_g)

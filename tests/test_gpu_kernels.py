@@ -227,8 +227,9 @@ def test_trp_attention_project_tail_scores_mse():
     st = _stream()
     hip.check(lib.rsg_trp_project_g(xptr, ld, wgd.data_ptr(), bgd.data_ptr(), gT.data_ptr(), None, B, S, Cc, 0, st))
     hip.check(lib.rsg_trp_attention(xptr, ld, gT.data_ptr(), None, e.data_ptr(), B, S, Cc, 0, st))
+    ws = torch.zeros(lib.rsg_trp_tail_workspace_bytes(B, S, Cc) // 4, device=DEV)
     hip.check(lib.rsg_trp_tail(e.data_ptr(), wwd.data_ptr(), bwd.data_ptr(), gd.data_ptr(), bd.data_ptr(),
-                               out.data_ptr(), ld, B, S, Cc, 0, st))
+                               out.data_ptr(), ld, B, S, Cc, 0, ws.data_ptr(), st))
     hip.check(lib.rsg_trp_scores(xptr, ld, scores.data_ptr(), B, S, Cc, 0, st))
     p = torch.rand(B, S, generator=g)
     pd = p.to(DEV)
