@@ -40,9 +40,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
-    # per-file extras.  trp.hip: MFMA results are consumed by VALU code (sigmoid) every tile, so keep the
-    # accumulators in VGPRs (gfx950 has a unified file); the default AGPR form costs 64 v_accvgpr moves/tile
-    extra = {"trp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+    # MFMA accumulators in VGPRs (gfx950 has one unified register file): the default AGPR form costs
+    # v_accvgpr moves wherever VALU code touches an accumulator (64 per tile in trp.hip's sigmoid loop,
+    # 16 per tile in every conv epilogue).  Measured in one visit: TRP loop -18 registers; HRNet step -1.8 %.
+    vgpr_form = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+    extra = {f: vgpr_form for f in ("trp.hip", "chain.hip", "group.hip", "conv_igemm.hip")}
+    for f in os.environ.get("RSGNET_HIP_NO_VGPR_FORM", "").split(","):  # experiment switch
+        extra.pop(f, None)
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")

@@ -31,6 +31,7 @@ struct ChainArgs {
     int halo;     // = nlayers in row-tile mode, 0 in whole-image mode
     int NI;       // images per workgroup (whole-image mode), else 1
     int tiles_y;
+    int RP;       // LDS row pitch in bytes (host: chain_row_pitch)
 };
 
 template <class DT, int C, int WM, int WN, int NT>
@@ -48,7 +49,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     const int wm = wave / WN, wn = wave % WN;
     const int n = lane & 31, hh = lane >> 5;
     const int W = p.W, R = p.R;
-    const int RP = (W + 2) * PS;                         // LDS row pitch (one zero pixel left and right)
+    // LDS row pitch: one zero pixel left and right, padded so that RP == W*PS (mod 256 B).  A 32-pixel
+    // group that wraps to the next row then continues the same odd-slot bank progression (conflict-free
+    // ds_read_b128); the dense pitch cost 43 % of the LDS cycles in bank conflicts (SQ_LDS_BANK_CONFLICT)
+    const int RP = p.RP;
     const int slot_rows = R + 2;                         // + one zero row above and below
 
     const int tile = block_id % p.tiles_y;
@@ -76,7 +80,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
                 const int y = y_first + r, b = b0 + i;
                 if (y >= 0 && y < p.H && b < p.B) {
                     v[j] = *reinterpret_cast<const uint4*>(p.in + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2);
-                    lo[j] = ((i * slot_rows + r + 1) * (W + 2) + x + 1) * PS + cg * 16;
+                    lo[j] = (i * slot_rows + r + 1) * RP + (x + 1) * PS + cg * 16;
                 }
             }
         }
@@ -99,7 +103,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         const int r = rem / W, x = rem - r * W;
         const int y = y_first + r;
         inside[g] = live[g] && y >= 0 && y < p.H && (b0 + i) < p.B;
-        pixoff[g] = ((i * slot_rows + r + 1) * (W + 2) + x + 1) * PS + hh * 16;
+        pixoff[g] = (i * slot_rows + r + 1) * RP + (x + 1) * PS + hh * 16;
     }
     const int cbase = wm * 32 + hh * 16;                 // this lane's 16 output channels
     __syncthreads();
@@ -197,7 +201,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         const int y = tile * p.TH + r, b = b0 + i;
         if (y < p.H && b < p.B) {
             const uint4 v = *reinterpret_cast<const uint4*>(
-                smem + ((i * slot_rows + r + p.halo + 1) * (W + 2) + x + 1) * PS + cg * 16);
+                smem + (i * slot_rows + r + p.halo + 1) * RP + (x + 1) * PS + cg * 16);
             *reinterpret_cast<uint4*>(p.out + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2) = v;
         }
     }
@@ -238,9 +242,15 @@ struct ChainCfg { int C, WM, WN, NT; };
 static const ChainCfg kChainCfgs[] = {{32, 1, 8, 5}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
 static const int CHAIN_LDS_LIMIT = 160 * 1024;
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
-static int g_chain_max_ni = 1;   // rsg_tune("chain_max_ni", n): images per workgroup cap in whole-image mode
+static int g_chain_max_ni = 1;
+static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
+static int chain_row_pitch(int C, int W) {
+    const int PS = 2 * C + 16;
+    return (W + 2) * PS + (g_chain_pitch_pad ? (256 - (2 * PS) % 256) % 256 : 0);
+}   // rsg_tune("chain_max_ni", n): images per workgroup cap in whole-image mode
 extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "chain_max_ni") && value >= 1) { g_chain_max_ni = value; return 0; }
+    if (key && !strcmp(key, "chain_pitch_pad")) { g_chain_pitch_pad = value ? 1 : 0; return 0; }
     RSG_FAIL("tune: unknown key or bad value");
 }
 
@@ -264,7 +274,9 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     const int cap = 32 * cfg->NT * cfg->WN;              // pixels a workgroup can own
     const int PS = 2 * C + 16;
     nthr = 64 * cfg->WM * cfg->WN;
-    auto bytes = [&](int ni, int R) { return ni * (R + 2) * (W + 2) * PS; };
+    const int RP = chain_row_pitch(C, W);
+    a.RP = RP;
+    auto bytes = [&](int ni, int R) { return ni * (R + 2) * RP; };
     if (H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
         int ni = cap / (H * W);
         while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > g_chain_max_ni)) --ni;

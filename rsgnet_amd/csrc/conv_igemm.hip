@@ -50,7 +50,10 @@ static void tile_geometry(const rsg_conv_desc* d, TilePlan& t) {
     const int PS = 2 * t.CINB + 16;
     t.TIH = (t.TH - 1) * d->stride + d->kh;
     t.TIW = (t.TW - 1) * d->stride + d->kw;
-    t.RP = t.TW >= 16 ? round_up(t.TIW * PS, 256) : t.TIW * PS;
+    // row pitch == TW*PS (mod 256 B): a 32-pixel group wrapping to the next tile row keeps the odd-slot
+    // bank progression (see chain.hip); >= the dense pitch
+    const int base = t.TIW * PS, want = (t.TW * PS) % 256;
+    t.RP = base + ((want - base) % 256 + 256) % 256;
     t.lds = t.TIH * t.RP;
     t.tiles_y = ceil_div(d->out_h, t.TH);
     t.tiles_x = ceil_div(d->out_w, t.TW);

@@ -38,7 +38,7 @@ static int variant_id(int cinb, int taps, int wm, int nt) {
 // The item table lives in device memory (built once per plan): indexing a by-value copy of it with the
 // runtime item id would spill the whole table to scratch.
 template <class DT>
-__global__ void __launch_bounds__(256) conv_group_kernel(const GroupArgs* __restrict__ gp) {
+__global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs* __restrict__ gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GroupArgs& g = *gp;
     const int n = g.n_conv + g.n_fuse;

@@ -100,9 +100,9 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        ni = os.environ.get("RSGNET_HIP_CHAIN_MAX_NI")
-        if ni:
-            l.rsg_tune(b"chain_max_ni", int(ni))
+        for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad")):
+            if os.environ.get(env):
+                l.rsg_tune(key, int(os.environ[env]))
         _lib = l
     return _lib
 
