@@ -213,6 +213,10 @@ class Plan:
         wp, bo, I, O = self.pack_conv(weight, scale, shift, bias)
         kh, kw = int(weight.shape[2]), int(weight.shape[3])
         cin_pad = self.lib.rsg_conv_padded_cin(I)
+        if x.C > cin_pad and x.C == _round_up(I, 32):
+            # e.g. a 48-channel map lives in a 64-channel buffer (outputs are padded to 32-channel tiles,
+            # the padding holds zeros): read the first padded_cin channels of it
+            x = x.view(0, cin_pad)
         if x.C != cin_pad:
             raise ValueError(f"{name}: input view has {x.C} channels, conv needs padded cin {cin_pad}")
         if pad is None:
@@ -662,6 +666,7 @@ class _BackboneMixin:
         for b, branch in enumerate(mod.branches):
             blocks = list(branch)
             plain = all(not hasattr(blk, "conv3") and blk.downsample is None for blk in blocks)
+            plain = plain and blocks[0].conv1.in_channels == xs[b].C        # no channel padding (W48: 48 in 64)
             step = self.chain_mode(xs[b].C, xs[b].H, xs[b].W, len(blocks)) if plain else 0
             if not step:
                 with self.on_lane(b):

@@ -69,6 +69,20 @@ def test_hrnet_w32_random_init_regime_meets_1e3():
     assert e < ABS_TOL
 
 
+def test_hrnet_w48_384x288_golden():
+    """BASELINE configs[2] backbone (channels 48/96/192/384, maps 96x72 ... 12x9): the per-conv kernels
+    (CINB=16 path, 48-channel maps in 64-channel buffers); the LDS-resident chains cover W32 widths only."""
+    cfg, model, sd, x, gold = load_case("hrnet_w48_384x288")
+    model = model.cuda()
+    with torch.no_grad():
+        y = model(x.cuda()).cpu()
+    assert y.shape == (2, 17, 96, 72)
+    ref = gold["heatmaps_crop0"]
+    e = _stats("W48 384x288 heatmaps", y[0], ref)
+    assert e < REL_TOL * float(ref.std())
+    assert maxabs(y[1, :, ::4, ::4], gold["heatmaps_crop1_sub"]) < REL_TOL * float(ref.std())
+
+
 def test_batch_sharding_is_invariant():
     """Crops are independent: a batch of 4 equals two batches of 2 (what --gpus N relies on)."""
     cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")

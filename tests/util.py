@@ -12,6 +12,7 @@ TAGS = {
     "hrnet_w32_256x192": ("pose_hrnet", 32, (192, 256), 17),
     "rsgnet_w32_256x192_coco": ("pose_rsgnet", 32, (192, 256), 17),
     "rsgnet_w32_256x192_crowdpose": ("pose_rsgnet", 32, (192, 256), 14),
+    "hrnet_w48_384x288": ("pose_hrnet", 48, (288, 384), 17),
 }
 
 
