@@ -233,7 +233,10 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
         case 32: chain_body<DT, 32, 1, 8, 5>(g.a[i], bid, smem); break;
         case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem); break;
         case 128: chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem); break;
-        case 256: chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem); break;
+        case 256:   // NT follows the pixels a workgroup owns (1 image = 48 px = 2 groups, 2 images = 3 groups)
+            if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) chain_body<DT, 256, 8, 1, 2>(g.a[i], bid, smem);
+            else chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem);
+            break;
     }
 }
 
@@ -256,7 +259,8 @@ extern "C" int rsg_tune(const char* key, int32_t value) {
 
 typedef void (*chain_fn)(const ChainArgs);
 template <class DT>
-static chain_fn chain_lookup(int C) {
+static chain_fn chain_lookup(int C, int npix) {
+    if (C == 256 && npix <= 64) return chain_kernel<DT, 256, 8, 1, 2>;
     switch (C) {
         case 32: return chain_kernel<DT, 32, 1, 8, 5>;
         case 64: return chain_kernel<DT, 64, 2, 4, 6>;
@@ -324,7 +328,8 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
         a.wpk[l] = (const uint4*)w_packed[l];
         a.bias[l] = bias[l];
     }
-    chain_fn fn = dtype == RSG_BF16 ? chain_lookup<BF16>(c) : chain_lookup<F16>(c);
+    const int npix = a.NI * a.R * w;
+    chain_fn fn = dtype == RSG_BF16 ? chain_lookup<BF16>(c, npix) : chain_lookup<F16>(c, npix);
     if (!fn) RSG_FAIL("basic_chain: no kernel for C=%d", c);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         RSG_FAIL("basic_chain: cannot reserve %d B of LDS", lds);

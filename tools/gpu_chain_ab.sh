@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || exit 1
-for pad in 0 1; do for grp in 0 1; do
+for pad in 1; do for grp in 0 1; do
   RSGNET_HIP_CHAIN_PITCH_PAD=$pad RSGNET_HIP_GROUP=$grp python bench.py --steps 10 --warmup 3 --no-cpu-baseline --per-op gpurun_out/po_${pad}_${grp}.json > gpurun_out/ab.log 2>&1
   python - <<PY
 import json
