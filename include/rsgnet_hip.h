@@ -155,6 +155,14 @@ int rsg_conv_fuse_group_run(const void* table_dev, int32_t blocks, int32_t lds, 
 int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t planes, int32_t h, int32_t w,
                             int32_t sigmoid, void* stream);
 
+/* Flip-test merge on the device (lib/core/function.py:400-427 with lib/utils/transforms.py:23-37):
+ * out = 0.5 * (h + shift(flip_back(h_flipped))), fp32 NCHW [batch,joints,height,width].  perm_host[j] is the
+ * channel of h_flipped that lands on joint j (identity with the dataset's flip_pairs swapped); HOST
+ * array.  shift_heatmap = cfg.TEST.SHIFT_HEATMAP. */
+int rsg_flip_merge_nchw_f32(const float* h, const float* h_flipped, const int32_t* perm_host, float* out,
+                            int32_t batch, int32_t joints, int32_t height, int32_t width,
+                            int32_t shift_heatmap, void* stream);
+
 /* ---- TRP: SpatialRelationHead (association.py:280-301) ---------------------------------------- */
 /* E[b,i,:] = sum_j sigmoid(<x_i,x_j>) * g_j   without materialising the S x S map.
  * x: [batch,S,ld_x] 16-bit (channels [0,C)), gT: [batch,C,S] 16-bit pair (hi, lo) of the projected

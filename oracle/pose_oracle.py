@@ -365,3 +365,16 @@ def rsgnet_forward(sd, cfg, x, relation_target=None, want_scores=True, **kw):
         if relation_target is not None:                                           # :1014-1018
             scores = ((relation_target.to(ctx.dtype) - scores) ** 2).mean(dim=(1, 2))
         return multi, kpt, limbs, scores
+
+
+def flip_test_merge(output, output_flipped, flip_pairs, shift_heatmap=True):
+    """lib/core/function.py:414-427 with lib/utils/transforms.py:23-37 (flip_back), restated with torch ops:
+    reverse W, swap the paired joint channels, shift one pixel to the right, average."""
+    f = output_flipped.flip(3).clone()
+    for a, b in flip_pairs:
+        tmp = f[:, a].clone()
+        f[:, a] = f[:, b]
+        f[:, b] = tmp
+    if shift_heatmap:
+        f[:, :, :, 1:] = f.clone()[:, :, :, 0:-1]
+    return (output + f) * 0.5

@@ -135,3 +135,50 @@ extern "C" int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t plan
     RSG_CHECK_LAUNCH("bilinear2x");
     return 0;
 }
+
+// ---- flip-test merge (lib/core/function.py:400-427, lib/utils/transforms.py:23-37) ---------------------
+// out = 0.5 * (h + shift(flip_back(hf))): flip_back reverses W and swaps the left/right joint channels,
+// SHIFT_HEATMAP moves the flipped map one pixel to the right (column 0 keeps its value).  The reference
+// does this on the host through numpy; here it is one fp32 NCHW pass.
+struct FlipArgs {
+    const float* h;
+    const float* hf;
+    float* out;
+    int J, H, W, shift;
+    long total;
+    int perm[64];
+};
+
+__global__ void __launch_bounds__(256) flip_merge_kernel(const FlipArgs a) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % a.W);
+        long t = i / a.W;
+        const int y = (int)(t % a.H);
+        t /= a.H;
+        const int j = (int)(t % a.J);
+        const long b = t / a.J;
+        const int xs = a.shift ? (x > 0 ? x - 1 : 0) : x;          // column of the un-shifted flipped-back map
+        const long src = ((b * a.J + a.perm[j]) * a.H + y) * a.W + (a.W - 1 - xs);
+        a.out[i] = 0.5f * (a.h[i] + a.hf[src]);
+    }
+}
+
+extern "C" int rsg_flip_merge_nchw_f32(const float* h, const float* h_flipped, const int32_t* perm_host,
+                                       float* out, int32_t batch, int32_t joints, int32_t height, int32_t width,
+                                       int32_t shift_heatmap, void* stream) {
+    if (!h || !h_flipped || !perm_host || !out) RSG_FAIL("flip_merge: null pointer");
+    if (joints < 1 || joints > 64 || batch < 1 || height < 1 || width < 1) RSG_FAIL("flip_merge: bad shape");
+    FlipArgs a;
+    memset(&a, 0, sizeof(a));
+    a.h = h; a.hf = h_flipped; a.out = out; a.J = joints; a.H = height; a.W = width; a.shift = shift_heatmap;
+    a.total = (long)batch * joints * height * width;
+    for (int j = 0; j < joints; ++j) {
+        if (perm_host[j] < 0 || perm_host[j] >= joints) RSG_FAIL("flip_merge: perm[%d]=%d", j, perm_host[j]);
+        a.perm[j] = perm_host[j];
+    }
+    long blocks = (a.total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    RSG_LAUNCH(flip_merge_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH("flip_merge");
+    return 0;
+}

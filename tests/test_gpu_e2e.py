@@ -127,3 +127,29 @@ def test_rsgnet_w32_golden(tag):
     emu = po.rsgnet_forward(sd, cfg, x, want_scores=False, emulate="fp16")
     for name, t, r in (("multi", multi, emu[0]), ("kpt", kpt, emu[1]), ("limbs", limbs, emu[2])):
         _stats(name + " vs fp16-emulating oracle", t.cpu(), r.numpy())
+
+
+CROWDPOSE_FLIP_PAIRS = [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9], [10, 11]]      # lib/dataset/crowdpose.py:988-989
+COCO_FLIP_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]   # lib/dataset/coco.py:92
+
+
+@pytest.mark.parametrize("shift", [True, False])
+def test_flip_merge_kernel_is_exact(shift):
+    from rsgnet_amd.flip import flip_merge
+    g = torch.Generator().manual_seed(3)
+    h, hf = torch.randn(3, 14, 16, 12, generator=g), torch.randn(3, 14, 16, 12, generator=g)
+    want = po.flip_test_merge(h, hf, CROWDPOSE_FLIP_PAIRS, shift)
+    got = flip_merge(h.cuda(), hf.cuda(), CROWDPOSE_FLIP_PAIRS, shift).cpu()
+    assert torch.equal(got, want)                    # same two fp32 operations per element
+
+
+def test_flip_test_forward_hrnet():
+    """One 2B forward + fused merge == the reference's two forwards + host flip_back (function.py:125-146)."""
+    from rsgnet_amd.flip import forward_flip_test
+    cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+    model = model.cuda()
+    with torch.no_grad():
+        got = forward_flip_test(model, x.cuda(), COCO_FLIP_PAIRS).cpu()
+    want = po.flip_test_merge(po.hrnet_forward(sd, cfg, x), po.hrnet_forward(sd, cfg, x.flip(3)), COCO_FLIP_PAIRS)
+    e = _stats("flip-test heatmaps", got, want.numpy())
+    assert e < REL_TOL * float(want.std())
