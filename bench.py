@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-GFLOP_PER_IMG = {"hrnet_w32_256x192": 15.29, "rsgnet_w32_256x192_coco": 17.80}
+GFLOP_PER_IMG = {"hrnet_w32_256x192": 15.29, "rsgnet_w32_256x192_coco": 17.80,
+                 "rsgnet_w32_256x192_crowdpose": 17.78, "hrnet_w48_384x288": 70.6}
 PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
 
 
@@ -43,7 +44,11 @@ def pmc_traffic(kernel_key):
 WORKLOADS = {
     "hrnet_w32_256x192": ("pose_hrnet", 32, (192, 256), 17, 64),
     "rsgnet_w32_256x192_coco": ("pose_rsgnet", 32, (192, 256), 17, 64),
+    "rsgnet_w32_256x192_crowdpose": ("pose_rsgnet", 32, (192, 256), 14, 64),     # BASELINE configs[4]
+    "hrnet_w48_384x288": ("pose_hrnet", 48, (288, 384), 17, 32),                 # BASELINE configs[2]
 }
+FLIP_PAIRS = {17: [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]],   # coco.py:92
+              14: [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9], [10, 11]]}                        # crowdpose.py:988
 
 
 def make_model(tag):
@@ -171,6 +176,8 @@ def main():
     ap.add_argument("--workload", default="hrnet_w32_256x192", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the metric's 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flip-test", action="store_true",
+                    help="a step = flip-tested heatmaps: one forward over [x ; x mirrored] + the fused merge")
     ap.add_argument("--per-op", default="", help="write a per-op timing table (JSON) to this path")
     a = ap.parse_args()
 
@@ -197,8 +204,14 @@ def main():
     model = model.to(dev)
     x = synth_input(batch, wh, seed=rank).to(dev)          # resident in HBM before the timed region
 
+    joints = WORKLOADS[a.workload][3]
+    if a.flip_test:
+        from rsgnet_amd.flip import forward_flip_test
+
     def step():
         with torch.no_grad():
+            if a.flip_test:
+                return forward_flip_test(model, x, FLIP_PAIRS[joints])
             return model(x)
 
     for _ in range(max(a.warmup, 1)):
@@ -209,7 +222,7 @@ def main():
 
     wall, dev_ms = timed_steps(step, a.steps, dist, dev)
 
-    plan = model.plan_for(x)
+    plan = model.plan_for(torch.cat((x, x)) if a.flip_test else x)
     # per-launch timing pass (outside the timed region, rank 0): every op of the launch list is re-run back
     # to back between HIP events on the launch stream; gives the per-kernel-family table and the roofline
     # of the dominant kernel
@@ -236,12 +249,13 @@ def main():
         ms = wall / a.steps * 1e3
         imgs = world * batch * a.steps / wall
         gflop = GFLOP_PER_IMG[a.workload]
-        whole = gflop * batch / (dev_ms / a.steps)               # GFLOP / ms = TFLOP/s over the whole step
+        fwd_imgs = batch * (2 if a.flip_test else 1)            # a flip-tested crop costs two forwards
+        whole = gflop * fwd_imgs / (dev_ms / a.steps)            # GFLOP / ms = TFLOP/s over the whole step
         dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["us"])
         ach = dom["gflop"] / (dom["us"] / 1e3)                   # GFLOP / ms = TFLOP/s
         line = {
-            "metric": "images/sec HRNet-W32 256x192 bs64 fwd" if a.workload.startswith("hrnet") else
-                      "images/sec RSGNet-W32 256x192 bs64 fwd",
+            "metric": {"hrnet_w32_256x192": "images/sec HRNet-W32 256x192 bs64 fwd"}.get(
+                a.workload, f"images/sec {a.workload} bs{batch} fwd") + (" flip-test" if a.flip_test else ""),
             "value": round(imgs, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": model.compute_dtype, "data": "synthetic",

@@ -280,7 +280,10 @@ class Plan:
             return 0
         info = (C.c_int32 * 4)()
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nblocks, self.batch, info) and info[0] == H:
-            return nblocks
+            # whole images stay in LDS.  RSGNET_HIP_CHAIN_SLICES=2 cuts the chain in two launches so that
+            # both grouped launches of a module hold a slice of EVERY branch (better balanced grids)
+            slices = int(os.environ.get("RSGNET_HIP_CHAIN_SLICES", "2"))
+            return max(1, nblocks // slices) if nblocks % max(slices, 1) == 0 else nblocks
         # row tiles: the MFMAs are far from busy on these wide, thin maps, so halo recompute is cheap;
         # RSGNET_HIP_ROWTILE_BLOCKS blocks per launch (default 2: measured best; 4 makes the 2.6x halo
         # recompute and the second wave of workgroups cost more than the saved launch), then 1
