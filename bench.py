@@ -63,8 +63,9 @@ def make_model(tag):
     return cfg, model.eval(), sd, wh, batch
 
 
-def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0):
-    """The CPU oracle (port of the reference's torch-CPU forward) timed on this box's host cores."""
+def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0, gpu_model=None):
+    """The CPU oracle (port of the reference's torch-CPU forward) timed on this box's host cores; the
+    same crops then go through the GPU model once, which gives the metric's "heatmap max-abs err"."""
     from oracle import pose_oracle as po
     from rsgnet_amd.weights import synth_input
     # the GPU box gives one GPU's share of the host: 16 cores (more threads than that only thrash)
@@ -81,8 +82,18 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0):
         fwd()
         best = min(best, time.time() - t0)
         n += 1
-    return {"value": round(b / best, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} forwards of batch {b} (best), {tag}, torch {torch.__version__} CPU fp32, eval"}
+    out = {"value": round(b / best, 2), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{n} forwards of batch {b} (best), {tag}, torch {torch.__version__} CPU fp32, eval"}
+    if gpu_model is not None:
+        ref = fwd()
+        with torch.no_grad():
+            got = gpu_model(x.to(next(gpu_model.parameters()).device))
+        pairs = [("heatmaps", got, ref)] if torch.is_tensor(got) else \
+                [(k, g, r) for k, g, r in zip(("multi_kpt_scores", "kpt_scores", "limbs_scores"), got[:3], ref[:3])]
+        out["parity_vs_fp32_cpu"] = {k: {"max_abs_err": float(f"{(g.float().cpu() - r).abs().max().item():.3e}"),
+                                         "ref_abs_max": round(float(r.abs().max()), 3),
+                                         "ref_std": round(float(r.std()), 3)} for k, g, r in pairs}
+    return out
 
 
 def timed_steps(step, steps, dist, dev):
@@ -277,7 +288,7 @@ def main():
                          "families": fam},
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh)
+            line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh, gpu_model=model)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
