@@ -123,6 +123,12 @@ int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype,
 int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch, int32_t c, int32_t h, int32_t w,
                            int32_t c_pad, int32_t dtype, void* stream);
 
+/* x.float NCHW -> space-to-depth(2) NHWC 16-bit [batch, h/2, w/2, 16]: channel (py*2+px)*c + k holds
+ * in[b,k,2Y+py,2X+px], channels 4c..15 are zero (c <= 4).  Lets a 3x3 stride-2 conv over few channels (the
+ * stem's conv1, pose_hrnet.py:285-286) run as a 2x2 stride-1 conv with pad (1,1). */
+int rsg_nchw_f32_to_s2d_nhwc16(const float* in, void* out, int32_t batch, int32_t c, int32_t h, int32_t w,
+                               int32_t dtype, void* stream);
+
 /* HighResolutionModule fuse for ONE output branch (pose_hrnet.py:259-266):
  *   out = ReLU( sum_k same[k] + sum_k nearest_up(low[k], low_shift[k]) )
  * same[k]: [batch,h,w,c] 16-bit (identity branch and the strided-conv results),

@@ -43,6 +43,56 @@ extern "C" int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch,
     return 0;
 }
 
+// ---- NCHW fp32 -> space-to-depth(2) NHWC 16-bit: out[b, Y, X, (py*2+px)*c + k] = in[b, k, 2Y+py, 2X+px] -------
+// With 3 input channels that is 12 of 16 channels per half-resolution pixel: the stem's 3x3 stride-2
+// conv1 (pose_hrnet.py:285-286) becomes a 2x2 stride-1 conv over this map (4 k-steps instead of 9, a
+// quarter of the bytes of the channel-padded full-resolution layout).
+template <class DT>
+__global__ void __launch_bounds__(256) nchw_to_s2d16_kernel(const float* __restrict__ in, char* __restrict__ out,
+                                                           int c, int h, int w, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one thread per output (half-res) pixel
+    if (i >= total) return;
+    const int w2 = w / 2, h2 = h / 2;
+    const int X = (int)(i % w2);
+    long t = i / w2;
+    const int Y = (int)(t % h2);
+    const long b = t / h2;
+    typename DT::elem v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (typename DT::elem)0.f;
+    for (int k = 0; k < c; ++k) {
+        const float* pl = in + ((b * c + k) * h + 2 * Y) * (long)w + 2 * X;
+        const float2 r0 = *reinterpret_cast<const float2*>(pl);
+        const float2 r1 = *reinterpret_cast<const float2*>(pl + w);
+        v[0 * c + k] = (typename DT::elem)r0.x;
+        v[1 * c + k] = (typename DT::elem)r0.y;
+        v[2 * c + k] = (typename DT::elem)r1.x;
+        v[3 * c + k] = (typename DT::elem)r1.y;
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + i * 32);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        typename DT::vec8 p8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p8[e] = v[q * 8 + e];
+        o[q] = __builtin_bit_cast(uint4, p8);
+    }
+}
+
+extern "C" int rsg_nchw_f32_to_s2d_nhwc16(const float* in, void* out, int32_t batch, int32_t c, int32_t h,
+                                          int32_t w, int32_t dtype, void* stream) {
+    if (!in || !out) RSG_FAIL("nchw_to_s2d: null pointer");
+    if (c < 1 || c > 4 || (h & 1) || (w & 1) || ((uintptr_t)in & 7)) RSG_FAIL("nchw_to_s2d: c=%d (<=4), even h,w required", c);
+    const long total = (long)batch * (h / 2) * (w / 2);
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == RSG_BF16)
+        RSG_LAUNCH(nchw_to_s2d16_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (char*)out, c, h, w, total);
+    else
+        RSG_LAUNCH(nchw_to_s2d16_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (char*)out, c, h, w, total);
+    RSG_CHECK_LAUNCH("nchw_to_s2d");
+    return 0;
+}
+
 // ---- HighResolutionModule fuse (pose_hrnet.py:259-266) ------------------------------------------------
 template <class DT>
 __global__ void __launch_bounds__(256) hr_fuse_kernel(const FuseArgs a) {

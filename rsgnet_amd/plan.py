@@ -646,6 +646,40 @@ class _BackboneMixin:
         self.custom("input_to_nhwc16", [], [x16], make)
         return x16
 
+    def _record_stem_s2d(self: Plan, m, H: int, W: int) -> VT:
+        """conv1 (3x3, stride 2, pad 1, 3 -> 64) as a 2x2 stride-1 conv over the space-to-depth input.
+
+        out[y,x] = sum w[ky,kx,c] in[2y+ky-1, 2x+kx-1, c]; the half-resolution pixel (Y,X) holds the four
+        phases in[2Y+py, 2X+px], so tap (a,b) in {0,1}^2 of the 2x2 conv reads pixel (y+a-1, x+b-1) and the
+        phase (py,px) of it carries w[2(a-1)+py+1, 2(b-1)+px+1] when that index is in [0,2], else 0."""
+        self.x_static = torch.zeros(self.batch, 3, H, W, dtype=torch.float32, device=self.device)
+        xs = self.new(H // 2, W // 2, 16, name="x_s2d16")
+        lib, B, dt = self.lib, self.batch, self.dtype
+
+        def make():
+            src, dst = self.x_static.data_ptr(), xs.ptr()
+
+            def launch(stream):
+                hip.check(lib.rsg_nchw_f32_to_s2d_nhwc16(src, dst, B, 3, H, W, dt, stream), "nchw_to_s2d")
+            return launch
+
+        self.custom("input_to_s2d_nhwc16", [], [xs], make)
+        w = m.conv1.weight.detach().float().cpu()                  # [64,3,3,3]
+        O = w.shape[0]
+        w2 = torch.zeros(O, 16, 2, 2)
+        for a in range(2):
+            for py in range(2):
+                ky = 2 * (a - 1) + py + 1
+                if not 0 <= ky <= 2:
+                    continue
+                for b in range(2):
+                    for px in range(2):
+                        kx = 2 * (b - 1) + px + 1
+                        if 0 <= kx <= 2:
+                            w2[:, (py * 2 + px) * 3:(py * 2 + px) * 3 + 3, a, b] = w[:, :, ky, kx]
+        return self.conv(xs, w2, m.bn1, m.conv1.bias, relu=True, pad=(1, 1), out_hw=(H // 2, W // 2),
+                         name="conv1(s2d 2x2)")
+
     def _unit(self: Plan, x: VT, conv: nn.Conv2d, bn, **kw) -> VT:
         return self.conv(x, conv.weight, bn, conv.bias, stride=conv.stride[0], **kw)
 
@@ -727,8 +761,11 @@ class _BackboneMixin:
         return outs
 
     def _record_backbone(self: Plan, m, H: int, W: int) -> List[VT]:
-        x = self._record_input(H, W)
-        x = self._unit(x, m.conv1, m.bn1, relu=True, name="conv1")
+        if os.environ.get("RSGNET_HIP_S2D", "1") != "0" and H % 2 == 0 and W % 2 == 0:
+            x = self._record_stem_s2d(m, H, W)
+        else:
+            x = self._record_input(H, W)
+            x = self._unit(x, m.conv1, m.bn1, relu=True, name="conv1")
         b0 = m.layer1[0]
         fold = (os.environ.get("RSGNET_HIP_L1CAT", "1") != "0" and b0.downsample is not None
                 and hasattr(b0, "conv3") and b0.downsample[0].kernel_size == (1, 1)
