@@ -60,7 +60,7 @@ typedef struct rsg_conv_desc {
     int32_t relu;
     int32_t dtype;             /* RSG_F16 | RSG_BF16 */
     int32_t tile_hint;         /* 0 = auto; else WM | NT<<4 | TH<<8 | TW<<16 (tuning/tests) */
-    int32_t reserved;
+    int32_t relu_tile_mask;    /* 0 = use `relu` for all channels; else bit t = ReLU on output channels [32t, 32t+32) */
 } rsg_conv_desc;
 
 int rsg_conv_igemm(const rsg_conv_desc* d, void* stream);
@@ -147,6 +147,9 @@ typedef struct rsg_fuse_item {
     int32_t n_same, n_low;
     void* out;
     int32_t batch, h, w, c;
+    int32_t same_ld[4];        /* channel stride of each operand (0 = dense, i.e. c): operands may be */
+    int32_t low_ld[3];         /* channel slices of wider buffers                                       */
+    int32_t reserved;
 } rsg_fuse_item;
 int rsg_conv_groupable(const rsg_conv_desc* d);
 /* two steps: _plan (HOST) writes the launch table (rsg_group_table_bytes bytes) and launch2 = {grid

@@ -136,7 +136,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
                 for (int e = 0; e < 8; ++e) v[k * 8 + e] += (float)rh[e];
             }
         }
-        if (p.relu) {
+        if ((p.relu >> (ct & 31)) & 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
         }

@@ -178,7 +178,9 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     a.Hout = d->out_h; a.Wout = d->out_w; a.Cout = d->out_c; a.ldo = d->out_ld; a.ldr = d->res_ld;
     a.SI = d->stride; a.oy0 = -d->pad_y; a.ox0 = -d->pad_x;
     a.up = d->up; a.upy = d->up_y; a.upx = d->up_x; a.Hp = d->phys_h; a.Wp = d->phys_w;
-    a.relu = d->relu;
+    // bit t = ReLU on the t-th 32-channel output tile; relu_tile_mask lets one launch mix convs with and
+    // without ReLU (fan-out fusion of the HRNet fuse layers)
+    a.relu = d->relu_tile_mask ? d->relu_tile_mask : (d->relu ? -1 : 0);
     a.TH = t.TH; a.TW = t.TW; a.TIH = t.TIH; a.TIW = t.TIW; a.RP = t.RP;
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     a.nchunks = d->in_c / t.CINB;

@@ -100,14 +100,23 @@ __global__ void __launch_bounds__(256) hr_fuse_kernel(const FuseArgs a) {
 }
 
 int rsg_fuse_prepare(const void* const* same, int n_same, const void* const* low, const int32_t* low_shift,
-                     int n_low, void* out, int batch, int h, int w, int c, FuseArgs& a, int& blocks) {
+                     int n_low, void* out, int batch, int h, int w, int c, FuseArgs& a, int& blocks,
+                     const int32_t* same_ld, const int32_t* low_ld) {
     if (n_same < 1 || n_same > 4 || n_low < 0 || n_low > 3 || !out) RSG_FAIL("hr_fuse: bad operand count");
     if (c % 8) RSG_FAIL("hr_fuse: channels %d not a multiple of 8", c);
     memset(&a, 0, sizeof(a));
-    for (int k = 0; k < n_same; ++k) a.same[k] = (const char*)same[k];
+    for (int k = 0; k < n_same; ++k) {
+        a.same[k] = (const char*)same[k];
+        const int ld = same_ld && same_ld[k] ? same_ld[k] : c;
+        if (ld < c || ld % 8 || ((uintptr_t)same[k] & 15)) RSG_FAIL("hr_fuse: operand %d stride %d / alignment", k, ld);
+        a.ld_same[k] = ld / 8;
+    }
     for (int k = 0; k < n_low; ++k) {
         a.low[k] = (const char*)low[k];
         a.shift[k] = low_shift[k];
+        const int ld = low_ld && low_ld[k] ? low_ld[k] : c;
+        if (ld < c || ld % 8 || ((uintptr_t)low[k] & 15)) RSG_FAIL("hr_fuse: low operand %d stride %d / alignment", k, ld);
+        a.ld_low[k] = ld / 8;
         if ((h & ((1 << a.shift[k]) - 1)) || (w & ((1 << a.shift[k]) - 1)) || a.shift[k] < 1)
             RSG_FAIL("hr_fuse: %dx%d not divisible by 2^%d", h, w, a.shift[k]);
     }

@@ -9,6 +9,8 @@ struct FuseArgs {
     int n_same, n_low;
     char* out;
     int h, w, c8;   // c8 = channels / 8
+    int ld_same[4]; // 16-byte vectors per pixel of each operand (c8 when dense)
+    int ld_low[3];
     long total;     // batch*h*w*c8 16-byte vectors
 };
 
@@ -18,9 +20,11 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, const int block, co
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        const int cg0 = (int)(i % a.c8);
+        const long pix0 = i / a.c8;
         for (int k = 0; k < a.n_same; ++k) {
-            const typename DT::vec8 v =
-                __builtin_bit_cast(typename DT::vec8, reinterpret_cast<const uint4*>(a.same[k])[i]);
+            const typename DT::vec8 v = __builtin_bit_cast(
+                typename DT::vec8, reinterpret_cast<const uint4*>(a.same[k])[pix0 * a.ld_same[k] + cg0]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
         }
@@ -33,7 +37,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, const int block, co
             const long b = pix / a.h;
             for (int k = 0; k < a.n_low; ++k) {
                 const int s = a.shift[k];
-                const long src = ((b * (a.h >> s) + (y >> s)) * (a.w >> s) + (x >> s)) * a.c8 + cg;
+                const long src = ((b * (a.h >> s) + (y >> s)) * (a.w >> s) + (x >> s)) * a.ld_low[k] + cg;
                 const typename DT::vec8 v =
                     __builtin_bit_cast(typename DT::vec8, reinterpret_cast<const uint4*>(a.low[k])[src]);
 #pragma unroll
@@ -49,4 +53,5 @@ __device__ __forceinline__ void fuse_body(const FuseArgs& a, const int block, co
 
 
 int rsg_fuse_prepare(const void* const* same, int n_same, const void* const* low, const int32_t* low_shift,
-                     int n_low, void* out, int batch, int h, int w, int c, FuseArgs& a, int& blocks);
+                     int n_low, void* out, int batch, int h, int w, int c, FuseArgs& a, int& blocks,
+                     const int32_t* same_ld = nullptr, const int32_t* low_ld = nullptr);

@@ -109,7 +109,8 @@ extern "C" int rsg_conv_fuse_group_plan(const rsg_conv_desc* convs, int32_t n_co
     for (int i = 0; i < n_fuses; ++i) {
         const rsg_fuse_item& f = fuses[i];
         int nb = 0;
-        if (rsg_fuse_prepare(f.same, f.n_same, f.low, f.low_shift, f.n_low, f.out, f.batch, f.h, f.w, f.c, g.fuse[i], nb))
+        if (rsg_fuse_prepare(f.same, f.n_same, f.low, f.low_shift, f.n_low, f.out, f.batch, f.h, f.w, f.c, g.fuse[i], nb,
+                             f.same_ld, f.low_ld))
             return 1;
         if (nb > 1024) nb = 1024;
         g.first[n_convs + i] = blocks;

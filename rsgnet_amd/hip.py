@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         ("out_h", C.c_int32), ("out_w", C.c_int32), ("out_c", C.c_int32), ("out_ld", C.c_int32), ("res_ld", C.c_int32),
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
         ("up", C.c_int32), ("up_y", C.c_int32), ("up_x", C.c_int32), ("phys_h", C.c_int32), ("phys_w", C.c_int32),
-        ("relu", C.c_int32), ("dtype", C.c_int32), ("tile_hint", C.c_int32), ("reserved", C.c_int32),
+        ("relu", C.c_int32), ("dtype", C.c_int32), ("tile_hint", C.c_int32), ("relu_tile_mask", C.c_int32),
     ]
 
 
@@ -31,7 +31,8 @@ class FuseItem(C.Structure):
     """struct rsg_fuse_item (include/rsgnet_hip.h)."""
     _fields_ = [("same", C.c_void_p * 4), ("low", C.c_void_p * 3), ("low_shift", C.c_int32 * 3),
                 ("n_same", C.c_int32), ("n_low", C.c_int32), ("out", C.c_void_p), ("batch", C.c_int32),
-                ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32)]
+                ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("same_ld", C.c_int32 * 4),
+                ("low_ld", C.c_int32 * 3), ("reserved", C.c_int32)]
 
 
 class ChainItem(C.Structure):

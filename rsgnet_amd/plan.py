@@ -82,6 +82,7 @@ class Plan:
         self.use_graph = self.graph_mode != "0"
         self.use_chain = os.environ.get("RSGNET_HIP_CHAIN", "1") != "0"
         self.use_group = os.environ.get("RSGNET_HIP_GROUP", "1") != "0"
+        self.use_fanout = os.environ.get("RSGNET_HIP_FANOUT", "0") != "0"   # measured +0.7%: merged convs still stage per 32-channel block
         self.conv_log: List[dict] = []
         self.flops = 0
         # lanes = HIP streams the launches are spread over (independent HRNet branches run concurrently);
@@ -205,9 +206,10 @@ class Plan:
     def conv(self, x: VT, weight: torch.Tensor, bn: Optional[nn.Module] = None, bias=None, *, stride=1,
              relu=False, residual: Optional[VT] = None, out: Optional[VT] = None,
              out_f32: Optional[torch.Tensor] = None, want16=True, pad=None, up=(1, 0, 0),
-             out_hw=None, phys_hw=None, name="", extra_shift=None) -> Optional[VT]:
+             out_hw=None, phys_hw=None, name="", extra_shift=None, scale_shift=None,
+             relu_mask=0) -> Optional[VT]:
         """Record conv(+BN)(+bias)(+residual)(+ReLU).  ``x.C`` must be the padded input channels."""
-        scale, shift = self.bn_fold(bn)
+        scale, shift = self.bn_fold(bn) if scale_shift is None else scale_shift
         if extra_shift is not None:
             shift = extra_shift if shift is None else shift + extra_shift
         wp, bo, I, O = self.pack_conv(weight, scale, shift, bias)
@@ -232,9 +234,38 @@ class Plan:
             raise ValueError(f"{name}: output buffer is {out.H}x{out.W}, conv writes {phys_hw}")
         self._record(dict(kind="conv", x=x, wp=wp, bias=bo, res=residual, out=out, out_f32=out_f32,
                           I=cin_pad, O=O, kh=kh, kw=kw, stride=stride, pad=pad, up=up, out_hw=out_hw,
-                          phys_hw=phys_hw, relu=relu, name=name), [x, residual], [out, out_f32])
+                          phys_hw=phys_hw, relu=relu, relu_mask=relu_mask, name=name), [x, residual], [out, out_f32])
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
+
+    def conv_multi(self, x: VT, parts, name="") -> List[VT]:
+        """Several convs that read the SAME input with the same geometry as ONE conv with concatenated output
+        channels (fan-out fusion): parts = [(conv, bn, relu)], every cout a multiple of 32.  Returns one
+        channel view per part."""
+        ws, scs, shs, mask, off = [], [], [], 0, 0
+        for conv, bn, relu in parts:
+            sc, sh = self.bn_fold(bn)
+            O = conv.out_channels
+            if O % 32 or conv.bias is not None:
+                raise ValueError("conv_multi needs bias-free convs with cout % 32 == 0")
+            ws.append(conv.weight.detach().float().cpu())
+            scs.append(sc)
+            shs.append(sh)
+            if relu:
+                for t in range(off // 32, (off + O) // 32):
+                    mask |= 1 << t
+            off += O
+        if off > 1024:
+            raise ValueError("conv_multi: more than 32 output tiles")
+        c0 = parts[0][0]
+        out = self.conv(x, torch.cat(ws, 0), None, None, stride=c0.stride[0], relu=False,
+                        scale_shift=(torch.cat(scs), torch.cat(shs)), relu_mask=mask if mask else 0,
+                        name=name)
+        views, off = [], 0
+        for conv, _bn, _r in parts:
+            views.append(out.view(off, conv.out_channels))
+            off += conv.out_channels
+        return views
 
     def fuse(self, same: Sequence[VT], low: Sequence[Tuple[VT, int]], name="") -> VT:
         ref = same[0]
@@ -389,6 +420,7 @@ class Plan:
         d.up, d.up_y, d.up_x = r["up"]
         d.phys_h, d.phys_w = r["phys_hw"]
         d.relu = 1 if r["relu"] else 0
+        d.relu_tile_mask = r.get("relu_mask", 0)
         d.dtype = self.dtype
         d.tile_hint = 0
         return d
@@ -415,15 +447,16 @@ class Plan:
 
     def _fuse_item(self, r) -> "hip.FuseItem":
         same, low, out = r["same"], r["low"], r["out"]
-        for v in list(same) + [v for v, _ in low]:
-            if v.ld != v.C or v.coff:
-                raise ValueError("fuse operands must be dense tensors")
+        if out.ld != out.C or out.coff:
+            raise ValueError("fuse output must be a dense tensor")
         it = hip.FuseItem()
         for k, v in enumerate(same):
             it.same[k] = v.ptr()
+            it.same_ld[k] = v.ld
         for k, (v, sh) in enumerate(low):
             it.low[k] = v.ptr()
             it.low_shift[k] = sh
+            it.low_ld[k] = v.ld
         it.n_same, it.n_low, it.out = len(same), len(low), out.ptr()
         it.batch, it.h, it.w, it.c = self.batch, out.H, out.W, out.C
         return it
@@ -455,23 +488,8 @@ class Plan:
         self.ops.append((nm, launch))
 
     def _lower_fuse(self, r):
-        same, low, out = r["same"], r["low"], r["out"]
-        for v in list(same) + [v for v, _ in low]:
-            if v.ld != v.C or v.coff:
-                raise ValueError("fuse operands must be dense tensors")
-        sp = (C.c_void_p * 4)(*[v.ptr() for v in same])
-        lp = (C.c_void_p * 3)(*[v.ptr() for v, _ in low])
-        sh = (C.c_int32 * 3)(*[s for _, s in low])
-        self._keep += [sp, lp, sh]
-        args = (sp, len(same), lp, sh, len(low), out.ptr(), self.batch, out.H, out.W, out.C, self.dtype)
-        fn, nm = self.lib.rsg_hr_fuse_sum, r["name"]
-
-        def launch(stream):
-            rc = fn(*args, stream)
-            if rc:
-                hip.check(rc, nm)
-
-        self.ops.append((r["name"], launch))
+        # a lone fuse-sum is a group of one (the grouped entry point takes strided operands)
+        self._lower_group(dict(subs=[r], name=r["name"]))
 
     def _lower_chain(self, r):
         x, out, layers = r["x"], r["out"], r["layers"]
@@ -743,15 +761,30 @@ class _BackboneMixin:
         ready = {i: max([d for (ii, _), d in depth.items() if ii == i], default=0) for i in range(n_out)}
         for level in range(max_depth + 1):
             self.begin_group()
+            # convs of this level, bucketed by (input tensor, geometry): same-bucket convs share one launch
+            # item with concatenated output channels (fan-out fusion: the input tile is staged once)
+            buckets: Dict[tuple, list] = {}
             for (i, j), dep in depth.items():
                 if level < dep:
                     fl = rows[i][j]
-                    if j > i:
-                        cur[(i, j)] = self._unit(cur[(i, j)], fl[0], fl[1], name=f"{name}.fuse.{i}.{j}")
-                    else:
-                        step = fl[level]
-                        cur[(i, j)] = self._unit(cur[(i, j)], step[0], step[1], relu=(level != dep - 1),
-                                                 name=f"{name}.fuse.{i}.{j}.{level}")
+                    conv, bnm = (fl[0], fl[1]) if j > i else (fl[level][0], fl[level][1])
+                    relu = False if j > i else (level != dep - 1)
+                    xin = cur[(i, j)]
+                    key = (id(xin.base), xin.coff, xin.C, conv.kernel_size, conv.stride)
+                    buckets.setdefault(key, []).append(((i, j), xin, conv, bnm, relu))
+            for items in buckets.values():
+                mergeable = self.use_fanout and len(items) > 1 and \
+                    all(c.out_channels % 32 == 0 and c.bias is None for _, _, c, _, _ in items)
+                if mergeable:
+                    xin = items[0][1]
+                    views = self.conv_multi(xin, [(c, b, r) for _, _, c, b, r in items],
+                                            name=f"{name}.fuse.L{level}.from{items[0][0][1]}x{len(items)}")
+                    for (ij, _x, _c, _b, _r), v in zip(items, views):
+                        cur[ij] = v
+                else:
+                    for ij, xin, conv, bnm, relu in items:
+                        cur[ij] = self._unit(xin, conv, bnm, relu=relu,
+                                             name=f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level}"))
             for i in range(n_out):
                 if ready[i] == level:                    # every addend was finished by the previous level
                     same = [cur[(i, j)] for j in range(i)] + [xs[i]]
