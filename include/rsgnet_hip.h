@@ -172,6 +172,15 @@ int rsg_flip_merge_nchw_f32(const float* h, const float* h_flipped, const int32_
                             int32_t batch, int32_t joints, int32_t height, int32_t width,
                             int32_t shift_heatmap, void* stream);
 
+/* get_final_preds on the device (lib/core/inference.py:52-82): per (crop, joint) argmax (first index on
+ * ties), zero when max <= 0, +-0.25 px towards the larger neighbour when post_process, then the inverse
+ * crop affine for rot = 0.  heat fp32 [batch,joints,height,width]; center, scale fp32 [batch,2] (as
+ * produced by the datasets: scale in units of 200 px); preds fp32 [batch,joints,2] in image pixels;
+ * maxvals fp32 [batch,joints]. */
+int rsg_decode_heatmaps(const float* heat, const float* center, const float* scale, float* preds, float* maxvals,
+                        int32_t batch, int32_t joints, int32_t height, int32_t width, int32_t post_process,
+                        void* stream);
+
 /* ---- TRP: SpatialRelationHead (association.py:280-301) ---------------------------------------- */
 /* E[b,i,:] = sum_j sigmoid(<x_i,x_j>) * g_j   without materialising the S x S map.
  * x: [batch,S,ld_x] 16-bit (channels [0,C)), gT: [batch,C,S] 16-bit pair (hi, lo) of the projected

@@ -378,3 +378,54 @@ def flip_test_merge(output, output_flipped, flip_pairs, shift_heatmap=True):
     if shift_heatmap:
         f[:, :, :, 1:] = f.clone()[:, :, :, 0:-1]
     return (output + f) * 0.5
+
+
+def _affine_from_points(src, dst):
+    """What cv2.getAffineTransform(src, dst) returns (third-party, not installed here): the 2x3 matrix
+    mapping the three src points onto the three dst points, solved in float64."""
+    a = np.hstack([np.asarray(src, np.float64), np.ones((3, 1))])
+    return np.linalg.solve(a, np.asarray(dst, np.float64)).T
+
+
+def inverse_crop_affine(center, scale, output_size):
+    """get_affine_transform(center, scale, rot=0, output_size, inv=1), lib/utils/transforms.py:65-101."""
+    scale_tmp = np.asarray(scale, np.float32) * 200.0
+    src_w, dst_w, dst_h = scale_tmp[0], output_size[0], output_size[1]
+    src = np.zeros((3, 2), np.float32)
+    dst = np.zeros((3, 2), np.float32)
+    src[0] = center
+    src[1] = np.asarray(center, np.float32) + np.array([0, src_w * -0.5], np.float32)
+    dst[0] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1] = np.array([dst_w * 0.5, dst_h * 0.5]) + np.array([0, dst_w * -0.5], np.float32)
+    for p in (src, dst):                     # get_3rd_point: a + (-(a-b).y, (a-b).x) rotated by 90 degrees
+        d = p[0] - p[1]
+        p[2] = p[1] + np.array([-d[1], d[0]], np.float32)
+    return _affine_from_points(dst, src)
+
+
+def final_preds(batch_heatmaps, center, scale, post_process=True):
+    """get_max_preds + get_final_preds, lib/core/inference.py:21-82 (numpy, loops and all)."""
+    hm = np.asarray(batch_heatmaps, np.float32)
+    b, j, h, w = hm.shape
+    flat = hm.reshape(b, j, -1)
+    idx = np.argmax(flat, 2)
+    maxvals = np.amax(flat, 2).reshape(b, j, 1)
+    coords = np.zeros((b, j, 2), np.float32)
+    coords[:, :, 0] = idx % w
+    coords[:, :, 1] = np.floor(idx / w)
+    coords *= np.tile(np.greater(maxvals, 0.0), (1, 1, 2)).astype(np.float32)
+    if post_process:
+        for n in range(b):
+            for p in range(j):
+                m = hm[n][p]
+                px = int(math.floor(coords[n][p][0] + 0.5))
+                py = int(math.floor(coords[n][p][1] + 0.5))
+                if 1 < px < w - 1 and 1 < py < h - 1:
+                    diff = np.array([m[py][px + 1] - m[py][px - 1], m[py + 1][px] - m[py - 1][px]])
+                    coords[n][p] += np.sign(diff) * .25
+    preds = coords.copy()
+    for i in range(b):
+        t = inverse_crop_affine(center[i], scale[i], [w, h])
+        for p in range(j):
+            preds[i, p] = t @ np.array([coords[i, p, 0], coords[i, p, 1], 1.0])
+    return preds, maxvals

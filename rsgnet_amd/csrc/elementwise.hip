@@ -241,3 +241,56 @@ extern "C" int rsg_flip_merge_nchw_f32(const float* h, const float* h_flipped, c
     RSG_CHECK_LAUNCH("flip_merge");
     return 0;
 }
+
+// ---- heatmap decode (lib/core/inference.py:21-82, lib/utils/transforms.py:57-101) ---------------------
+// One wave per (crop, joint): argmax with numpy's first-index tie-break, coordinates zeroed when the maximum
+// is <= 0, quarter-pixel refinement towards the larger neighbour (POST_PROCESS), then the inverse crop
+// affine.  With rot = 0 that affine is x' = cx + (x - W/2) * s, y' = cy + (y - H/2) * s, s = 200*scale_x/W
+// (get_affine_transform builds it from the width only).  The reference does this on the host in a Python
+// double loop after copying the full heatmaps off the GPU.
+__global__ void __launch_bounds__(64) decode_kernel(const float* __restrict__ heat, const float* __restrict__ center,
+                                                   const float* __restrict__ scale, float* __restrict__ preds,
+                                                   float* __restrict__ maxvals, int J, int H, int W, int post) {
+    const int bj = blockIdx.x, b = bj / J, lane = threadIdx.x;
+    const float* hm = heat + (size_t)bj * H * W;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < H * W; i += 64) {
+        const float v = hm[i];
+        if (v > best) { best = v; bi = i; }          // strictly greater: keeps the first index per lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        float x = (float)(bi % W), y = (float)(bi / W);
+        if (!(best > 0.f)) { x = 0.f; y = 0.f; }
+        if (post) {
+            const int px = (int)floorf(x + 0.5f), py = (int)floorf(y + 0.5f);
+            if (1 < px && px < W - 1 && 1 < py && py < H - 1) {
+                const float dx = hm[py * W + px + 1] - hm[py * W + px - 1];
+                const float dy = hm[(py + 1) * W + px] - hm[(py - 1) * W + px];
+                x += (dx > 0.f ? 0.25f : (dx < 0.f ? -0.25f : 0.f));
+                y += (dy > 0.f ? 0.25f : (dy < 0.f ? -0.25f : 0.f));
+            }
+        }
+        const float s = scale[2 * b] * 200.0f / (float)W;
+        preds[2 * bj] = center[2 * b] + (x - 0.5f * (float)W) * s;
+        preds[2 * bj + 1] = center[2 * b + 1] + (y - 0.5f * (float)H) * s;
+        maxvals[bj] = best;
+    }
+}
+
+extern "C" int rsg_decode_heatmaps(const float* heat, const float* center, const float* scale, float* preds,
+                                   float* maxvals, int32_t batch, int32_t joints, int32_t height, int32_t width,
+                                   int32_t post_process, void* stream) {
+    if (!heat || !center || !scale || !preds || !maxvals) RSG_FAIL("decode: null pointer");
+    if (batch < 1 || joints < 1 || height < 1 || width < 1) RSG_FAIL("decode: bad shape");
+    RSG_LAUNCH(decode_kernel, dim3(batch * joints), dim3(64), 0, (hipStream_t)stream, heat, center, scale, preds,
+               maxvals, joints, height, width, post_process);
+    RSG_CHECK_LAUNCH("decode");
+    return 0;
+}

@@ -153,3 +153,27 @@ def test_flip_test_forward_hrnet():
     want = po.flip_test_merge(po.hrnet_forward(sd, cfg, x), po.hrnet_forward(sd, cfg, x.flip(3)), COCO_FLIP_PAIRS)
     e = _stats("flip-test heatmaps", got, want.numpy())
     assert e < REL_TOL * float(want.std())
+
+
+def test_decode_matches_reference_semantics():
+    """rsg_decode_heatmaps vs the numpy restatement of get_final_preds: indices exact, coordinates to 1e-3 px;
+    includes ties, non-positive maxima and maxima on the border (no refinement there)."""
+    from rsgnet_amd.decode import get_final_preds
+    g = torch.Generator().manual_seed(11)
+    B, J, H, W = 3, 17, 64, 48
+    hm = torch.randn(B, J, H, W, generator=g)
+    hm[0, 0] = -1.0                                   # max <= 0 -> coordinates zeroed
+    hm[0, 1] = 0.0
+    hm[0, 1, 10, 7] = 2.0
+    hm[0, 1, 30, 20] = 2.0                            # tie: first index wins
+    hm[0, 2, 0, 5] = 9.0                              # border maximum: no quarter-pixel shift
+    hm[0, 3, 63, 47] = 9.0
+    center = np.array([[100.5, 200.25], [320.0, 240.0], [55.0, 77.0]], np.float32)
+    scale = np.array([[1.2, 1.6], [0.8, 1.0667], [2.5, 3.333]], np.float32)
+    want_p, want_m = po.final_preds(hm.numpy(), center, scale, True)
+    got_p, got_m = get_final_preds(hm.cuda(), center, scale, True)
+    assert torch.equal(got_m.cpu().reshape(B, J), torch.from_numpy(want_m).reshape(B, J))
+    assert maxabs(got_p.cpu(), want_p) < 1e-3
+    want_p0, _ = po.final_preds(hm.numpy(), center, scale, False)
+    got_p0, _ = get_final_preds(hm.cuda(), center, scale, False)
+    assert maxabs(got_p0.cpu(), want_p0) < 1e-3
