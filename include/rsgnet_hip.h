@@ -39,7 +39,7 @@ int rsg_tune(const char* key, int32_t value);
  * Input  : [batch, in_h, in_w, in_ld] 16-bit, the conv reads channels [0, in_c) of each pixel
  *          (pass a pointer already offset to the first channel when reading a slice of a concat buffer);
  *          in_c must equal rsg_conv_padded_cin(real cin) and the padding channels must hold zeros.
- * Output : out16  [batch, phys_h, phys_w, out_ld] 16-bit, channels [0, round_up(out_c,32)) written
+ * Output : out16  [batch, phys_h, phys_w, out_ld] 16-bit, channels [0, round_up(out_c,32)) written (or out_c_store)
  *          (padding channels get bias-only values = 0 when packed by the packer), and/or
  *          out_nchw_f32 [batch, out_c, phys_h, phys_w] fp32 (classifier heads).
  * Geometry: logical output pixel (y,x), y<out_h, x<out_w reads input (y*stride + ky - pad_y, ...)
@@ -61,6 +61,9 @@ typedef struct rsg_conv_desc {
     int32_t dtype;             /* RSG_F16 | RSG_BF16 */
     int32_t tile_hint;         /* 0 = auto; else WM | NT<<4 | TH<<8 | TW<<16 (tuning/tests) */
     int32_t relu_tile_mask;    /* 0 = use `relu` for all channels; else bit t = ReLU on output channels [32t, 32t+32) */
+    int32_t out_c_store;       /* 0 = write round_up(out_c,32) channels of out16; else only [0, out_c_store) (multiple
+                                  of 8): for outputs that are a channel slice narrower than a 32-channel tile */
+    int32_t reserved;
 } rsg_conv_desc;
 
 int rsg_conv_igemm(const rsg_conv_desc* d, void* stream);

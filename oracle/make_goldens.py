@@ -124,8 +124,9 @@ def generate(tag: str) -> None:
         outs = {"multi_kpt_scores": multi, "kpt_scores": kpt, "limbs_scores": limbs}
     else:
         outs = {"heatmaps": out}
+    big = wh[0] * wh[1] > 192 * 256 and is_rsg      # 384x288 RSGNet: keep fixtures small, store every 2nd pixel
     for k, v in outs.items():
-        gold[k + "_crop0"] = v[0].numpy()
+        gold[k + "_crop0"] = v[0, :, ::2, ::2].numpy() if big else v[0].numpy()
         gold[k + "_max"], gold[k + "_argmax"] = _summ(v)
         gold[k + "_crop1_sub"] = v[1, :, ::4, ::4].numpy()
     gold["layer1_crop0_sub"] = taps["layer1"][0, ::8, ::2, ::2].numpy()
@@ -134,12 +135,14 @@ def generate(tag: str) -> None:
     if is_rsg:
         S = rel.shape[1]
         idx = sample_index(S)
-        gold["final_vis_crop0"] = taps["final_vis"][0].numpy()
-        gold["relation_feats_crop0"] = taps["relation_head"][0][0].numpy()
+        gold["final_vis_crop0"] = taps["final_vis"][0, :, ::2, ::2].numpy() if big else taps["final_vis"][0].numpy()
+        rf = taps["relation_head"][0][0]
+        gold["relation_feats_crop0"] = rf[:, ::2, ::2].numpy() if big else rf.numpy()
         gold["relation_scores_rowsum"] = rel.sum(dim=2).numpy()
         gold["relation_scores_samples"] = rel[:, idx[:, 0], idx[:, 1]].numpy()
         gold["limb_weights"] = taps["limb_weights"].numpy()
-        gold["limbs_features_crop0"] = taps["limbs_features"][0].numpy()
+        lfe = taps["limbs_features"][0]
+        gold["limbs_features_crop0"] = lfe[:, ::2, ::2].numpy() if big else lfe.numpy()
         # training-tail variant: relation_target given -> per-sample MSE [B] (pose_rsgnet.py:1014-1018)
         r = np.random.RandomState(11)
         p = torch.from_numpy(r.uniform(0, 1, (EVAL_BATCH, S)).astype(np.float32))

@@ -11,6 +11,7 @@ struct ConvArgs {
     float* out32;
     int B, Hin, Win, ldi;
     int Hout, Wout, Cout, ldo, ldr;
+    int CoutStore;   // channels [0, CoutStore) are written to the 16-bit output (multiple of 8)
     int SI, oy0, ox0;
     int up, upy, upx, Hp, Wp;
     int relu;

@@ -147,7 +147,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
                 typename DT::vec8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (typename DT::elem)v[k * 8 + e];
-                *reinterpret_cast<uint4*>(op + k * 16) = __builtin_bit_cast(uint4, o);
+                if (cbase + k * 8 < p.CoutStore) *reinterpret_cast<uint4*>(op + k * 16) = __builtin_bit_cast(uint4, o);
             }
         }
         if (p.out32) {

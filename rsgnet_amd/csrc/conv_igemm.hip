@@ -163,7 +163,9 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     if (d->in_ld < d->in_c || (d->in_ld % 8) || d->in_c != rsg_conv_padded_cin(d->in_c))
         RSG_FAIL("conv: in_c=%d in_ld=%d must be padded/aligned (multiple of 8, in_c padded)", d->in_c, d->in_ld);
     const int cout_pad = round_up(d->out_c, 32);
-    if (d->out16 && (d->out_ld < cout_pad || d->out_ld % 8)) RSG_FAIL("conv: out_ld=%d < padded cout %d", d->out_ld, cout_pad);
+    const int store = d->out_c_store ? d->out_c_store : cout_pad;
+    if (store % 8 || store > cout_pad || store < 8) RSG_FAIL("conv: out_c_store=%d", d->out_c_store);
+    if (d->out16 && (d->out_ld < store || d->out_ld % 8)) RSG_FAIL("conv: out_ld=%d < stored channels %d", d->out_ld, store);
     if (d->residual && (d->res_ld < cout_pad || d->res_ld % 8)) RSG_FAIL("conv: res_ld=%d", d->res_ld);
     if (d->up < 1 || d->up_y < 0 || d->up_x < 0 || (d->out_h - 1) * d->up + d->up_y >= d->phys_h ||
         (d->out_w - 1) * d->up + d->up_x >= d->phys_w)
@@ -176,6 +178,7 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     a.res = (const char*)d->residual; a.out = (char*)d->out16; a.out32 = d->out_nchw_f32;
     a.B = d->batch; a.Hin = d->in_h; a.Win = d->in_w; a.ldi = d->in_ld;
     a.Hout = d->out_h; a.Wout = d->out_w; a.Cout = d->out_c; a.ldo = d->out_ld; a.ldr = d->res_ld;
+    a.CoutStore = store;
     a.SI = d->stride; a.oy0 = -d->pad_y; a.ox0 = -d->pad_x;
     a.up = d->up; a.upy = d->up_y; a.upx = d->up_x; a.Hp = d->phys_h; a.Wp = d->phys_w;
     // bit t = ReLU on the t-th 32-channel output tile; relu_tile_mask lets one launch mix convs with and

@@ -38,9 +38,15 @@ struct TrpArgs {
     float inv_ss;
 };
 
-template <class DT, int MODE>
+// C = channels of x and g (32: HRNet-W32 head, 48: W48 head).  The value product pads its output channels
+// to CP = 32 or 64 (MFMA rows); the rows of the G^T tile beyond C stay zero.
+template <class DT, int MODE, int C>
 __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
-    constexpr int C = 32;
+    constexpr int KQ = C / 16;                 // k-steps of X = K.Q^T
+    constexpr int CP = (C + 31) / 32 * 32, MY = CP / 32;
+    constexpr int PK = C / 8;                  // 16-byte pieces per key row
+    constexpr int RSK = PK + 1;                // K tile row in 16-byte slots (odd: conflict-free ds_read_b128)
+    constexpr int NKP = 32 * PK, NGP = C * 4;  // pieces of the K tile / of the G^T tile (real rows only)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, hh = lane >> 5;
@@ -49,48 +55,59 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
     const char* xb = a.x + (size_t)b * a.S * a.ldx * 2;
 
     // query fragments (B operand of X = K.Q^T): lane (i=n, hh) holds x[q0+i][16s+8hh .. +8]
-    typename DT::vec8 qf[2];
+    typename DT::vec8 qf[KQ];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < KQ; ++s)
         qf[s] = __builtin_bit_cast(typename DT::vec8,
                                    *reinterpret_cast<const uint4*>(xb + ((size_t)(q0 + n) * a.ldx + 16 * s + 8 * hh) * 2));
 
-    f32x16 y;
+    f32x16 y[MY];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+    for (int m = 0; m < MY; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[m][r] = 0.f;
     float pq = 0.f, part = 0.f;
     if (MODE == TRP_MSE) pq = a.p[(size_t)b * a.S + q0 + n];
 
-    // K / G^T tiles of 32 keys are shared by the 4 waves of the workgroup: each thread fetches ONE 16-byte
-    // piece (threads 0-127: keys x 64 B of x, threads 128-255: 32 channel rows x 64 B of g^T), coalesced,
-    // into a double-buffered LDS tile with 80-byte rows (5 slots: the 16-lane ds_read_b128 groups hit 16
-    // different banks).  Per-wave scattered global loads of the same data saturated the address path.
-    __shared__ uint4 tiles[2][2][32 * 5];
-    const int trow = (threadIdx.x & 127) >> 2, tpiece = threadIdx.x & 3;
-    const bool is_g = threadIdx.x >= 128;
-    const bool loader = !is_g || MODE == TRP_ATTN;
-    auto fetch = [&](int j0) -> uint4 {
-        if (!loader) return make_uint4(0, 0, 0, 0);
-        const char* src = is_g ? a.gT + (((size_t)b * C + trow) * a.S + j0 + tpiece * 8) * 2
-                               : xb + ((size_t)(j0 + trow) * a.ldx + tpiece * 8) * 2;
-        return *reinterpret_cast<const uint4*>(src);
-    };
-    auto stash = [&](int buf, uint4 v) {
-        if (loader) tiles[buf][is_g ? 1 : 0][trow * 5 + tpiece] = v;
-    };
-    auto load_tile = [&](int buf, typename DT::vec8 (&kf)[2], typename DT::vec8 (&gf)[2]) {
+    // K / G^T tiles of 32 keys are shared by the 4 waves of the workgroup: every thread fetches 16-byte
+    // pieces (coalesced) into a double-buffered LDS tile; per-wave scattered global loads of the same
+    // data saturated the address path (295 -> 145 us at S = 3072).  Rows are padded to an odd number of
+    // 16-byte slots so the 16-lane ds_read_b128 groups hit 16 different banks.
+    __shared__ uint4 tk[2][32 * RSK];
+    __shared__ uint4 tg[2][CP * 5];
+    constexpr int NPIECE = NKP + (MODE == TRP_ATTN ? NGP : 0);
+    constexpr int PPT = (NPIECE + 255) / 256;             // pieces per thread
+    if (MODE == TRP_ATTN)
+        for (int i = threadIdx.x; i < 2 * CP * 5; i += 256) (&tg[0][0])[i] = make_uint4(0, 0, 0, 0);
+    auto fetch = [&](int j0, uint4 (&v)[PPT]) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            kf[s] = __builtin_bit_cast(typename DT::vec8, tiles[buf][0][n * 5 + 2 * s + hh]);
-            if (MODE == TRP_ATTN) gf[s] = __builtin_bit_cast(typename DT::vec8, tiles[buf][1][n * 5 + 2 * s + hh]);
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + k * 256;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (p < NKP) {
+                const int row = p / PK, piece = p % PK;
+                v[k] = *reinterpret_cast<const uint4*>(xb + ((size_t)(j0 + row) * a.ldx + piece * 8) * 2);
+            } else if (p < NPIECE) {
+                const int q = p - NKP, row = q >> 2, piece = q & 3;
+                v[k] = *reinterpret_cast<const uint4*>(a.gT + (((size_t)b * C + row) * a.S + j0 + piece * 8) * 2);
+            }
         }
     };
-    auto do_tile = [&](int j0, const typename DT::vec8 (&kf)[2], const typename DT::vec8 (&gf)[2]) {
+    auto stash = [&](int buf, const uint4 (&v)[PPT]) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int p = threadIdx.x + k * 256;
+            if (p < NKP) tk[buf][(p / PK) * RSK + p % PK] = v[k];
+            else if (p < NPIECE) tg[buf][((p - NKP) >> 2) * 5 + ((p - NKP) & 3)] = v[k];
+        }
+    };
+    auto do_tile = [&](int j0, int buf) {
         f32x16 xacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
-        xacc = DT::mfma(kf[0], qf[0], xacc);
-        xacc = DT::mfma(kf[1], qf[1], xacc);
+#pragma unroll
+        for (int s = 0; s < KQ; ++s)
+            xacc = DT::mfma(__builtin_bit_cast(typename DT::vec8, tk[buf][n * RSK + 2 * s + hh]), qf[s], xacc);
         // xacc[r] = <x_key, x_query>, key = j0 + (r&3) + 8*(r>>2) + 4*hh, query = q0 + n
         float pr[16];
 #pragma unroll
@@ -101,7 +118,9 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
                 typename DT::vec8 pf;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pf[e] = (typename DT::elem)pr[8 * s + e];
-                y = DT::mfma(gf[s], pf, y);
+#pragma unroll
+                for (int m = 0; m < MY; ++m)
+                    y[m] = DT::mfma(__builtin_bit_cast(typename DT::vec8, tg[buf][(32 * m + n) * 5 + 2 * s + hh]), pf, y[m]);
             }
         } else if (MODE == TRP_SCORES) {
 #pragma unroll
@@ -120,25 +139,29 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
     };
     // one barrier per tile: fetch tile t+1 into registers, compute tile t from LDS, stash, barrier
     const int ntiles = a.S / 32;
-    stash(0, fetch(0));
+    uint4 nxt[PPT];
+    fetch(0, nxt);
+    __syncthreads();                                       // the zero fill of tg is complete
+    stash(0, nxt);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (more) nxt = fetch((t + 1) * 32);
-        typename DT::vec8 kf[2], gf[2];
-        load_tile(t & 1, kf, gf);
-        do_tile(t * 32, kf, gf);
+        if (more) fetch((t + 1) * 32, nxt);
+        do_tile(t * 32, t & 1);
         if (more) stash((t + 1) & 1, nxt);
         __syncthreads();
     }
 
     if (MODE == TRP_ATTN) {
-        // y[r] = E[query q0+n][channel (r&3) + 8*(r>>2) + 4*hh]
+        // y[m][r] = E[query q0+n][channel 32m + (r&3) + 8*(r>>2) + 4*hh]
         float* eo = a.e + ((size_t)b * a.S + q0 + n) * C + 4 * hh;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            *reinterpret_cast<float4*>(eo + 8 * k) = make_float4(y[4 * k], y[4 * k + 1], y[4 * k + 2], y[4 * k + 3]);
+        for (int m = 0; m < MY; ++m)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (32 * m + 8 * k < C)
+                    *reinterpret_cast<float4*>(eo + 32 * m + 8 * k) =
+                        make_float4(y[m][4 * k], y[m][4 * k + 1], y[m][4 * k + 2], y[m][4 * k + 3]);
     } else if (MODE == TRP_MSE) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -148,19 +171,19 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
 
 static int trp_check(const void* x, int ld_x, int batch, int S, int C) {
     if (!x || batch < 1) RSG_FAIL("trp: null input");
-    if (C != 32) RSG_FAIL("trp: C=%d (only 32 is built)", C);
+    if (C != 32 && C != 48) RSG_FAIL("trp: C=%d (32 and 48 are built)", C);
     if (S % 128 || S < 128) RSG_FAIL("trp: S=%d must be a multiple of 128", S);
-    if (ld_x < C || ld_x % 8) RSG_FAIL("trp: ld_x=%d", ld_x);
+    if (ld_x < C || ld_x % 8 || ((uintptr_t)x & 15)) RSG_FAIL("trp: ld_x=%d / alignment", ld_x);
     return 0;
 }
 
 template <int MODE>
-static int trp_launch(const TrpArgs& a, int batch, int dtype, void* stream) {
+static int trp_launch(const TrpArgs& a, int batch, int C, int dtype, void* stream) {
     dim3 grid(ceil_div(a.S, 128), batch);
-    if (dtype == RSG_BF16)
-        RSG_LAUNCH((trp_kernel<BF16, MODE>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    else
-        RSG_LAUNCH((trp_kernel<F16, MODE>), grid, dim3(256), 0, (hipStream_t)stream, a);
+#define RSG_TRP(DT_, C_) RSG_LAUNCH((trp_kernel<DT_, MODE, C_>), grid, dim3(256), 0, (hipStream_t)stream, a)
+    if (dtype == RSG_BF16) { if (C == 32) RSG_TRP(BF16, 32); else RSG_TRP(BF16, 48); }
+    else { if (C == 32) RSG_TRP(F16, 32); else RSG_TRP(F16, 48); }
+#undef RSG_TRP
     RSG_CHECK_LAUNCH("trp");
     return 0;
 }
@@ -174,7 +197,7 @@ extern "C" int rsg_trp_attention(const void* x, int32_t ld_x, const void* gT_hi,
     TrpArgs a;
     memset(&a, 0, sizeof(a));
     a.x = (const char*)x; a.gT = (const char*)gT_hi; a.e = e_out; a.S = S; a.ldx = ld_x;
-    return trp_launch<TRP_ATTN>(a, batch, dtype, stream);
+    return trp_launch<TRP_ATTN>(a, batch, C, dtype, stream);
 }
 
 extern "C" int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S,
@@ -184,7 +207,7 @@ extern "C" int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_
     TrpArgs a;
     memset(&a, 0, sizeof(a));
     a.x = (const char*)x; a.scores = scores; a.S = S; a.ldx = ld_x;
-    return trp_launch<TRP_SCORES>(a, batch, dtype, stream);
+    return trp_launch<TRP_SCORES>(a, batch, C, dtype, stream);
 }
 
 extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, int32_t batch,
@@ -197,16 +220,15 @@ extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p,
     memset(&a, 0, sizeof(a));
     a.x = (const char*)x; a.p = p; a.mse = mse; a.S = S; a.ldx = ld_x;
     a.inv_ss = 1.0f / ((float)S * (float)S);
-    return trp_launch<TRP_MSE>(a, batch, dtype, stream);
+    return trp_launch<TRP_MSE>(a, batch, C, dtype, stream);
 }
 
 // ---- g projection, transposed + key-permuted (association.py:288-289) -------------------------------
-template <class DT>
+template <class DT, int C>
 __global__ void __launch_bounds__(256) trp_project_g_kernel(const char* __restrict__ x, int ldx,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            char* __restrict__ gT, int S, long total) {
-    constexpr int C = 32;
     __shared__ float ws[C * C + C];
     for (int i = threadIdx.x; i < C * C + C; i += 256) ws[i] = i < C * C ? w[i] : bias[i - C * C];
     __syncthreads();
@@ -243,12 +265,11 @@ extern "C" int rsg_trp_project_g(const void* x, int32_t ld_x, const float* w, co
     if (gT_lo) RSG_FAIL("trp_project_g: split values are not built; pass gT_lo = NULL");
     const long total = (long)batch * S;
     const int grid = (int)((total + 255) / 256);
-    if (dtype == RSG_BF16)
-        RSG_LAUNCH(trp_project_g_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const char*)x, ld_x, w, bias, (char*)gT_hi, S, total);
-    else
-        RSG_LAUNCH(trp_project_g_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const char*)x, ld_x, w, bias, (char*)gT_hi, S, total);
+#define RSG_PG(DT_, C_) RSG_LAUNCH((trp_project_g_kernel<DT_, C_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
+                                   (const char*)x, ld_x, w, bias, (char*)gT_hi, S, total)
+    if (dtype == RSG_BF16) { if (C == 32) RSG_PG(BF16, 32); else RSG_PG(BF16, 48); }
+    else { if (C == 32) RSG_PG(F16, 32); else RSG_PG(F16, 48); }
+#undef RSG_PG
     RSG_CHECK_LAUNCH("trp_project_g");
     return 0;
 }
@@ -266,10 +287,11 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+template <int C>
 __global__ void __launch_bounds__(256) trp_w_project_kernel(const float* __restrict__ e, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            float* __restrict__ part, int S) {
-    constexpr int C = 32, G = 8, CG = 4;
+    constexpr int G = 8, CG = C / G;
     __shared__ float ws[C * C + C];
     __shared__ float red[4];
     for (int i = threadIdx.x; i < C * C + C; i += 256) ws[i] = i < C * C ? w[i] : bias[i - C * C];
@@ -295,22 +317,24 @@ __global__ void __launch_bounds__(256) trp_w_project_kernel(const float* __restr
     float* po = part + (((size_t)b * gridDim.x + blockIdx.x) * G) * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const float sum = (yv[4 * g] + yv[4 * g + 1]) + (yv[4 * g + 2] + yv[4 * g + 3]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) sum += yv[CG * g + c];
         const float mean = block_sum256(sum, red) * (1.f / (256 * CG));
         float m2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < CG; ++c) m2 += (yv[4 * g + c] - mean) * (yv[4 * g + c] - mean);
+        for (int c = 0; c < CG; ++c) m2 += (yv[CG * g + c] - mean) * (yv[CG * g + c] - mean);
         m2 = block_sum256(m2, red);
         if (threadIdx.x == 0) { po[2 * g] = mean; po[2 * g + 1] = m2; }
     }
 }
 
-template <class DT>
+template <class DT, int C>
 __global__ void __launch_bounds__(256) trp_gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ part,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, char* __restrict__ out,
                                                           int out_ld, int S) {
-    constexpr int C = 32, G = 8, CG = 4;
+    constexpr int G = 8, CG = C / G;
     __shared__ float scale[C], shift[C];
     const int b = blockIdx.y, nb = gridDim.x;
     if (threadIdx.x < G) {
@@ -357,20 +381,20 @@ extern "C" int rsg_trp_tail(const float* e, const float* w, const float* bias, c
                             const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S,
                             int32_t C, int32_t dtype, void* workspace, void* stream) {
     if (!e || !w || !bias || !gn_gamma || !gn_beta || !out || !workspace) RSG_FAIL("trp_tail: null pointer");
-    if (C != 32) RSG_FAIL("trp_tail: C=%d (only 32 is built)", C);
+    if (C != 32 && C != 48) RSG_FAIL("trp_tail: C=%d (32 and 48 are built)", C);
     if (S % 256) RSG_FAIL("trp_tail: S=%d must be a multiple of 256", S);
     if (out_ld < C || out_ld % 8 || ((uintptr_t)out & 15)) RSG_FAIL("trp_tail: out_ld=%d / alignment", out_ld);
     float* y = (float*)workspace;
     float* part = y + (size_t)batch * S * C;
     dim3 grid(S / 256, batch);
-    RSG_LAUNCH(trp_w_project_kernel, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, y, part, S);
+    if (C == 32) RSG_LAUNCH(trp_w_project_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, y, part, S);
+    else RSG_LAUNCH(trp_w_project_kernel<48>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, y, part, S);
     RSG_CHECK_LAUNCH("trp_tail(project)");
-    if (dtype == RSG_BF16)
-        RSG_LAUNCH(trp_gn_apply_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y,
-                   (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S);
-    else
-        RSG_LAUNCH(trp_gn_apply_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)y,
-                   (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S);
+#define RSG_GN(DT_, C_) RSG_LAUNCH((trp_gn_apply_kernel<DT_, C_>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                   (const float*)y, (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S)
+    if (dtype == RSG_BF16) { if (C == 32) RSG_GN(BF16, 32); else RSG_GN(BF16, 48); }
+    else { if (C == 32) RSG_GN(F16, 32); else RSG_GN(F16, 48); }
+#undef RSG_GN
     RSG_CHECK_LAUNCH("trp_tail(groupnorm)");
     return 0;
 }

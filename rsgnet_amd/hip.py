@@ -24,6 +24,7 @@ class ConvDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
         ("up", C.c_int32), ("up_y", C.c_int32), ("up_x", C.c_int32), ("phys_h", C.c_int32), ("phys_w", C.c_int32),
         ("relu", C.c_int32), ("dtype", C.c_int32), ("tile_hint", C.c_int32), ("relu_tile_mask", C.c_int32),
+        ("out_c_store", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

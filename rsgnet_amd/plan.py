@@ -232,9 +232,17 @@ class Plan:
             out = self.new(phys_hw[0], phys_hw[1], cpad, name=name)
         if out is not None and (out.H, out.W) != tuple(phys_hw):
             raise ValueError(f"{name}: output buffer is {out.H}x{out.W}, conv writes {phys_hw}")
+        store = 0
+        if out is not None and out.C < cpad:
+            # the destination is a channel slice narrower than the 32-channel output tile (e.g. 48 of 64):
+            # write only the slice, the neighbouring channels belong to someone else
+            if out.C % 8 or out.C < O:
+                raise ValueError(f"{name}: output slice of {out.C} channels cannot hold cout {O}")
+            store = out.C
         self._record(dict(kind="conv", x=x, wp=wp, bias=bo, res=residual, out=out, out_f32=out_f32,
                           I=cin_pad, O=O, kh=kh, kw=kw, stride=stride, pad=pad, up=up, out_hw=out_hw,
-                          phys_hw=phys_hw, relu=relu, relu_mask=relu_mask, name=name), [x, residual], [out, out_f32])
+                          phys_hw=phys_hw, relu=relu, relu_mask=relu_mask, store=store, name=name),
+                     [x, residual], [out, out_f32])
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
 
@@ -421,6 +429,7 @@ class Plan:
         d.phys_h, d.phys_w = r["phys_hw"]
         d.relu = 1 if r["relu"] else 0
         d.relu_tile_mask = r.get("relu_mask", 0)
+        d.out_c_store = r.get("store", 0)
         d.dtype = self.dtype
         d.tile_hint = 0
         return d

@@ -77,8 +77,8 @@ def record_rsgnet(p: Plan, model) -> None:
     W, H = cfg.IMAGE_SIZE
     J, L = cfg.NUM_JOINTS, cfg.NUM_LIMBS
     c0 = cfg.EXTRA["OUTPUT_CONVS"][0]
-    if c0 != 32:
-        raise NotImplementedError(f"RSGNet head with C0={c0}: only the W32 head (C0=32) is built so far")
+    if c0 not in (32, 48):
+        raise NotImplementedError(f"RSGNet head with C0={c0}: the TRP kernels are built for 32 and 48 channels")
     if model.scale_factor != 2:
         raise NotImplementedError("UP_SCALE=1")
     B, dev, lib, dt = p.batch, p.device, p.lib, p.dtype
@@ -147,7 +147,7 @@ def record_rsgnet(p: Plan, model) -> None:
     # ---- joints-of-target branch (:991-1000)
     k = p._unit(cat2, model.kpt_net[0], model.kpt_net[1], relu=True, name="kpt_net")
     dc, dbn = model.predict_convtranspose[0], model.predict_convtranspose[1]
-    k2 = p.new(2 * H4, 2 * W4, c0, name="deconv")
+    k2 = p.new(2 * H4, 2 * W4, c0, name="deconv")       # the four phases store exactly c0 channels
     for py, px, pad_y, pad_x, wph in deconv_phase_weights(dc.weight):
         p.conv(k, wph, dbn, None, relu=True, out=k2, pad=(pad_y, pad_x), up=(2, py, px),
                out_hw=(H4, W4), phys_hw=(2 * H4, 2 * W4), name=f"deconv.phase{py}{px}")

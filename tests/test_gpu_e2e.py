@@ -7,7 +7,7 @@ import torch
 
 from oracle import pose_oracle as po
 from oracle.make_goldens import sample_index
-from tests.util import ROOT, TAGS, load_case, maxabs
+from tests.util import ROOT, TAGS, like_gold, load_case, maxabs
 
 pytestmark = pytest.mark.gpu
 
@@ -95,7 +95,8 @@ def test_batch_sharding_is_invariant():
     assert torch.equal(full, halves)
 
 
-@pytest.mark.parametrize("tag", ["rsgnet_w32_256x192_coco", "rsgnet_w32_256x192_crowdpose"])
+@pytest.mark.parametrize("tag", ["rsgnet_w32_256x192_coco", "rsgnet_w32_256x192_crowdpose",
+                                 "rsgnet_w48_384x288_coco"])
 def test_rsgnet_w32_golden(tag):
     cfg, model, sd, x, gold = load_case(tag)
     model = model.cuda()
@@ -104,16 +105,18 @@ def test_rsgnet_w32_golden(tag):
         multi, kpt, limbs, rel = model(xc)
     J = TAGS[tag][3]
     L = 18 if J == 17 else 14
-    assert multi.shape == (2, J, 128, 96) and kpt.shape == (2, J, 128, 96) and limbs.shape == (2, L, 128, 96)
+    W_, H_ = TAGS[tag][2]
+    S = (H_ // 4) * (W_ // 4)
+    assert multi.shape == (2, J, H_ // 2, W_ // 2) and kpt.shape == multi.shape and limbs.shape == (2, L, H_ // 2, W_ // 2)
     for name, t in (("multi_kpt_scores", multi), ("kpt_scores", kpt), ("limbs_scores", limbs)):
         ref = gold[name + "_crop0"]
-        e = _stats(name, t[0].cpu(), ref)
+        e = _stats(tag.split("_")[1] + " " + name, like_gold(t[0], ref), ref)
         scale = float(ref.std()) if name != "limbs_scores" else 0.25      # sigmoid output
         assert e < REL_TOL * scale, name
     # TRP: the lazy handle materialises R = sigmoid(x x^T) on demand
-    assert rel.shape == (2, 3072, 3072)
+    assert rel.shape == (2, S, S)
     R = rel.materialize()
-    idx = sample_index(3072)
+    idx = sample_index(S)
     e = _stats("relation_scores samples", R[:, idx[:, 0], idx[:, 1]].cpu(), gold["relation_scores_samples"])
     assert e < 2e-2
     rs = gold["relation_scores_rowsum"]                       # sums of 3072 correlated terms
@@ -124,6 +127,8 @@ def test_rsgnet_w32_golden(tag):
         mse = model(xc, relation_target=p)[3]
     assert maxabs(mse.cpu(), gold["relation_mse"]) < 1e-3
     # against the rounding-aware oracle (kernel correctness)
+    if S > 4000:
+        return                                       # the CPU emulation of the 384x288 net is slow; goldens suffice
     emu = po.rsgnet_forward(sd, cfg, x, want_scores=False, emulate="fp16")
     for name, t, r in (("multi", multi, emu[0]), ("kpt", kpt, emu[1]), ("limbs", limbs, emu[2])):
         _stats(name + " vs fp16-emulating oracle", t.cpu(), r.numpy())

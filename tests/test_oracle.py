@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import pose_oracle as po
-from tests.util import TAGS, load_case, maxabs
+from tests.util import TAGS, like_gold, load_case, maxabs
 from oracle.make_goldens import sample_index
 
 TOL = 2e-5   # fp32 summation-order noise on O(1) outputs
@@ -21,15 +21,16 @@ def test_oracle_matches_reference_goldens(tag):
         out = {"multi_kpt_scores": multi, "kpt_scores": kpt, "limbs_scores": limbs}
         idx = sample_index(rel.shape[1])
         assert maxabs(rel[:, idx[:, 0], idx[:, 1]], gold["relation_scores_samples"]) < TOL
-        assert maxabs(rel.sum(dim=2), gold["relation_scores_rowsum"]) < 2e-2   # sums of 3072 terms
-        assert maxabs(ctx.taps["final_vis"][0], gold["final_vis_crop0"]) < 1e-4
-        assert maxabs(ctx.taps["relation_feats"][0], gold["relation_feats_crop0"]) < 1e-4
+        assert maxabs(rel.sum(dim=2), gold["relation_scores_rowsum"]) < 5e-2   # sums of 3072 / 6912 terms
+        assert maxabs(like_gold(ctx.taps["final_vis"][0], gold["final_vis_crop0"]), gold["final_vis_crop0"]) < 1e-4
+        assert maxabs(like_gold(ctx.taps["relation_feats"][0], gold["relation_feats_crop0"]),
+                      gold["relation_feats_crop0"]) < 1e-4
         assert maxabs(ctx.taps["limb_weights"], gold["limb_weights"]) < 1e-6
         p = torch.from_numpy(gold["relation_target_vec"])
         mse = po.rsgnet_forward(sd, cfg, x, relation_target=p[:, :, None] * p[:, None, :])[3]
         assert maxabs(mse, gold["relation_mse"]) < 1e-6
     for k, v in out.items():
-        assert maxabs(v[0], gold[k + "_crop0"]) < TOL, k
+        assert maxabs(like_gold(v[0], gold[k + "_crop0"]), gold[k + "_crop0"]) < TOL, k
         assert maxabs(v[1, :, ::4, ::4], gold[k + "_crop1_sub"]) < TOL, k
         b, c = v.shape[:2]
         assert np.array_equal(v.reshape(b, c, -1).argmax(2).numpy(), gold[k + "_argmax"]), k
