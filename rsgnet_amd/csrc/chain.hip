@@ -19,6 +19,23 @@
 
 #define RSG_CHAIN_MAX_LAYERS 8
 
+// Diagnostic build (-DRSG_CHAIN_STAMPS): wave 0 of every workgroup records shader-clock stamps at the phase
+// boundaries into a side buffer that nothing else reads (tools/chain_stamps.py prints the shares).  The
+// production build contains none of this.
+#ifdef RSG_CHAIN_STAMPS
+__device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][8 waves][32]
+#define RSG_STAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (g_chain_stamps && (threadIdx.x & 63) == 0) {                                             \
+            unsigned long long t__;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");              \
+            g_chain_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (slot)] = t__;       \
+        }                                                                                            \
+    } while (0)
+#else
+#define RSG_STAMP(slot) do {} while (0)
+#endif
+
 struct ChainArgs {
     const char* in;
     char* out;
@@ -59,10 +76,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     const int b0 = (block_id / p.tiles_y) * p.NI;      // first image of this workgroup
     const int y_first = tile * p.TH - p.halo;            // image row held in slot row 0 (+1 border)
 
+    RSG_STAMP(0);
     // ---- zero the whole image (borders, rows outside the picture), then stage the input ------------
     const int lds_bytes = p.NI * slot_rows * RP;
     for (int o = tid * 16; o < lds_bytes; o += NTHR * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
     __syncthreads();
+    RSG_STAMP(1);
     const int chunks_per_img = R * W * CPP;
     constexpr int NLD = 12;                              // staging loads in flight per thread
     for (int base = 0; base < p.NI * chunks_per_img; base += NTHR * NLD) {
@@ -107,6 +126,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     }
     const int cbase = wm * 32 + hh * 16;                 // this lane's 16 output channels
     __syncthreads();
+    RSG_STAMP(2);
 
     uint4 res[NT][2];                                    // block input at this lane's pixels/channels
     constexpr int NPF = (C >= 128) ? 9 : 6;            // ring depth; must divide KS (18, 36, 72, 144)
@@ -126,11 +146,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             const float4 bv = *reinterpret_cast<const float4*>(p.bias[l] + cbase + r4 * 4);
             bias[r4 * 4 + 0] = bv.x; bias[r4 * 4 + 1] = bv.y; bias[r4 * 4 + 2] = bv.z; bias[r4 * 4 + 3] = bv.w;
         }
-        f32x16 acc[NT];
+        f32x16 acc[NT];                                  // accumulators start at the folded-BN bias
 #pragma unroll
         for (int g = 0; g < NT; ++g)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[g][r] = bias[r];
 
         // A operands: an NPF-deep prefetch ring that keeps running across the layer boundary
         const uint4* ap = p.wpk[l] + (size_t)wm * KS * 64 + lane;
@@ -139,48 +159,96 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 #pragma unroll
             for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
         }
+        RSG_STAMP(3 + 3 * l);
         // k-loop, one scheduling region per k-step (the compiler otherwise sinks the prefetches next to
         // their uses): issue the A load NPF steps ahead and the B reads one step ahead, then the MFMAs.
         auto boff = [&](int ks) {
             const int ch = ks / (9 * KPT), t = (ks / KPT) % 9, c = ks % KPT;
             return (t / 3 - 1) * RP + (t % 3 - 1) * PS + ch * CINB * 2 + c * 32;
         };
-        uint4 bq[2][NT];
+        // B fragments.  The order "reads of step ks+1 issue before/between the MFMAs of step ks" must be pinned:
+        // left alone, hipcc sinks the reads under the MFMAs (fewer live registers) and every k-step then waits
+        // ~130 cycles on LDS reads it has only just issued (measured with the stamp build: 295 instead of 160
+        // cycles per k-step, the two waves of a SIMD serialise).
+        constexpr bool DOUBLE_BUF = NT <= 4;
+        if constexpr (DOUBLE_BUF) {
+            // narrow tiles: two register sets, reads one whole k-step ahead, two scheduling regions per step
+            uint4 bq[2][NT];
 #pragma unroll
-        for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
+            for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
-            if (ks + 1 < KS) {
+            for (int ks = 0; ks < KS; ++ks) {
+                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+                if (ks + 1 < KS) {
+#pragma unroll
+                    for (int g = 0; g < NT; ++g)
+                        bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
+                }
+                aq[ks % NPF] = (ks + NPF < KS) ? ap[(ks + NPF) * 64] : apn[(ks + NPF - KS) * 64];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < NT; ++g)
-                    bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
+                    acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), acc[g]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            aq[ks % NPF] = (ks + NPF < KS) ? ap[(ks + NPF) * 64] : apn[(ks + NPF - KS) * 64];
+        } else {
+            // wide tiles: ONE register set; the read that refills fragment g for step ks+1 issues right after
+            // the MFMA that consumed it, so it has (NT-1) MFMAs = 128+ cycles to land (1 MFMA : 1 DS_READ)
+            uint4 bq[NT];
 #pragma unroll
-            for (int g = 0; g < NT; ++g)
-                acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), acc[g]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < NT; ++g) bq[g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+                aq[ks % NPF] = (ks + NPF < KS) ? ap[(ks + NPF) * 64] : apn[(ks + NPF - KS) * 64];
+#pragma unroll
+                for (int g = 0; g < NT; ++g) {
+                    acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[g]), acc[g]);
+                    if (ks + 1 < KS) bq[g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // the A prefetch (VMEM read)
+#pragma unroll
+                for (int g = 0; g < NT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         // ---- bias (+ block input) + ReLU, zero outside the picture, pack to 16 bit --------------------
+        // (+ block input on odd layers) -> ReLU, zero outside the picture -> 16 bit.  Two VALU instructions
+        // per element plus packed converts: a wave-uniform branch for the residual (not a per-element
+        // select), v_med3_f32(v, 0, hi) = ReLU and mask in one (hi = 0 outside the picture), v_cvt_pk.
+        // The first version issued 8.5 instructions per element and cost as much as the k-loop.
         uint4 o[NT][2];
+        if (l & 1) {
 #pragma unroll
-        for (int g = 0; g < NT; ++g) {
+            for (int g = 0; g < NT; ++g) {
+                const float hig = inside[g] ? 3.0e38f : 0.f;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const typename DT::vec8 rh = __builtin_bit_cast(typename DT::vec8, res[g][k]);
-                typename DT::vec8 ov;
+                for (int k = 0; k < 2; ++k) {
+                    const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, res[g][k]), f32x8);
+                    f32x8 v;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = acc[g][k * 8 + e] + bias[k * 8 + e];
-                    if (l & 1) v += (float)rh[e];
-                    v = inside[g] ? fmaxf(v, 0.f) : 0.f;
-                    ov[e] = (typename DT::elem)v;
+                    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(acc[g][k * 8 + e] + rf[e], 0.f, hig);
+                    o[g][k] = __builtin_bit_cast(uint4, __builtin_convertvector(v, typename DT::vec8));
                 }
-                o[g][k] = __builtin_bit_cast(uint4, ov);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NT; ++g) {
+                const float hig = inside[g] ? 3.0e38f : 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f32x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(acc[g][k * 8 + e], 0.f, hig);
+                    o[g][k] = __builtin_bit_cast(uint4, __builtin_convertvector(v, typename DT::vec8));
+                }
             }
         }
+        RSG_STAMP(4 + 3 * l);
         __syncthreads();                                 // every wave has finished reading the image
 #pragma unroll
         for (int g = 0; g < NT; ++g) {
@@ -190,6 +258,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             }
         }
         __syncthreads();                                 // the new image is complete
+        RSG_STAMP(5 + 3 * l);
     }
 
     // ---- store the TH output rows of every image slot -----------------------------------------------------
@@ -205,6 +274,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             *reinterpret_cast<uint4*>(p.out + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2) = v;
         }
     }
+    RSG_STAMP(30);
 }
 
 template <class DT, int C, int WM, int WN, int NT>
@@ -372,3 +442,11 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
     RSG_CHECK_LAUNCH("basic_chain_group");
     return 0;
 }
+
+#ifdef RSG_CHAIN_STAMPS
+extern "C" int rsg_chain_set_stamp_buffer(void* dev_ptr) {
+    unsigned long long* p = (unsigned long long*)dev_ptr;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps), &p, sizeof(p)) != hipSuccess) RSG_FAIL("stamps: memcpy failed");
+    return 0;
+}
+#endif

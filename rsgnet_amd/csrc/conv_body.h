@@ -40,11 +40,24 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         opix[g] = valid ? ((b * p.Hp + (y0 + py) * p.up + p.upy) * p.Wp + (x0 + px) * p.up + p.upx) : -1;
     }
 
+    // accumulators start at the folded-BN bias of this lane's 16 output channels
+    const int cbase = ct * 32 + hh * 16;
     f32x16 acc[NT];
+    {
+        float bias[16];
 #pragma unroll
-    for (int g = 0; g < NT; ++g)
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias + cbase + r4 * 4);
+            bias[r4 * 4 + 0] = bv.x;
+            bias[r4 * 4 + 1] = bv.y;
+            bias[r4 * 4 + 2] = bv.z;
+            bias[r4 * 4 + 3] = bv.w;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+        for (int g = 0; g < NT; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = bias[r];
+    }
 
     const uint4* ap = p.wpk + (size_t)ct * p.KS * 64 + lane;
     const int total = p.TIH * p.TIW * CPP;
@@ -101,6 +114,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
                     bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
             }
             if (ks + NPF < KSB) aq[ks % NPF] = apc[(ks + NPF) * 64];
+            // pin: reads issue before the MFMAs (see chain.hip)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < NT; ++g)
                 acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), acc[g]);
@@ -109,34 +124,25 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         if (ch + 1 < p.nchunks) __syncthreads();
     }
 
-    // ---- epilogue: + bias (+ residual) (ReLU) -> 16-bit NHWC and/or fp32 NCHW ---------------------------
-    const int cbase = ct * 32 + hh * 16;
-    float bias[16];
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + cbase + r4 * 4);
-        bias[r4 * 4 + 0] = bv.x;
-        bias[r4 * 4 + 1] = bv.y;
-        bias[r4 * 4 + 2] = bv.z;
-        bias[r4 * 4 + 3] = bv.w;
-    }
+    // ---- epilogue: (+ residual) (ReLU) -> 16-bit NHWC and/or fp32 NCHW; the branches are wave-uniform ----
+    const bool relu = (p.relu >> (ct & 31)) & 1;
 #pragma unroll
     for (int g = 0; g < NT; ++g) {
         if (opix[g] < 0) continue;
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = acc[g][r] + bias[r];
+        for (int r = 0; r < 16; ++r) v[r] = acc[g][r];
         if (p.res) {
             const char* rp = p.res + ((size_t)opix[g] * p.ldr + cbase) * 2;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const uint4 rv = *reinterpret_cast<const uint4*>(rp + k * 16);
-                const typename DT::vec8 rh = __builtin_bit_cast(typename DT::vec8, rv);
+                const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv), f32x8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[k * 8 + e] += (float)rh[e];
+                for (int e = 0; e < 8; ++e) v[k * 8 + e] += rf[e];
             }
         }
-        if ((p.relu >> (ct & 31)) & 1) {
+        if (relu) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
         }
@@ -144,9 +150,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
             char* op = p.out + ((size_t)opix[g] * p.ldo + cbase) * 2;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                typename DT::vec8 o;
+                f32x8 f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (typename DT::elem)v[k * 8 + e];
+                for (int e = 0; e < 8; ++e) f[e] = v[k * 8 + e];
+                const typename DT::vec8 o = __builtin_convertvector(f, typename DT::vec8);
                 if (cbase + k * 8 < p.CoutStore) *reinterpret_cast<uint4*>(op + k * 16) = __builtin_bit_cast(uint4, o);
             }
         }

@@ -88,7 +88,8 @@ _lib: Optional[C.CDLL] = None
 
 
 def lib_path() -> str:
-    return _build.LIB
+    """The in-tree library; RSGNET_HIP_LIB names another build of the same sources (A/B runs)."""
+    return os.environ.get("RSGNET_HIP_LIB") or _build.LIB
 
 
 def lib() -> C.CDLL:
