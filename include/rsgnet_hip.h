@@ -103,10 +103,14 @@ int rsg_graph_destroy(void* graph);
  * in != out.  w_packed[l], bias[l]: per-layer device pointers from rsg_pack_conv_weights_host
  * (HOST arrays of nlayers device pointers).  c in {32,64,128,256}.
  * rsg_basic_chain_supported returns 1 when (c,h,w,nlayers) can run and fills
- * info4 = {tile rows, images per workgroup, LDS bytes, workgroups}. */
+ * info4 = {tile rows, images per workgroup, LDS bytes, workgroups}.
+ * workspace: device scratch of rsg_basic_chain_workspace_bytes(...) bytes; it carries each block's input
+ * to the residual add of that block and holds nothing between calls, so chains that never run
+ * concurrently may share one. */
 int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, const float* const* bias,
                     int32_t nlayers, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t dtype,
-                    void* stream);
+                    void* workspace, void* stream);
+size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch);
 int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
                               int32_t* info4);
 /* Up to 4 chains (the branches of one HighResolutionModule, pose_hrnet.py:254-255) in ONE launch; the
@@ -117,6 +121,7 @@ typedef struct rsg_chain_item {
     const void* const* w_packed;   /* HOST array of nlayers device pointers */
     const float* const* bias;      /* HOST array of nlayers device pointers */
     int32_t nlayers, batch, h, w, c, reserved;
+    void* workspace;               /* rsg_basic_chain_workspace_bytes(c,h,w,nlayers,batch) bytes, own per item */
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
 

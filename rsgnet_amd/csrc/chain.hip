@@ -11,9 +11,12 @@
 //   * row-tile mode: `rows` output rows + L halo rows each side (branch 0: 64x48x32 does not fit), the
 //     outer rows are recomputed by the neighbouring tile.
 // Each layer runs IN PLACE: all waves accumulate their output tiles from the image (k-loop), barrier,
-// write the 16-bit results back over it, barrier.  The residual of a block never leaves registers: a
-// wave owns the same (32 couts x 32 pixels) tiles in every layer, so it reads them once at the start
-// of the block.  Rows outside the image are re-zeroed after every layer (zero padding of each conv).
+// write the 16-bit results back over it, barrier.  A wave owns the same (32 couts x 32 pixels) tiles in
+// every layer, so the block input it must add back is private to each lane.  It is NOT parked in registers
+// across the two k-loops (48-56 VGPRs: the compiler spilled them to scratch and reloaded them at the point of
+// use, +3..7k cycles on every second layer): it waits in a per-lane slot of a global workspace, written from the
+// staged image (first block) or by the previous block's epilogue, and is fetched one k-step before the k-loop
+// ends.  Rows outside the image are re-zeroed after every layer (zero padding).
 // MFMA mapping, weight packing and LDS pixel layout are those of conv_igemm.hip.
 #include "common.h"
 
@@ -44,11 +47,12 @@ struct ChainArgs {
     int nlayers;
     int B, H, W;
     int TH;       // output rows per tile
-    int R;        // rows held per image slot = TH + 2*halo
+    int R;        // rows held per image slot: TH + 2*halo, TH + halo with two tiles, H with one
     int halo;     // = nlayers in row-tile mode, 0 in whole-image mode
     int NI;       // images per workgroup (whole-image mode), else 1
     int tiles_y;
     int RP;       // LDS row pitch in bytes (host: chain_row_pitch)
+    uint4* ws;    // block inputs: [workgroup][NT*2][threads] x 16 B
 };
 
 template <class DT, int C, int WM, int WN, int NT>
@@ -74,7 +78,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 
     const int tile = block_id % p.tiles_y;
     const int b0 = (block_id / p.tiles_y) * p.NI;      // first image of this workgroup
-    const int y_first = tile * p.TH - p.halo;            // image row held in slot row 0 (+1 border)
+    // image row held in slot row 0 (+1 border).  Tiles at the top/bottom of the picture need no halo on
+    // that side: the window is clamped into the picture, so two 32-row tiles of a 64-row map hold 36 rows
+    // each instead of 40 and every held row is a real one.
+    const int y_first = min(max(tile * p.TH - p.halo, 0), p.H - R);
 
     RSG_STAMP(0);
     // ---- zero the whole image (borders, rows outside the picture), then stage the input ------------
@@ -108,7 +115,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             if (lo[j] >= 0) *reinterpret_cast<uint4*>(smem + lo[j]) = v[j];
     }
 
+    // folded-BN biases of every layer, behind the image (read back at each layer top: LDS, not L2, latency)
+    float* sbias = reinterpret_cast<float*>(smem + lds_bytes);
+    for (int l = 0; l < p.nlayers; ++l)
+        for (int c = tid; c < C; c += NTHR) sbias[l * C + c] = p.bias[l][c];
+
     // ---- this lane's pixels ---------------------------------------------------------------------------
+    const int cbase = wm * 32 + hh * 16;                 // this lane's 16 output channels
     int pixoff[NT];     // LDS byte address of the pixel (centre tap), + lane-half offset
     bool live[NT];      // pixel exists in this workgroup's tile
     bool inside[NT];    // ... and lies inside the picture (else it must stay zero)
@@ -124,26 +137,46 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         inside[g] = live[g] && y >= 0 && y < p.H && (b0 + i) < p.B;
         pixoff[g] = (i * slot_rows + r + 1) * RP + (x + 1) * PS + hh * 16;
     }
-    const int cbase = wm * 32 + hh * 16;                 // this lane's 16 output channels
     __syncthreads();
     RSG_STAMP(2);
 
-    uint4 res[NT][2];                                    // block input at this lane's pixels/channels
     constexpr int NPF = (C >= 128) ? 9 : 6;            // ring depth; must divide KS (18, 36, 72, 144)
     static_assert(KS % NPF == 0, "prefetch ring must wrap at the layer boundary");
     uint4 aq[NPF];
-    for (int l = 0; l < p.nlayers; ++l) {
-        if ((l & 1) == 0) {
+    // block-input slots of this lane, through a buffer descriptor: uniform base in SGPRs, ONE address VGPR (the
+    // lane offset) and a constant per (pixel group, half).  Plain pointers made hipcc hoist 2*NT 64-bit
+    // addresses out of the layer loop and spill them.
+    const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(p.ws) + (size_t)block_id * (NT * 2 * NTHR * 16), 0, NT * 2 * NTHR * 16, 0x00020000);
+    const int ws_lane = tid * 16;
+    auto ws_load = [&](int g, int k) {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ws_rsrc, ws_lane, (g * 2 + k) * NTHR * 16, 0));
+    };
+    auto ws_store = [&](int g, int k, const uint4& v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ws_rsrc, ws_lane, (g * 2 + k) * NTHR * 16, 0);
+    };
+    const int own_delta = cbase * 2 - hh * 16;           // pixoff -> this lane's 16 channels of the pixel
 #pragma unroll
-            for (int g = 0; g < NT; ++g) {
-                res[g][0] = *reinterpret_cast<const uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2);
-                res[g][1] = *reinterpret_cast<const uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2 + 16);
+    for (int g = 0; g < NT; ++g) {                       // the first block's input, from the staged image
+        ws_store(g, 0, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta));
+        ws_store(g, 1, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta + 16));
+    }
+    for (int l = 0; l < p.nlayers; ++l) {
+        uint4 res[NT][2];                               // block input at this lane's pixels/channels (odd layers)
+        // fetched in two parts: the first NRE pixel groups one k-step before the k-loop ends (all the registers
+        // the widest variant has left there), the others right after it; the epilogue consumes them in order
+        constexpr int NRE = NT >= 7 ? 3 : NT;
+        auto fetch_res = [&](int g0, int g1) {
+#pragma unroll
+            for (int g = g0; g < g1; ++g) {
+                res[g][0] = ws_load(g, 0);
+                res[g][1] = ws_load(g, 1);
             }
-        }
-        float bias[16];                                 // issued now, consumed after the k-loop
+        };
+        float bias[16];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 bv = *reinterpret_cast<const float4*>(p.bias[l] + cbase + r4 * 4);
+            const float4 bv = *reinterpret_cast<const float4*>(sbias + l * C + cbase + r4 * 4);
             bias[r4 * 4 + 0] = bv.x; bias[r4 * 4 + 1] = bv.y; bias[r4 * 4 + 2] = bv.z; bias[r4 * 4 + 3] = bv.w;
         }
         f32x16 acc[NT];                                  // accumulators start at the folded-BN bias
@@ -171,6 +204,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         // ~130 cycles on LDS reads it has only just issued (measured with the stamp build: 295 instead of 160
         // cycles per k-step, the two waves of a SIMD serialise).
         constexpr bool DOUBLE_BUF = NT <= 4;
+        constexpr int RES_LEAD = 1;                      // k-steps between the block-input fetch and its use
         if constexpr (DOUBLE_BUF) {
             // narrow tiles: two register sets, reads one whole k-step ahead, two scheduling regions per step
             uint4 bq[2][NT];
@@ -178,6 +212,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                if (ks == KS - RES_LEAD && (l & 1)) fetch_res(0, NRE);
                 const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
                 if (ks + 1 < KS) {
 #pragma unroll
@@ -199,6 +234,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             for (int g = 0; g < NT; ++g) bq[g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+                if (ks == KS - RES_LEAD && (l & 1)) fetch_res(0, NRE);
                 const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
                 aq[ks % NPF] = (ks + NPF < KS) ? ap[(ks + NPF) * 64] : apn[(ks + NPF - KS) * 64];
 #pragma unroll
@@ -223,6 +259,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         // The first version issued 8.5 instructions per element and cost as much as the k-loop.
         uint4 o[NT][2];
         if (l & 1) {
+            if constexpr (NRE < NT) fetch_res(NRE, NT);
 #pragma unroll
             for (int g = 0; g < NT; ++g) {
                 const float hig = inside[g] ? 3.0e38f : 0.f;
@@ -233,6 +270,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(acc[g][k * 8 + e] + rf[e], 0.f, hig);
                     o[g][k] = __builtin_bit_cast(uint4, __builtin_convertvector(v, typename DT::vec8));
+                    if (l + 1 < p.nlayers) ws_store(g, k, o[g][k]);            // the next block's input
                 }
             }
         } else {
@@ -250,11 +288,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         }
         RSG_STAMP(4 + 3 * l);
         __syncthreads();                                 // every wave has finished reading the image
+        int wd = own_delta;
+        asm volatile("" : "+v"(wd));                     // keep the 2*NT write addresses out of the loop preheader
 #pragma unroll
         for (int g = 0; g < NT; ++g) {
             if (live[g]) {
-                *reinterpret_cast<uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2) = o[g][0];
-                *reinterpret_cast<uint4*>(smem + pixoff[g] - hh * 16 + cbase * 2 + 16) = o[g][1];
+                *reinterpret_cast<uint4*>(smem + pixoff[g] + wd) = o[g][0];
+                *reinterpret_cast<uint4*>(smem + pixoff[g] + wd + 16) = o[g][1];
             }
         }
         __syncthreads();                                 // the new image is complete
@@ -270,7 +310,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         const int y = tile * p.TH + r, b = b0 + i;
         if (y < p.H && b < p.B) {
             const uint4 v = *reinterpret_cast<const uint4*>(
-                smem + (i * slot_rows + r + p.halo + 1) * RP + (x + 1) * PS + cg * 16);
+                smem + (i * slot_rows + y - y_first + 1) * RP + (x + 1) * PS + cg * 16);
             *reinterpret_cast<uint4*>(p.out + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2) = v;
         }
     }
@@ -300,7 +340,7 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
     const int bid = blockIdx.x - g.first[i];
     switch (g.c[i]) {
-        case 32: chain_body<DT, 32, 1, 8, 5>(g.a[i], bid, smem); break;
+        case 32: chain_body<DT, 32, 1, 8, 7>(g.a[i], bid, smem); break;
         case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem); break;
         case 128: chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem); break;
         case 256:   // NT follows the pixels a workgroup owns (1 image = 48 px = 2 groups, 2 images = 3 groups)
@@ -312,8 +352,9 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
 
 // ------------------------------------------------------------------------------------------------
 struct ChainCfg { int C, WM, WN, NT; };
-static const ChainCfg kChainCfgs[] = {{32, 1, 8, 5}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
+static const ChainCfg kChainCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
 static const int CHAIN_LDS_LIMIT = 160 * 1024;
+static const int kChainMaxNT = 8;      // workspace slots are sized for the widest variant (standalone or grouped)
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
 static int g_chain_max_ni = 1;
 static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
@@ -332,7 +373,7 @@ template <class DT>
 static chain_fn chain_lookup(int C, int npix) {
     if (C == 256 && npix <= 64) return chain_kernel<DT, 256, 8, 1, 2>;
     switch (C) {
-        case 32: return chain_kernel<DT, 32, 1, 8, 5>;
+        case 32: return chain_kernel<DT, 32, 1, 8, 7>;
         case 64: return chain_kernel<DT, 64, 2, 4, 6>;
         case 128: return chain_kernel<DT, 128, 4, 1, 6>;
         case 256: return chain_kernel<DT, 256, 8, 1, 3>;
@@ -350,7 +391,7 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     nthr = 64 * cfg->WM * cfg->WN;
     const int RP = chain_row_pitch(C, W);
     a.RP = RP;
-    auto bytes = [&](int ni, int R) { return ni * (R + 2) * RP; };
+    auto bytes = [&](int ni, int R) { return ni * (R + 2) * RP + RSG_CHAIN_MAX_LAYERS * C * 4; };   // image + biases
     if (H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
         int ni = cap / (H * W);
         while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > g_chain_max_ni)) --ni;
@@ -358,16 +399,18 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
         lds = bytes(ni, H);
         return 0;
     }
-    // row tiles with halo recompute: the largest R = TH + 2L that fits the pixel capacity and the LDS
-    int R = cap / W;
-    while (R > 2 * nlayers && bytes(1, R) > CHAIN_LDS_LIMIT) --R;
-    int TH = R - 2 * nlayers;
-    if (TH < 4) return 1;
-    const int tiles = ceil_div(H, TH);
-    TH = ceil_div(H, tiles);                              // even the tiles out
-    a.TH = TH; a.R = TH + 2 * nlayers; a.halo = nlayers; a.NI = 1; a.tiles_y = tiles;
-    lds = bytes(1, a.R);
-    return 0;
+    // row tiles with halo recompute: the fewest tiles whose window (TH rows + an L-row halo on every side
+    // that is not the picture's edge) fits the pixel capacity and the LDS
+    for (int tiles = 2; tiles <= H; ++tiles) {
+        const int TH = ceil_div(H, tiles);
+        const int R = TH + (tiles == 2 ? 1 : 2) * nlayers;
+        if (TH < 4) break;
+        if (R > H || R * W > cap || bytes(1, R) > CHAIN_LDS_LIMIT) continue;
+        a.TH = TH; a.R = R; a.halo = nlayers; a.NI = 1; a.tiles_y = ceil_div(H, TH);
+        lds = bytes(1, R);
+        return 0;
+    }
+    return 1;
 }
 
 extern "C" int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
@@ -380,10 +423,26 @@ extern "C" int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_
     return 1;
 }
 
+// bytes of the block-input workspace of one chain: a 32-byte slot per lane and pixel group, per workgroup
+static size_t chain_ws_bytes(int C, const ChainArgs& a, int batch, int nlayers, int nthr) {
+    const int blocks = ceil_div(batch, a.NI) * a.tiles_y;
+    return (size_t)blocks * nthr * kChainMaxNT * 32;
+}
+
+extern "C" size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch) {
+    ChainArgs a;
+    int lds = 0, nthr = 0;
+    if (nlayers < 2 || nlayers > RSG_CHAIN_MAX_LAYERS || (nlayers & 1)) return 0;
+    if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr)) return 0;
+    return chain_ws_bytes(c, a, batch, nlayers, 512);
+}
+
 extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, const float* const* bias,
                                int32_t nlayers, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t dtype,
-                               void* stream) {
+                               void* workspace, void* stream) {
     if (!in || !out || !w_packed || !bias) RSG_FAIL("basic_chain: null pointer");
+    if (!workspace || ((uintptr_t)workspace & 15))
+        RSG_FAIL("basic_chain: needs a 16-byte aligned workspace (rsg_basic_chain_workspace_bytes)");
     if (in == out) RSG_FAIL("basic_chain: in-place operation is not supported (row tiles read neighbours' halos)");
     if (nlayers < 2 || nlayers > RSG_CHAIN_MAX_LAYERS || (nlayers & 1))
         RSG_FAIL("basic_chain: nlayers=%d must be even and <= %d", nlayers, RSG_CHAIN_MAX_LAYERS);
@@ -393,6 +452,7 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
     if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr))
         RSG_FAIL("basic_chain: unsupported shape C=%d %dx%d L=%d", c, h, w, nlayers);
     a.in = (const char*)in; a.out = (char*)out; a.nlayers = nlayers; a.B = batch; a.H = h; a.W = w;
+    a.ws = (uint4*)workspace;
     for (int l = 0; l < nlayers; ++l) {
         if (!w_packed[l] || !bias[l]) RSG_FAIL("basic_chain: null weights for layer %d", l);
         a.wpk[l] = (const uint4*)w_packed[l];
@@ -423,7 +483,9 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         int lds = 0, nthr = 0;
         if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr))
             RSG_FAIL("chain_group: unsupported shape C=%d %dx%d L=%d", it.c, it.h, it.w, it.nlayers);
+        if ((!it.workspace || ((uintptr_t)it.workspace & 15))) RSG_FAIL("chain_group: item %d needs a workspace", i);
         a.in = (const char*)it.in; a.out = (char*)it.out; a.nlayers = it.nlayers; a.B = it.batch; a.H = it.h; a.W = it.w;
+        a.ws = (uint4*)it.workspace;
         for (int l = 0; l < it.nlayers; ++l) {
             if (!it.w_packed[l] || !it.bias[l]) RSG_FAIL("chain_group: null weights (item %d layer %d)", i, l);
             a.wpk[l] = (const uint4*)it.w_packed[l];

@@ -40,7 +40,7 @@ class ChainItem(C.Structure):
     """struct rsg_chain_item (include/rsgnet_hip.h)."""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
                 ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
-                ("w", C.c_int32), ("c", C.c_int32), ("reserved", C.c_int32)]
+                ("w", C.c_int32), ("c", C.c_int32), ("reserved", C.c_int32), ("workspace", C.c_void_p)]
 
 
 # every symbol include/rsgnet_hip.h declares: name -> (restype, argtypes)
@@ -61,7 +61,8 @@ SYMBOLS = {
     "rsg_graph_abort": (C.c_int, [_vp]),
     "rsg_graph_launch": (C.c_int, [_vp, _vp]),
     "rsg_graph_destroy": (C.c_int, [_vp]),
-    "rsg_basic_chain": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp]),
+    "rsg_basic_chain": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rsg_basic_chain_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rsg_basic_chain_group": (C.c_int, [C.POINTER(ChainItem), _i, _i, _vp]),
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_conv_groupable": (C.c_int, [C.POINTER(ConvDesc)]),

@@ -500,6 +500,17 @@ class Plan:
         # a lone fuse-sum is a group of one (the grouped entry point takes strided operands)
         self._lower_group(dict(subs=[r], name=r["name"]))
 
+    def _chain_workspace(self, slot: int, x: VT, nlayers: int):
+        """Block-input scratch of the chain in position ``slot`` of its launch.  Launches run one after the other,
+        so position k of every launch shares one buffer per distinct size (addresses are baked into the ops)."""
+        need = int(self.lib.rsg_basic_chain_workspace_bytes(x.C, x.H, x.W, nlayers, self.batch))
+        if not need:
+            return None
+        pool = self.__dict__.setdefault("_chain_ws", {})
+        if (slot, need) not in pool:
+            pool[(slot, need)] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return pool[(slot, need)].data_ptr()
+
     def _lower_chain(self, r):
         x, out, layers = r["x"], r["out"], r["layers"]
         if x.ld != x.C or x.coff or out.ld != out.C or out.coff:
@@ -508,7 +519,8 @@ class Plan:
         wps = (C.c_void_p * n)(*[w.data_ptr() for w, _ in layers])
         bps = (C.c_void_p * n)(*[b.data_ptr() for _, b in layers])
         self._keep += [wps, bps]
-        args = (x.ptr(), out.ptr(), wps, bps, n, self.batch, x.H, x.W, x.C, self.dtype)
+        ws = self._chain_workspace(0, x, n)
+        args = (x.ptr(), out.ptr(), wps, bps, n, self.batch, x.H, x.W, x.C, self.dtype, ws)
         fn, nm = self.lib.rsg_basic_chain, r["name"]
         info = (C.c_int32 * 4)()
         self.lib.rsg_basic_chain_supported(x.C, x.H, x.W, n, self.batch, info)
@@ -538,6 +550,7 @@ class Plan:
             it.w_packed = C.cast(wps, C.POINTER(C.c_void_p))
             it.bias = C.cast(bps, C.POINTER(C.c_void_p))
             it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, x.C
+            it.workspace = self._chain_workspace(len(log), x, n)
             log.append((x.C, x.H, x.W, n))
         self._keep.append(items)
         fn, nm, n_items, dt = self.lib.rsg_basic_chain_group, r["name"], len(subs), self.dtype

@@ -260,7 +260,8 @@ def test_trp_attention_project_tail_scores_mse():
 
 
 @pytest.mark.parametrize("Cc,H,W,L", [(128, 16, 12, 8), (256, 8, 6, 8), (64, 32, 24, 8), (32, 64, 48, 2),
-                                      (256, 8, 6, 2), (32, 30, 48, 2)])
+                                      (256, 8, 6, 2), (32, 30, 48, 2), (32, 64, 48, 4), (32, 64, 48, 8),
+                                      (32, 61, 48, 4), (64, 32, 24, 4)])
 def test_basic_chain_matches_cpu(Cc, H, W, L):
     """rsg_basic_chain vs a CPU chain that rounds to fp16 where the kernel does (after every conv)."""
     lib = hip.lib()
@@ -287,8 +288,11 @@ def test_basic_chain_matches_cpu(Cc, H, W, L):
         bps.append(bd.data_ptr())
     xin = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
     out = torch.full_like(xin, float("nan"))
+    need = lib.rsg_basic_chain_workspace_bytes(Cc, H, W, L, B)
+    assert need > 0
+    wsp = torch.empty(need, dtype=torch.uint8, device=DEV)
     hip.check(lib.rsg_basic_chain(xin.data_ptr(), out.data_ptr(), (C.c_void_p * L)(*wps), (C.c_void_p * L)(*bps),
-                                  L, B, H, W, Cc, 0, _stream()), "chain")
+                                  L, B, H, W, Cc, 0, wsp.data_ptr(), _stream()), "chain")
     torch.cuda.synchronize()
     got = out.float().cpu().permute(0, 3, 1, 2)
     t = x.half().double()

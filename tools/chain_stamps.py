@@ -15,13 +15,13 @@ from rsgnet_amd import build as B  # noqa: E402
 so = "/tmp/librsg_stamps.so"
 srcs = [os.path.join(B.CSRC, f) for f in ("chain.hip", "graph.hip", "conv_igemm.hip")]
 cmd = [B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shared", "-DRSG_CHAIN_STAMPS",
-       "-mllvm", "-amdgpu-mfma-vgpr-form", *srcs, "-o", so]
+       *os.environ.get("CHAIN_STAMP_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form").split(), *srcs, "-o", so]
 subprocess.check_call(cmd)
 lib = C.CDLL(so)
 lib.rsg_last_error.restype = C.c_char_p
 Bn = 64
 for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8, 6, 4), (64, 32, 24, 8)):
-    x = torch.randn(Bn, H, W, Cc, device="cuda").half()
+    x = (torch.zeros if os.environ.get("STAMP_ZERO") else torch.randn)(Bn, H, W, Cc, device="cuda").half()
     out = torch.empty_like(x)
     keep, wps, bps = [], [], []
     for l in range(L):
@@ -40,7 +40,10 @@ for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8,
     nblk = info[3]
     stamps = torch.zeros(nblk * 8 * 32, dtype=torch.int64, device="cuda")
     lib.rsg_chain_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
-    args = (C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), (C.c_void_p * L)(*wps), (C.c_void_p * L)(*bps), L, Bn, H, W, Cc, 0, None)
+    lib.rsg_basic_chain_workspace_bytes.restype = C.c_size_t
+    wsp = torch.empty(max(lib.rsg_basic_chain_workspace_bytes(Cc, H, W, L, Bn), 16), dtype=torch.uint8, device="cuda")
+    args = (C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), (C.c_void_p * L)(*wps), (C.c_void_p * L)(*bps), L, Bn, H, W, Cc, 0,
+            C.c_void_p(wsp.data_ptr()), None)
     for _ in range(3):
         rc = lib.rsg_basic_chain(*args)
         assert rc == 0, lib.rsg_last_error()
@@ -51,9 +54,10 @@ for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8,
     e1.record()
     torch.cuda.synchronize()
     sw = stamps.cpu().numpy().reshape(nblk, 8, 32).astype(np.float64)
-    nw = 8 if Cc != 128 else 4
+    nw = int(np.count_nonzero(sw[nblk // 2, :, 0]))
     blk = nblk // 2
     t0 = sw[blk, 0, 0]
+    print('   k-loop cycles per layer, wave 0 / last wave: ' + '  '.join(f'{sw[blk, 0, 4 + 3 * l] - sw[blk, 0, 3 + 3 * l]:.0f}/{sw[blk, nw - 1, 4 + 3 * l] - sw[blk, nw - 1, 3 + 3 * l]:.0f}' for l in range(L)))
     for l in range(min(L, 2)):
         print(f"   layer {l}: per-wave [k-loop start, k-loop end, after barriers] rel. to WG start: " + "  ".join(f"w{w}:{sw[blk, w, 3 + 3 * l] - t0:.0f}/{sw[blk, w, 4 + 3 * l] - t0:.0f}/{sw[blk, w, 5 + 3 * l] - t0:.0f}" for w in range(nw)))
     st = sw[:, 0, :]
@@ -65,6 +69,6 @@ for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8,
     epi = np.median(sum(st[:, 5 + 3 * l] - st[:, 4 + 3 * l] for l in range(L)))
     parts += [("layer prologue (bias/res/B preload)", pro), ("k-loops", kl), ("epilogue+barriers+write", epi),
               ("final store", d(5 + 3 * (L - 1), 30))]
-    print(f"C={Cc} {H}x{W} L={L} blocks={nblk} tile_rows={info[0]} kernel {e0.elapsed_time(e1) * 1e3:.1f} us; "
-          f"median WG {tot:.0f} clk (100 MHz ticks? see ratio): " +
+    print(f"C={Cc} {H}x{W} L={L} blocks={nblk} waves={nw} tile_rows={info[0]} kernel {e0.elapsed_time(e1) * 1e3:.1f} us; "
+          f"median WG {tot:.0f} shader clk: " +
           ", ".join(f"{n} {v / tot * 100:.0f}%" for n, v in parts), flush=True)
