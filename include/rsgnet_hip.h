@@ -113,15 +113,23 @@ int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, cons
 size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch);
 int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
                               int32_t* info4);
-/* Up to 4 chains (the branches of one HighResolutionModule, pose_hrnet.py:254-255) in ONE launch; the
- * workgroups of items[0] are dispatched first, so put the longest chain there. */
+/* Up to 6 chains (the branches of one HighResolutionModule, pose_hrnet.py:254-255) in ONE launch; the
+ * workgroups of items[0] are dispatched first, so put the longest chain there.
+ * A branch whose map needs row tiles (halo grows with the chain) can be cut in two items that hand over inside
+ * the launch: the first sets done_flags[workgroup] after its stores, the second (later in the array, same
+ * shape, in == the first's out) names those flags in wait_flags, polls the tiles it reads and clears what it
+ * saw.  done_flags: int32[3 * workgroups of the item], zeroed ONCE by the caller (a launch leaves every word
+ * that is polled at zero again). */
 typedef struct rsg_chain_item {
     const void* in;
     void* out;
     const void* const* w_packed;   /* HOST array of nlayers device pointers */
     const float* const* bias;      /* HOST array of nlayers device pointers */
-    int32_t nlayers, batch, h, w, c, reserved;
+    int32_t nlayers, batch, h, w, c;
+    int32_t images_per_workgroup;  /* whole-image maps: images one workgroup takes (0 = default 1); fewer, longer workgroups */
     void* workspace;               /* rsg_basic_chain_workspace_bytes(c,h,w,nlayers,batch) bytes, own per item */
+    void* done_flags;              /* NULL, or 3 x int32 per workgroup (see above) */
+    const void* wait_flags;        /* NULL, or the done_flags of an earlier item */
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
 

@@ -53,6 +53,12 @@ struct ChainArgs {
     int tiles_y;
     int RP;       // LDS row pitch in bytes (host: chain_row_pitch)
     uint4* ws;    // block inputs: [workgroup][NT*2][threads] x 16 B
+    // hand-off inside one grouped launch (row-tiled branch cut in two chains): a workgroup sets its three words
+    // done[3*index + d] after its stores, one for each chain tile that reads it (the tile above, the same tile,
+    // the tile below); a dependent chain polls the words addressed to it before it stages and clears them.
+    // Both null for an ordinary chain.
+    int* done;
+    const int* wait;
 };
 
 template <class DT, int C, int WM, int WN, int NT>
@@ -89,8 +95,28 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     for (int o = tid * 16; o < lds_bytes; o += NTHR * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     RSG_STAMP(1);
+    if (p.wait) {
+        // producer tiles this window overlaps: tile-1 .. tile+1 of the same image.  One lane per flag polls with
+        // sc1 loads (L2, never this CU's L1); the barrier below releases the other waves (MI355X_MICROARCH.md,
+        // inter-workgroup visibility: sc1 stores + sc1 flag on the producer, sc1 poll + sc1 loads here, no fences).
+        // The poll is bounded: a producer that never signals costs a wrong answer, not a hung GPU.
+        // Every (producer tile, consumer tile) pair has a flag word of its own, so the consumer can clear it once
+        // it has seen it: the flags are back at zero when the launch ends and need no reset between launches.
+        const int t_lo = max(tile - 1, 0), t_hi = min(tile + 1, p.tiles_y - 1);
+        if (tid <= t_hi - t_lo) {
+            const int tp = t_lo + tid;                                  // producer tile
+            int* f = const_cast<int*>(p.wait) + (((block_id / p.tiles_y) * p.tiles_y + tp) * 3 + (tile - tp + 1));
+            for (int spin = 0; spin < (1 << 20) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+                __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     const int chunks_per_img = R * W * CPP;
     constexpr int NLD = 12;                              // staging loads in flight per thread
+    // sc1 loads (aux 16): served by L2, so a tile written by another workgroup of this launch is read fresh
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.in), 0, p.B * p.H * W * C * 2, 0x00020000);
     for (int base = 0; base < p.NI * chunks_per_img; base += NTHR * NLD) {
         uint4 v[NLD];
         int lo[NLD];
@@ -105,7 +131,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
                 const int r = pix / W, x = pix - r * W;
                 const int y = y_first + r, b = b0 + i;
                 if (y >= 0 && y < p.H && b < p.B) {
-                    v[j] = *reinterpret_cast<const uint4*>(p.in + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2);
+                    v[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                        in_rsrc, (((b * p.H + y) * W + x) * C + cg * 8) * 2, 0, 16));
                     lo[j] = (i * slot_rows + r + 1) * RP + (x + 1) * PS + cg * 16;
                 }
             }
@@ -301,7 +328,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         RSG_STAMP(5 + 3 * l);
     }
 
-    // ---- store the TH output rows of every image slot -----------------------------------------------------
+    // ---- store the TH output rows of every image slot (sc1: written through, see the hand-off above) ----------
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * W * C * 2, 0x00020000);
     const int out_chunks = p.TH * W * CPP;
     for (int id = tid; id < p.NI * out_chunks; id += NTHR) {
         const int i = id / out_chunks, rem = id - i * out_chunks;
@@ -311,8 +339,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         if (y < p.H && b < p.B) {
             const uint4 v = *reinterpret_cast<const uint4*>(
                 smem + (i * slot_rows + y - y_first + 1) * RP + (x + 1) * PS + cg * 16);
-            *reinterpret_cast<uint4*>(p.out + ((((size_t)b * p.H + y) * W + x) * C + cg * 8) * 2) = v;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc,
+                                                   (((b * p.H + y) * W + x) * C + cg * 8) * 2, 0, 16);
         }
+    }
+    if (p.done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores have left the CU
+        __syncthreads();
+        if (tid < 3) __hip_atomic_store(p.done + block_id * 3 + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     RSG_STAMP(30);
 }
@@ -325,7 +359,7 @@ __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) 
 
 // Grouped launch: up to 4 chains (different branches of one HighResolutionModule) in ONE grid; the
 // workgroups of item 0 come first (put the longest chain there).  Every variant runs 512 threads.
-#define RSG_CHAIN_GROUP_MAX 4
+#define RSG_CHAIN_GROUP_MAX 6
 struct ChainGroupArgs {
     int n;
     int first[RSG_CHAIN_GROUP_MAX + 1];   // first[i] = first block of item i, first[n] = grid size
@@ -340,9 +374,15 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
     const int bid = blockIdx.x - g.first[i];
     switch (g.c[i]) {
-        case 32: chain_body<DT, 32, 1, 8, 7>(g.a[i], bid, smem); break;
+        case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
+            if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6>(g.a[i], bid, smem);
+            else chain_body<DT, 32, 1, 8, 7>(g.a[i], bid, smem);
+            break;
         case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem); break;
-        case 128: chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem); break;
+        case 128:  // 16x12 maps: one image = 6 pixel groups over 2 wave columns; two images per workgroup = 12
+            if (g.a[i].NI * g.a[i].R * g.a[i].W <= 192) chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem);
+            else chain_body<DT, 128, 4, 2, 6>(g.a[i], bid, smem);
+            break;
         case 256:   // NT follows the pixels a workgroup owns (1 image = 48 px = 2 groups, 2 images = 3 groups)
             if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) chain_body<DT, 256, 8, 1, 2>(g.a[i], bid, smem);
             else chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem);
@@ -353,6 +393,8 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
 // ------------------------------------------------------------------------------------------------
 struct ChainCfg { int C, WM, WN, NT; };
 static const ChainCfg kChainCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
+// widest variants of the grouped launch (512 threads each)
+static const ChainCfg kChainGroupCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 2, 6}, {256, 8, 1, 3}};
 static const int CHAIN_LDS_LIMIT = 160 * 1024;
 static const int kChainMaxNT = 8;      // workspace slots are sized for the widest variant (standalone or grouped)
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
@@ -362,7 +404,9 @@ static int chain_row_pitch(int C, int W) {
     const int PS = 2 * C + 16;
     return (W + 2) * PS + (g_chain_pitch_pad ? (256 - (2 * PS) % 256) % 256 : 0);
 }   // rsg_tune("chain_max_ni", n): images per workgroup cap in whole-image mode
+extern int g_conv_lds_limit;
 extern "C" int rsg_tune(const char* key, int32_t value) {
+    if (key && !strcmp(key, "conv_lds_limit") && value >= 8192 && value <= 64 * 1024) { g_conv_lds_limit = value; return 0; }
     if (key && !strcmp(key, "chain_max_ni") && value >= 1) { g_chain_max_ni = value; return 0; }
     if (key && !strcmp(key, "chain_pitch_pad")) { g_chain_pitch_pad = value ? 1 : 0; return 0; }
     RSG_FAIL("tune: unknown key or bad value");
@@ -372,6 +416,7 @@ typedef void (*chain_fn)(const ChainArgs);
 template <class DT>
 static chain_fn chain_lookup(int C, int npix) {
     if (C == 256 && npix <= 64) return chain_kernel<DT, 256, 8, 1, 2>;
+    if (C == 32 && npix <= 1536) return chain_kernel<DT, 32, 1, 8, 6>;
     switch (C) {
         case 32: return chain_kernel<DT, 32, 1, 8, 7>;
         case 64: return chain_kernel<DT, 64, 2, 4, 6>;
@@ -382,9 +427,12 @@ static chain_fn chain_lookup(int C, int npix) {
 }
 
 // Picks (tile rows, images per workgroup) for a chain; returns 0 when the shape is supported.
-static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs& a, int& lds, int& nthr) {
+// ni_want: images per workgroup asked for in whole-image mode (0 = the process-wide default, rsg_tune)
+static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs& a, int& lds, int& nthr,
+                          bool grouped = false, int ni_want = 0) {
     const ChainCfg* cfg = nullptr;
-    for (const ChainCfg& c : kChainCfgs) if (c.C == C) cfg = &c;
+    for (const ChainCfg& c : (grouped ? kChainGroupCfgs : kChainCfgs)) if (c.C == C) cfg = &c;
+    if (ni_want < 1) ni_want = g_chain_max_ni;
     if (!cfg) return 1;
     const int cap = 32 * cfg->NT * cfg->WN;              // pixels a workgroup can own
     const int PS = 2 * C + 16;
@@ -394,7 +442,7 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     auto bytes = [&](int ni, int R) { return ni * (R + 2) * RP + RSG_CHAIN_MAX_LAYERS * C * 4; };   // image + biases
     if (H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
         int ni = cap / (H * W);
-        while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > g_chain_max_ni)) --ni;
+        while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > ni_want)) --ni;
         a.TH = H; a.R = H; a.halo = 0; a.NI = ni; a.tiles_y = 1;
         lds = bytes(ni, H);
         return 0;
@@ -453,6 +501,7 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
         RSG_FAIL("basic_chain: unsupported shape C=%d %dx%d L=%d", c, h, w, nlayers);
     a.in = (const char*)in; a.out = (char*)out; a.nlayers = nlayers; a.B = batch; a.H = h; a.W = w;
     a.ws = (uint4*)workspace;
+    a.done = nullptr; a.wait = nullptr;
     for (int l = 0; l < nlayers; ++l) {
         if (!w_packed[l] || !bias[l]) RSG_FAIL("basic_chain: null weights for layer %d", l);
         a.wpk[l] = (const uint4*)w_packed[l];
@@ -481,11 +530,25 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         if (it.nlayers < 2 || it.nlayers > RSG_CHAIN_MAX_LAYERS || (it.nlayers & 1)) RSG_FAIL("chain_group: nlayers=%d", it.nlayers);
         ChainArgs& a = g.a[i];
         int lds = 0, nthr = 0;
-        if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr))
+        if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr, true, it.images_per_workgroup))
             RSG_FAIL("chain_group: unsupported shape C=%d %dx%d L=%d", it.c, it.h, it.w, it.nlayers);
         if ((!it.workspace || ((uintptr_t)it.workspace & 15))) RSG_FAIL("chain_group: item %d needs a workspace", i);
         a.in = (const char*)it.in; a.out = (char*)it.out; a.nlayers = it.nlayers; a.B = it.batch; a.H = it.h; a.W = it.w;
         a.ws = (uint4*)it.workspace;
+        a.done = (int*)it.done_flags;
+        a.wait = (const int*)it.wait_flags;
+        if (it.wait_flags) {
+            // the producer must come EARLIER in the grid (workgroups are dispatched in index order, so every
+            // producer is running or finished before a consumer can occupy a CU), write what this item reads and
+            // cut the map into the same tiles
+            int j = 0;
+            while (j < i && items[j].done_flags != it.wait_flags) ++j;
+            if (j == i) RSG_FAIL("chain_group: item %d waits on flags no earlier item sets", i);
+            const rsg_chain_item& pr = items[j];
+            if (pr.out != it.in || pr.c != it.c || pr.h != it.h || pr.w != it.w || pr.batch != it.batch ||
+                pr.nlayers != it.nlayers || g.a[j].NI != 1 || a.NI != 1 || g.a[j].tiles_y != a.tiles_y)
+                RSG_FAIL("chain_group: item %d must read item %d's output with the same tiling", i, j);
+        }
         for (int l = 0; l < it.nlayers; ++l) {
             if (!it.w_packed[l] || !it.bias[l]) RSG_FAIL("chain_group: null weights (item %d layer %d)", i, l);
             a.wpk[l] = (const uint4*)it.w_packed[l];

@@ -40,7 +40,8 @@ class ChainItem(C.Structure):
     """struct rsg_chain_item (include/rsgnet_hip.h)."""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
                 ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
-                ("w", C.c_int32), ("c", C.c_int32), ("reserved", C.c_int32), ("workspace", C.c_void_p)]
+                ("w", C.c_int32), ("c", C.c_int32), ("images_per_workgroup", C.c_int32), ("workspace", C.c_void_p),
+                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p)]
 
 
 # every symbol include/rsgnet_hip.h declares: name -> (restype, argtypes)
@@ -107,7 +108,8 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad")):
+        for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad"),
+                         ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit")):
             if os.environ.get(env):
                 l.rsg_tune(key, int(os.environ[env]))
         _lib = l

@@ -296,9 +296,14 @@ class Plan:
         return out
 
     def chain_group(self, items, name="") -> List[VT]:
-        """Record ONE launch that runs several chains (rsg_basic_chain_group).  items: [(x, blocks)]."""
+        """Record ONE launch that runs several chains (rsg_basic_chain_group).  items: [(x, blocks)]; x may be the
+        INDEX of an earlier item: that chain then reads the earlier one's output and the two hand over inside the
+        launch (done/wait flags, include/rsgnet_hip.h)."""
         subs, outs = [], []
         for x, blocks in items:
+            after = None
+            if isinstance(x, int):
+                after, x = x, outs[x]
             layers = []
             for blk in blocks:
                 for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
@@ -306,10 +311,11 @@ class Plan:
                     wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
                     layers.append((wp, bo))
             out = self.new(x.H, x.W, x.C, name=name)
-            subs.append(dict(x=x, out=out, layers=layers))
+            subs.append(dict(x=x, out=out, layers=layers, after=after))
             outs.append(out)
             self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
-        self._record(dict(kind="chain_group", subs=subs, name=name), [d["x"] for d in subs], outs)
+        self._record(dict(kind="chain_group", subs=subs, name=name),
+                     [d["x"] for d in subs if d["after"] is None], outs)
         return outs
 
     def chain_mode(self, C_, H, W, nblocks) -> int:
@@ -552,6 +558,31 @@ class Plan:
             it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, x.C
             it.workspace = self._chain_workspace(len(log), x, n)
             log.append((x.C, x.H, x.W, n))
+        for k, d in enumerate(subs):
+            if d.get("after") is not None:
+                prod = items[d["after"]]
+                info = (C.c_int32 * 4)()
+                self.lib.rsg_basic_chain_supported(prod.c, prod.h, prod.w, prod.nlayers, prod.batch, info)
+                flags = torch.zeros(3 * info[3], dtype=torch.int32, device=self.device)   # zeroed once, self-clearing
+                self._keep.append(flags)
+                prod.done_flags = flags.data_ptr()
+                items[k].wait_flags = flags.data_ptr()
+        # RSGNET_HIP_CHAIN_PACK=1 (experiment, off: measured neutral): when the grid has more workgroups than CUs,
+        # let the smallest whole-image maps take two images per workgroup until it fits in one round
+        if os.environ.get("RSGNET_HIP_CHAIN_PACK", "0") != "0":
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            info = (C.c_int32 * 4)()
+            blocks = []
+            for it in items:
+                self.lib.rsg_basic_chain_supported(it.c, it.h, it.w, it.nlayers, it.batch, info)
+                blocks.append((info[3], info[0] == it.h))
+            total = sum(b for b, _ in blocks)
+            for k in sorted(range(len(subs)), key=lambda k: items[k].h * items[k].w):
+                if total <= cus:
+                    break
+                if blocks[k][1] and items[k].c >= 128:
+                    items[k].images_per_workgroup = 2
+                    total -= blocks[k][0] // 2
         self._keep.append(items)
         fn, nm, n_items, dt = self.lib.rsg_basic_chain_group, r["name"], len(subs), self.dtype
         self.conv_log.append(dict(name=nm, group=log))
@@ -740,11 +771,47 @@ class _BackboneMixin:
         # branches: LDS-resident chains, grouped so that ONE launch runs every branch of the module
         # (longest chain first); a branch that needs row tiles contributes its blocks slice by slice
         slices: List[List[Tuple[int, list]]] = []      # slices[k] = [(branch, blocks)] of the k-th launch
+        steps = {}
         for b, branch in enumerate(mod.branches):
             blocks = list(branch)
             plain = all(not hasattr(blk, "conv3") and blk.downsample is None for blk in blocks)
             plain = plain and blocks[0].conv1.in_channels == xs[b].C        # no channel padding (W48: 48 in 64)
-            step = self.chain_mode(xs[b].C, xs[b].H, xs[b].W, len(blocks)) if plain else 0
+            steps[b] = self.chain_mode(xs[b].C, xs[b].H, xs[b].W, len(blocks)) if plain else 0
+        # RSGNET_HIP_CHAIN_HANDOFF (default on): ONE launch per module.  Whole-image branches run all their blocks in
+        # one chain; a row-tiled branch (halo grows with the chain) runs as two chains that hand over inside the
+        # launch, so its second half needs no launch of its own (where half the CUs would idle).
+        info = (C.c_int32 * 4)()
+
+        def whole(b):
+            n = 2 * len(mod.branches[b])
+            return n <= 8 and self.lib.rsg_basic_chain_supported(xs[b].C, xs[b].H, xs[b].W, n, self.batch, info) \
+                and info[0] == xs[b].H
+
+        handoff = self.use_group and len(steps) > 1 and all(steps.values()) and \
+            os.environ.get("RSGNET_HIP_CHAIN_HANDOFF", "1") != "0" and \
+            all(whole(b) or 2 * steps[b] == len(mod.branches[b]) for b in steps)
+        if handoff:
+            order = sorted(steps, key=lambda b: (not whole(b), -xs[b].C))       # whole-image chains first, widest first
+            items, where = [], {}
+            for b in order:
+                blocks = list(mod.branches[b])
+                if whole(b):
+                    where[b] = len(items)
+                    items.append((xs[b], blocks))
+            for b in order:                      # first halves, then second halves: a producer precedes its consumer
+                if not whole(b):
+                    where[b] = len(items)
+                    items.append((xs[b], list(mod.branches[b])[:steps[b]]))
+            for b in order:
+                if not whole(b):
+                    first, where[b] = where[b], len(items)
+                    items.append((first, list(mod.branches[b])[steps[b]:]))
+            outs = self.chain_group(items, f"{name}.chains")
+            for b in order:
+                xs[b] = outs[where[b]]
+            steps = {}
+        for b, step in steps.items():
+            blocks = list(mod.branches[b])
             if not step:
                 with self.on_lane(b):
                     for k, blk in enumerate(blocks):

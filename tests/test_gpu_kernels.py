@@ -308,3 +308,82 @@ def test_basic_chain_matches_cpu(Cc, H, W, L):
     # identical roundings except where fp32 summation order flips a 16-bit tie: a few ulps, amplified
     # mildly along the chain
     assert err <= 2.0 ** -7 * float(t.abs().max()), (err, float(t.abs().max()), list(info))
+
+
+def _chain_layers(lib, Cc, L, seed):
+    """L packed 3x3 Cc->Cc layers (device weights, biases) with BasicBlock-like scales."""
+    g = torch.Generator().manual_seed(seed)
+    keep, wps, bps = [], [], []
+    for l in range(L):
+        w = (torch.randn(Cc, Cc, 3, 3, generator=g) * (2.0 / (Cc * 9)) ** 0.5).numpy()
+        sc = ((torch.rand(Cc, generator=g) * 0.4 + 0.1) if l % 2 else (torch.rand(Cc, generator=g) + 0.5)).numpy()
+        sh = (torch.randn(Cc, generator=g) * 0.1).numpy()
+        wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
+        bo = np.zeros(Cc, np.float32)
+        hip.check(lib.rsg_pack_conv_weights_host(w.ctypes.data, sc.ctypes.data, sh.ctypes.data, None, Cc, Cc, 3, 3, 0,
+                                                 wp.ctypes.data, bo.ctypes.data))
+        wd, bd = torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+        keep += [wd, bd]
+        wps.append(wd.data_ptr())
+        bps.append(bd.data_ptr())
+    return keep, wps, bps
+
+
+def test_chain_group_handoff_inside_one_launch():
+    """A row-tiled branch cut in two chains that hand over INSIDE one grouped launch (done/wait flags) gives
+    bit for bit what two separate launches give, next to a long whole-image chain that keeps the grid uneven."""
+    lib = hip.lib()
+    B, L = 64, 4
+    g = torch.Generator().manual_seed(5)
+    x32 = torch.randn(B, 64, 48, 32, generator=g).half().to(DEV)
+    x64 = torch.randn(B, 32, 24, 64, generator=g).half().to(DEV)
+    k32a, w32a, b32a = _chain_layers(lib, 32, L, 1)
+    k32b, w32b, b32b = _chain_layers(lib, 32, L, 2)
+    k64, w64, b64 = _chain_layers(lib, 64, 2 * L, 3)
+
+    def ws(Cc, H, W, n):
+        return torch.empty(lib.rsg_basic_chain_workspace_bytes(Cc, H, W, n, B), dtype=torch.uint8, device=DEV)
+
+    def arr(v):
+        return (C.c_void_p * len(v))(*v)
+
+    # reference: three separate launches
+    mid, ref32, ref64 = torch.empty_like(x32), torch.empty_like(x32), torch.empty_like(x64)
+    wsa, wsb, wsc = ws(32, 64, 48, L), ws(32, 64, 48, L), ws(64, 32, 24, 2 * L)
+    hip.check(lib.rsg_basic_chain(x32.data_ptr(), mid.data_ptr(), arr(w32a), arr(b32a), L, B, 64, 48, 32, 0, wsa.data_ptr(), _stream()))
+    hip.check(lib.rsg_basic_chain(mid.data_ptr(), ref32.data_ptr(), arr(w32b), arr(b32b), L, B, 64, 48, 32, 0, wsb.data_ptr(), _stream()))
+    hip.check(lib.rsg_basic_chain(x64.data_ptr(), ref64.data_ptr(), arr(w64), arr(b64), 2 * L, B, 32, 24, 64, 0, wsc.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+
+    info = (C.c_int32 * 4)()
+    assert lib.rsg_basic_chain_supported(32, 64, 48, L, B, info) == 1
+    flags = torch.zeros(info[3] * 3, dtype=torch.int32, device=DEV)      # zeroed once: launches leave them clean
+    items = (hip.ChainItem * 3)()
+    keep = []
+    spec = [(x64, None, 64, 32, 24, 2 * L, w64, b64, wsc, None, None),
+            (x32, None, 32, 64, 48, L, w32a, b32a, wsa, flags, None),
+            (None, None, 32, 64, 48, L, w32b, b32b, wsb, None, flags)]
+    outs = [torch.empty_like(x64), torch.empty_like(x32), torch.empty_like(x32)]
+    for it, (xin, _o, Cc, H, W, n, wp, bp, wsp, done, wait), out in zip(items, spec, outs):
+        wa, ba = arr(wp), arr(bp)
+        keep += [wa, ba]
+        it.inp = (outs[1] if xin is None else xin).data_ptr()
+        it.out = out.data_ptr()
+        it.w_packed, it.bias = C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p))
+        it.nlayers, it.batch, it.h, it.w, it.c = n, B, H, W, Cc
+        it.workspace = wsp.data_ptr()
+        it.done_flags = done.data_ptr() if done is not None else None
+        it.wait_flags = wait.data_ptr() if wait is not None else None
+    for rep in range(8):
+        for o in outs:
+            o.fill_(float("nan"))
+        hip.check(lib.rsg_basic_chain_group(items, 3, 0, _stream()), "chain_group")
+        torch.cuda.synchronize()
+        f = flags.view(-1, info[3] // B, 3).cpu()           # [image, producer tile, consumer tile - producer tile + 1]
+        assert not f[:, 0, 1:].any() and not f[:, -1, :2].any()      # every word that has a reader is clear again
+        assert torch.equal(outs[0], ref64), rep
+        assert torch.equal(outs[1], mid), rep
+        assert torch.equal(outs[2], ref32), rep
+    # the consumer must come after its producer
+    items[1], items[2] = items[2], items[1]
+    assert lib.rsg_basic_chain_group(items, 3, 0, _stream()) != 0

@@ -20,7 +20,7 @@ subprocess.check_call(cmd)
 lib = C.CDLL(so)
 lib.rsg_last_error.restype = C.c_char_p
 Bn = 64
-for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8, 6, 4), (64, 32, 24, 8)):
+for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8, 6, 4), (64, 32, 24, 8), (32, 64, 48, 8), (128, 16, 12, 8), (256, 8, 6, 8)):
     x = (torch.zeros if os.environ.get("STAMP_ZERO") else torch.randn)(Bn, H, W, Cc, device="cuda").half()
     out = torch.empty_like(x)
     keep, wps, bps = [], [], []
