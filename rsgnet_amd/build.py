@@ -4,6 +4,7 @@ from __future__ import annotations
 import concurrent.futures as cf
 import glob
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -50,12 +51,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc, *flags, *extra.get(os.path.basename(src), []), "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, *extra.get(os.path.basename(src), []), "-Rpass-analysis=kernel-resource-usage",
+               "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
-        if verbose and r.stderr:
-            print(r.stderr, file=sys.stderr)
+        # No kernel may touch scratch.  Register spills are not just slow here: grouped chain launches whose
+        # kernel spilled a handful of VGPRs gave different bits from run to run (one wave's pixels wrong, a few
+        # per cent of the launches; tools/chain_group_stress.py), and went away with the spills.  RSGNET_HIP_ALLOW_SCRATCH=1
+        # turns the check into a warning for experiments.
+        name, bad = None, []
+        for line in r.stderr.splitlines():
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+            if m and int(m.group(1)) and name:
+                bad.append(f"{name}: {m.group(1)} B/lane")
+        if bad:
+            msg = f"{os.path.basename(src)}: kernels using scratch memory: " + "; ".join(bad)
+            if os.environ.get("RSGNET_HIP_ALLOW_SCRATCH", "0") == "0":
+                raise RuntimeError(msg)
+            print("warning: " + msg, file=sys.stderr)
+        if verbose:
+            rest = "\n".join(ln for ln in r.stderr.splitlines() if "-Rpass-analysis" not in ln and "remark:" not in ln)
+            if rest.strip():
+                print(rest, file=sys.stderr)
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=4) as ex:

@@ -59,7 +59,7 @@ static void tile_geometry(const rsg_conv_desc* d, TilePlan& t) {
     t.tiles_x = ceil_div(d->out_w, t.TW);
 }
 
-int g_conv_lds_limit = 64 * 1024;      // rsg_tune("conv_lds_limit", bytes): LDS cap of the tile chooser
+int g_conv_lds_limit = 52 * 1024;      // rsg_tune("conv_lds_limit", bytes): LDS cap of the tile chooser
 #define LDS_LIMIT g_conv_lds_limit
 
 static int choose_tile(const rsg_conv_desc* d, TilePlan& best) {

@@ -22,15 +22,22 @@ lib = C.CDLL(so)
 lib.rsg_last_error.restype = C.c_char_p
 lib.rsg_basic_chain_workspace_bytes.restype = C.c_size_t
 Bn = int(os.environ.get("BATCH", "64"))
-L = int(os.environ.get("LAYERS", "4"))
-ni = [int(v) for v in os.environ.get("NI", "0,0,0,0").split(",")]
-branches = [(256, 8, 6), (128, 16, 12), (64, 32, 24), (32, 64, 48)][:int(os.environ.get("BRANCHES", "4"))]
+ni = [int(v) for v in os.environ.get("NI", "0,0,0,0,0").split(",")]
+nb = int(os.environ.get("BRANCHES", "4"))
+if os.environ.get("HANDOFF", "1") != "0":      # the module as the plan launches it: 8 layers, branch 0 as two halves
+    branches = [(256, 8, 6, 8, None), (128, 16, 12, 8, None), (64, 32, 24, 8, None)][3 - (nb - 1):] + \
+               [(32, 64, 48, 4, None), (32, 64, 48, 4, nb - 1)]
+else:
+    L = int(os.environ.get("LAYERS", "4"))
+    branches = [(256, 8, 6, L, None), (128, 16, 12, L, None), (64, 32, 24, L, None), (32, 64, 48, L, None)][4 - nb:]
 keep = []
 items = (hip.ChainItem * len(branches))()
 nblk = []
-for k, (Cc, H, W) in enumerate(branches):
-    x = torch.randn(Bn, H, W, Cc, device="cuda").half()
+outs = []
+for k, (Cc, H, W, L, after) in enumerate(branches):
+    x = torch.randn(Bn, H, W, Cc, device="cuda").half() if after is None else outs[after]
     out = torch.empty_like(x)
+    outs.append(out)
     wps, bps = [], []
     for l in range(L):
         w = (np.random.randn(Cc, Cc, 3, 3) * (2.0 / (Cc * 9)) ** 0.5).astype(np.float32)
@@ -54,6 +61,11 @@ for k, (Cc, H, W) in enumerate(branches):
     info = (C.c_int32 * 4)()
     lib.rsg_basic_chain_supported(Cc, H, W, L, Bn, info)
     nblk.append(info[3] // max(ni[k], 1) if info[0] == H else info[3])
+    if after is not None:
+        fl = torch.zeros(3 * info[3], dtype=torch.int32, device="cuda")
+        keep.append(fl)
+        items[after].done_flags = fl.data_ptr()
+        it.wait_flags = fl.data_ptr()
 total = sum(nblk)
 stamps = torch.zeros(total * 8 * 32, dtype=torch.int64, device="cuda")
 lib.rsg_chain_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
@@ -65,15 +77,42 @@ e0.record()
 lib.rsg_basic_chain_group(items, len(branches), 0, None)
 e1.record()
 torch.cuda.synchronize()
-sw = stamps.cpu().numpy().reshape(total, 8, 32).astype(np.float64)
-t0 = sw[:, 0, 0].min()
+raw = stamps.cpu().numpy().reshape(total, 8, 32)
+sw = raw.astype(np.float64)
+# every XCD has a clock of its own: times are taken from the first start seen on the workgroup's XCD
+xcc = (raw[:, 0, 31] >> 32) & 0xf
+hwid = raw[:, 0, 31] & 0xffffffff
+cu = ((hwid >> 8) & 0xf) | (((hwid >> 13) & 0x7) << 4) | (xcc << 8)      # cu_id, se_id (gfx9 HW_ID), XCD
+for x in np.unique(xcc):
+    m = xcc == x
+    sw[m, :, :31] -= sw[m, 0, 0].min()
+print(f"XCDs seen: {sorted(int(v) for v in np.unique(xcc))}, distinct CUs: {len(np.unique(cu))}")
 print(f"grouped launch: {total} workgroups, {e0.elapsed_time(e1) * 1e3:.1f} us by events; "
-      f"last end at {(sw[:, 0, 30].max() - t0):.0f} cycles")
+      f"last end at {sw[:, 0, 30].max():.0f} cycles")
 first = 0
-for (Cc, H, W), n in zip(branches, nblk):
-    st, en = sw[first:first + n, 0, 0] - t0, sw[first:first + n, 0, 30] - t0
+for (Cc, H, W, L, after), n in zip(branches, nblk):
+    st, en = sw[first:first + n, 0, 0], sw[first:first + n, 0, 30]
     d = en - st
-    late = int((st > 0.2 * en.max()).sum())
-    print(f"  C={Cc:3d} {H}x{W}: {n:3d} workgroups, start {st.min():.0f}..{st.max():.0f}, duration median {np.median(d):.0f} "
-          f"(min {d.min():.0f} max {d.max():.0f}), end max {en.max():.0f}; {late} started late")
+    late = int((st > 20000).sum())
+    print(f"  C={Cc:3d} {H}x{W} L={L}: {n:3d} workgroups, start {st.min():.0f}..{st.max():.0f}, duration median {np.median(d):.0f} "
+          f"(min {d.min():.0f} max {d.max():.0f}), end median {np.median(en):.0f} max {en.max():.0f}; {late} started after 20k cycles "
+          f"(their median start {np.median(st[st > 20000]) if late else 0:.0f})")
     first += n
+
+# per-CU view (clock offsets between CUs do not matter here): which workgroups ran on each CU, back to back?
+item_of = np.concatenate([np.full(n, k) for k, n in enumerate(nblk)])
+from collections import Counter
+pat, spans, idle = Counter(), [], []
+for c in np.unique(cu):
+    m = np.where(cu == c)[0]
+    m = m[np.argsort(raw[m, 0, 0])]
+    s0 = raw[m, 0, 0].astype(np.float64)
+    e0_ = raw[m, 0, 30].astype(np.float64)
+    pat[",".join(str(item_of[i]) for i in m)] += 1
+    spans.append(e0_.max() - s0.min())
+    idle.append(float(sum(max(0.0, s0[j + 1] - e0_[j]) for j in range(len(m) - 1))))
+spans = np.array(spans)
+print(f"per-CU busy span (first start to last end): median {np.median(spans):.0f} max {spans.max():.0f} cycles; "
+      f"gaps between consecutive workgroups on a CU: median {np.median(idle):.0f} max {max(idle):.0f}")
+for k, v in pat.most_common(12):
+    print(f"   {v:3d} CUs ran items [{k}]")
