@@ -97,14 +97,29 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         g_chain_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + 31] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
-    // ---- zero the whole image (borders = the zero padding of each conv; the interior is overwritten by the staging
-    // below; an image slot past the end of the batch stays zero).
-    // Zeroing only the borders (2-3 % of the kernel) made GROUPED launches give different bits from run to run, one
-    // 64-channel pixel group at a time, although every byte the kernel reads is then still written first
-    // (tools/chain_group_stress.py, tools/e2e_stress.py reproduce it; cause not found) -- so all of it, then a barrier.
+    // ---- zero what staging does not write: the border row above and below every image slot and the border pixel
+    // left and right of every row (the zero padding of each conv; the epilogues never touch them).  Every held row
+    // lies inside the picture (clamped window), so the interior is overwritten by the staging below; only an image
+    // slot past the end of the batch is zeroed as a whole.
     const int lds_bytes = p.NI * slot_rows * RP;
-    for (int o = tid * 16; o < lds_bytes; o += NTHR * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    {
+        const int row_chunks = RP / 16;                  // RP is a multiple of 16
+        const int per_slot = 2 * row_chunks + R * 2 * CPP;
+        for (int id = tid; id < p.NI * per_slot; id += NTHR) {
+            const int i = id / per_slot, e = id - i * per_slot;
+            int off;
+            if (e < 2 * row_chunks) off = (e < row_chunks ? 0 : (R + 1) * RP) + (e % row_chunks) * 16;
+            else {
+                const int q = e - 2 * row_chunks, r = q / (2 * CPP), c = q - r * (2 * CPP);
+                off = (r + 1) * RP + (c < CPP ? 0 : (W + 1) * PS) + (c % CPP) * 16;
+            }
+            *reinterpret_cast<uint4*>(smem + i * slot_rows * RP + off) = make_uint4(0, 0, 0, 0);
+        }
+        for (int i = 0; i < p.NI; ++i)
+            if (b0 + i >= p.B)
+                for (int o = tid * 16; o < slot_rows * RP; o += NTHR * 16)
+                    *reinterpret_cast<uint4*>(smem + i * slot_rows * RP + o) = make_uint4(0, 0, 0, 0);
+    }
     RSG_STAMP(1);
     if (p.wait) {
         // producer tiles this window overlaps: tile-1 .. tile+1 of the same image.  One lane per flag polls with
