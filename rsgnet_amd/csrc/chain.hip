@@ -19,6 +19,7 @@
 // ends.  Rows outside the image are re-zeroed after every layer (zero padding).
 // MFMA mapping, weight packing and LDS pixel layout are those of conv_igemm.hip.
 #include "common.h"
+#include <algorithm>
 
 #define RSG_CHAIN_MAX_LAYERS 8
 
@@ -62,7 +63,7 @@ struct ChainArgs {
 };
 
 template <class DT, int C, int WM, int WN, int NT>
-__device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_id, char* smem) {
+__device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_id, char* smem, const unsigned pf = 0) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int CINB = (C % 64 == 0) ? 64 : 32;      // same k order as rsg_pack_conv_weights_host
     constexpr int NCH = C / CINB, KPT = CINB / 16;
@@ -196,6 +197,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         pixoff[g] = (i * slot_rows + r + 1) * RP + (x + 1) * PS + hh * 16;
     }
     __syncthreads();
+    asm volatile("" ::"v"(pf));                           // the grouped launch's weight prefetch loads end here
     RSG_STAMP(2);
 
     constexpr int NPF = (C >= 128) ? 9 : (C == 64 ? 4 : 6);   // ring depth; must divide KS (18, 36, 72, 144)
@@ -397,29 +399,54 @@ __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) 
 #define RSG_CHAIN_GROUP_MAX 6
 struct ChainGroupArgs {
     int n;
+    // weight prefetch: one contiguous range of 128-byte lines per item (all its layers), 0 lines = none
+    const char* pre_ptr[RSG_CHAIN_GROUP_MAX];
+    int pre_lines[RSG_CHAIN_GROUP_MAX];
     int first[RSG_CHAIN_GROUP_MAX + 1];   // first[i] = first block of item i, first[n] = grid size
     int c[RSG_CHAIN_GROUP_MAX];
     ChainArgs a[RSG_CHAIN_GROUP_MAX];
 };
 
+// Weight prefetch of a grouped launch: before it stages, each of the first 256 workgroups (one per CU) touches
+// its share of the launch's weight lines once, first layers first, which brings them into the memory-side cache
+// while every workgroup is still staging (the loads are waited for behind the staging barrier).  In the running
+// forward nothing of a module's 3-12 MB of weights is cached any more when its turn comes (a stage-4 launch:
+// 188 us, 131 us repeated back to back, 141 us with only the weights warmed; tools/op_in_context.py) and the
+// A-operand ring does not cover an HBM miss.  Dedicated prefetch workgroups did the same for stage 4 but cost
+// stage 3 a CU each (they hold the launch's LDS).
+static __device__ __forceinline__ unsigned chain_prefetch_weights(const ChainGroupArgs& g) {
+    const int nw = min((int)gridDim.x, 256);
+    unsigned acc = 0;
+    if ((int)blockIdx.x >= nw) return 0;
+#pragma unroll
+    for (int i = 0; i < RSG_CHAIN_GROUP_MAX; ++i) {          // static indices: the scalar loads of the table batch up
+        const char* w = g.pre_ptr[i];
+        const int lines = g.pre_lines[i];                    // 0 for an unused entry
+        for (int k = blockIdx.x * 512 + threadIdx.x; k < lines; k += nw * 512)
+            acc ^= *reinterpret_cast<const unsigned*>(w + (size_t)k * 128);
+    }
+    return acc;
+}
+
 template <class DT>
 __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned pf = chain_prefetch_weights(g);
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
     const int bid = blockIdx.x - g.first[i];
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
-            if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6>(g.a[i], bid, smem);
-            else chain_body<DT, 32, 1, 8, 7>(g.a[i], bid, smem);
+            if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6>(g.a[i], bid, smem, pf);
+            else chain_body<DT, 32, 1, 8, 7>(g.a[i], bid, smem, pf);
             break;
-        case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem); break;
+        case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem, pf); break;
         case 128:  // 16x12 maps: one image = 6 pixel groups over 2 wave columns; two images per workgroup = 12
-            chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem);
+            chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem, pf);
             break;
         case 256:   // NT follows the pixels a workgroup owns (1 image = 48 px = 2 groups, 2 images = 3 groups)
-            if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) chain_body<DT, 256, 8, 1, 2>(g.a[i], bid, smem);
-            else chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem);
+            if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) chain_body<DT, 256, 8, 1, 2>(g.a[i], bid, smem, pf);
+            else chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem, pf);
             break;
     }
 }
@@ -434,6 +461,7 @@ static const int kChainMaxNT = 8;      // workspace slots are sized for the wide
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
 static int g_chain_max_ni = 1;
 static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
+static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
 static int chain_row_pitch(int C, int W) {
     const int PS = 2 * C + 16;
     return (W + 2) * PS + (g_chain_pitch_pad ? (256 - (2 * PS) % 256) % 256 : 0);
@@ -443,6 +471,7 @@ extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "conv_lds_limit") && value >= 8192 && value <= 64 * 1024) { g_conv_lds_limit = value; return 0; }
     if (key && !strcmp(key, "chain_max_ni") && value >= 1) { g_chain_max_ni = value; return 0; }
     if (key && !strcmp(key, "chain_pitch_pad")) { g_chain_pitch_pad = value ? 1 : 0; return 0; }
+    if (key && !strcmp(key, "chain_prefetch")) { g_chain_prefetch = value ? 1 : 0; return 0; }
     RSG_FAIL("tune: unknown key or bad value");
 }
 
@@ -587,6 +616,15 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
             if (!it.w_packed[l] || !it.bias[l]) RSG_FAIL("chain_group: null weights (item %d layer %d)", i, l);
             a.wpk[l] = (const uint4*)it.w_packed[l];
             a.bias[l] = it.bias[l];
+        }
+        // prefetch range: the item's layers when the caller packed them back to back (the plan does)
+        const size_t layer_bytes = (size_t)it.c * it.c * 18;
+        bool contiguous = g_chain_prefetch != 0;
+        for (int l = 1; l < it.nlayers; ++l)
+            contiguous = contiguous && (const char*)it.w_packed[l] == (const char*)it.w_packed[0] + l * layer_bytes;
+        if (contiguous) {
+            g.pre_ptr[i] = (const char*)it.w_packed[0];
+            g.pre_lines[i] = (int)(layer_bytes * it.nlayers / 128);
         }
         g.c[i] = it.c;
         g.first[i] = blocks;

@@ -310,6 +310,11 @@ class Plan:
                     scale, shift = self.bn_fold(bn)
                     wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
                     layers.append((wp, bo))
+            # the layers of one chain back to back in memory: the grouped launch prefetches them as one range
+            allw = torch.cat([w for w, _ in layers])
+            self._keep.append(allw)
+            n0 = layers[0][0].numel()
+            layers = [(allw[k * n0:(k + 1) * n0], b) for k, (_, b) in enumerate(layers)]
             out = self.new(x.H, x.W, x.C, name=name)
             subs.append(dict(x=x, out=out, layers=layers, after=after))
             outs.append(out)
