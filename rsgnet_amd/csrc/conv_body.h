@@ -3,6 +3,22 @@
 #pragma once
 #include "conv_args.h"
 
+// Diagnostic build (-DRSG_CONV_STAMPS): thread 0 of every workgroup records shader-clock stamps at the phase
+// boundaries (tools/conv_group_stamps.py); the production build contains none of this.
+#ifdef RSG_CONV_STAMPS
+static __device__ unsigned long long* g_conv_stamps = nullptr;      // [blocks][8]; one copy per translation unit
+#define RSG_CSTAMP(slot)                                                                      \
+    do {                                                                                      \
+        if (g_conv_stamps && threadIdx.x == 0) {                                              \
+            unsigned long long t__;                                                           \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");      \
+            g_conv_stamps[(size_t)blockIdx.x * 8 + (slot)] = t__;                             \
+        }                                                                                     \
+    } while (0)
+#else
+#define RSG_CSTAMP(slot) do {} while (0)
+#endif
+
 template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, const int block_y, char* smem) {
     constexpr int NTHR = 64 * WM * WN;
@@ -19,6 +35,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int n = lane & 31, hh = lane >> 5;
+    RSG_CSTAMP(1);
 
     int bx = block_x;
     const int tix = bx % p.tiles_x;
@@ -95,6 +112,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
                 if (lo[j] >= 0) *reinterpret_cast<uint4*>(smem + lo[j]) = r[j];
         }
         __syncthreads();
+        if (ch == 0) RSG_CSTAMP(2);
 
         // ---- MFMA over the taps of this channel block: one scheduling region per k-step (A loads NPF
         // steps ahead, LDS reads one step ahead), else the compiler sinks the loads next to their uses
@@ -124,6 +142,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         if (ch + 1 < p.nchunks) __syncthreads();
     }
 
+    RSG_CSTAMP(3);
     // ---- epilogue: (+ residual) (ReLU) -> 16-bit NHWC and/or fp32 NCHW; the branches are wave-uniform ----
     const bool relu = (p.relu >> (ct & 31)) & 1;
 #pragma unroll
@@ -167,5 +186,5 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
             }
         }
     }
+    RSG_CSTAMP(4);
 }
-

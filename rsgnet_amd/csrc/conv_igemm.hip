@@ -23,9 +23,18 @@ extern "C" const char* rsg_last_error(void) { return g_rsg_err; }
 extern "C" int rsg_version(void) { return 1; }
 
 
+#ifdef RSG_CONV_STAMPS
+extern "C" int rsg_conv_set_stamp_buffer_single(void* dev_ptr) {       // this translation unit's copy
+    unsigned long long* p = (unsigned long long*)dev_ptr;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &p, sizeof(p)) != hipSuccess) RSG_FAIL("stamps: memcpy failed");
+    return 0;
+}
+#endif
+
 template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    RSG_CSTAMP(0);
     conv_body<DT, CINB, TAPH, TAPW, WM, WN, NT>(p, blockIdx.x, blockIdx.y, smem);
 }
 

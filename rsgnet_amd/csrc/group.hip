@@ -37,13 +37,32 @@ static int variant_id(int cinb, int taps, int wm, int nt) {
 
 // The item table lives in device memory (built once per plan): indexing a by-value copy of it with the
 // runtime item id would spill the whole table to scratch.
+#ifdef RSG_CONV_STAMPS
+extern "C" int rsg_conv_set_stamp_buffer(void* dev_ptr) {
+    unsigned long long* p = (unsigned long long*)dev_ptr;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &p, sizeof(p)) != hipSuccess) RSG_FAIL("stamps: memcpy failed");
+    return 0;
+}
+#endif
+
 template <class DT>
 __global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs* __restrict__ gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    RSG_CSTAMP(0);
+#ifdef RSG_CONV_STAMPS
+    if (g_conv_stamps && threadIdx.x == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hwid));
+        g_conv_stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
     const GroupArgs& g = *gp;
     const int n = g.n_conv + g.n_fuse;
+    // which item?  Constant indices, so the whole first[] table comes in with one batch of scalar loads (a while
+    // loop made every step wait for its own load: 4-9 k cycles before the later items even started)
     int i = 0;
-    while (i + 1 < n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+#pragma unroll
+    for (int j = 1; j < RSG_GROUP_MAX_CONVS + RSG_GROUP_MAX_FUSES; ++j) i += (j < n && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
     const int local = blockIdx.x - g.first[i];
     if (i >= g.n_conv) {
         fuse_body<DT>(g.fuse[i - g.n_conv], local, g.first[i + 1] - g.first[i]);
