@@ -222,6 +222,28 @@ int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, in
 int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, int32_t batch,
                          int32_t S, int32_t C, int32_t dtype, void* stream);
 
+/* ---- training tail ------------------------------------------------------------
+ * Fused loss value + gradient kernels for the reference's training step (lib/core/function.py:246-305).
+ * All tensors fp32, contiguous, 16-byte aligned; loss: one device float, overwritten or (accumulate != 0)
+ * added to; grad may be NULL (value only).  workspace: rsg_loss_workspace_bytes(batch*joints) bytes. */
+size_t rsg_loss_workspace_bytes(int32_t rows);
+/* JointsMSELoss (lib/core/loss.py:14-38): loss = mean_j 0.5 * mean_{b,p} ((pred - gt) * w[b,j])^2 ; weight NULL =
+ * use_target_weight False; grad = grad_scale * dloss/dpred. */
+int rsg_joints_mse_loss(const float* pred, const float* gt, const float* weight, int32_t batch, int32_t joints,
+                        int32_t pixels, float grad_scale, float* loss, int32_t accumulate, float* grad,
+                        void* workspace, void* stream);
+/* loss_scale * torch.nn.BCELoss()(prob, target) (function.py:240,293 uses 0.01) and its gradient. */
+int rsg_bce_loss(const float* prob, const float* target, int64_t n, float loss_scale, float grad_scale, float* loss,
+                 int32_t accumulate, float* grad, void* workspace, void* stream);
+/* p[b, :] of the relation target p p^T (function.py:261-268): max over joints, bilinear x0.5, align_corners=True;
+ * feeds rsg_trp_relation_mse. target [batch,joints,h,w] -> out [batch,(h/2)*(w/2)]. */
+int rsg_relation_target_vec(const float* target, float* out, int32_t batch, int32_t joints, int32_t h, int32_t w,
+                            void* stream);
+/* torch.optim.Adam(lr) (lib/utils/utils.py:70-74): one step on flat fp32 buffers; step counts from 1;
+ * grad_scale folds the data-parallel 1/world average into the update. */
+int rsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,11 @@ SYMBOLS = {
     "rsg_trp_tail_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "rsg_trp_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rsg_trp_scores": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_loss_workspace_bytes": (C.c_size_t, [_i]),
+    "rsg_joints_mse_loss": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp, _vp, _vp]),
+    "rsg_bce_loss": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, _vp, _i, _vp, _vp, _vp]),
+    "rsg_relation_target_vec": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

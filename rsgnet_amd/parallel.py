@@ -1,0 +1,57 @@
+"""Data-parallel gradient exchange for the training step: one process per GPU,
+`torch.distributed` (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+The reference trains under nn.DataParallel: gradients are reduced onto GPU 0, Adam runs there and the 117 MB of
+parameters are re-broadcast on every forward (tools/cp_train.py:115).  Here every rank keeps a replica and its own
+Adam state; a step exchanges the flat gradient buffer of rsgnet_amd/optim.FusedAdam in a few large buckets.
+xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE link, so buckets
+are large (default 32 MB: 4 collectives for RSGNet-W32's 117 MB of fp32 gradients), launched on a side stream in
+reverse parameter order so the first ones overlap the rest of the backward, and the 1/world average is folded
+into the Adam kernel (`grad_scale`) instead of a pass over the buffer."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradReducer:
+    """All-reduces (sum) a flat gradient buffer in buckets.  `reduce()` returns after every bucket has been
+    enqueued and the current stream waits on them; the caller applies 1/world (e.g. FusedAdam.grad_scale)."""
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 32 << 20, group: Optional[dist.ProcessGroup] = None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group)
+        per = max(1, bucket_bytes // flat_grad.element_size())
+        n = flat_grad.numel()
+        # buckets from the END of the buffer: the last parameters get their gradients first in a backward pass
+        self.buckets: List[torch.Tensor] = []
+        hi = n
+        while hi > 0:
+            lo = max(0, hi - per)
+            self.buckets.append(flat_grad[lo:hi])
+            hi = lo
+        self._stream = torch.cuda.Stream(flat_grad.device) if flat_grad.is_cuda else None
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def reduce(self):
+        if self.world == 1:
+            return
+        if self._stream is None:                       # CPU tensors (gloo tests)
+            works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+            for w in works:
+                w.wait()
+            return
+        cur = torch.cuda.current_stream(self.flat.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            for b in self.buckets:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+        cur.wait_stream(self._stream)
