@@ -183,7 +183,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     const int cbase = wm * 32 + hh * 16;                 // this lane's 16 output channels
     int pixoff[NT];     // LDS byte address of the pixel (centre tap), + lane-half offset
     bool live[NT];      // pixel exists in this workgroup's tile
-    bool inside[NT];    // ... and lies inside the picture (else it must stay zero)
     const int npix = p.NI * R * W;
 #pragma unroll
     for (int g = 0; g < NT; ++g) {
@@ -193,7 +192,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         const int i = qq / (R * W), rem = qq - i * (R * W);
         const int r = rem / W, x = rem - r * W;
         const int y = y_first + r;
-        inside[g] = live[g] && y >= 0 && y < p.H && (b0 + i) < p.B;
         pixoff[g] = (i * slot_rows + r + 1) * RP + (x + 1) * PS + hh * 16;
     }
     __syncthreads();
@@ -316,37 +314,35 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             }
         }
 
-        // ---- bias (+ block input) + ReLU, zero outside the picture, pack to 16 bit --------------------
-        // (+ block input on odd layers) -> ReLU, zero outside the picture -> 16 bit.  Two VALU instructions
-        // per element plus packed converts: a wave-uniform branch for the residual (not a per-element
-        // select), v_med3_f32(v, 0, hi) = ReLU and mask in one (hi = 0 outside the picture), v_cvt_pk.
-        // The first version issued 8.5 instructions per element and cost as much as the k-loop.
+        // ---- (+ block input on odd layers) -> 16 bit -> ReLU.  One packed convert and one packed max per two
+        // elements (the residual add is a packed fp32 add); a wave-uniform branch for the residual instead of a
+        // per-element select.  No in-picture mask: every held row lies inside the picture (clamped window), and an
+        // image slot past the end of the batch only ever feeds itself.  The first version issued 8.5 instructions
+        // per element and cost as much as the k-loop.
         uint4 o[NT][2];
         if (l & 1) {
             if constexpr (NRE < NT) fetch_res(NRE, NT);
 #pragma unroll
             for (int g = 0; g < NT; ++g) {
-                const float hig = inside[g] ? 3.0e38f : 0.f;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, res[g][k]), f32x8);
                     f32x8 v;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(acc[g][k * 8 + e] + rf[e], 0.f, hig);
-                    o[g][k] = __builtin_bit_cast(uint4, __builtin_convertvector(v, typename DT::vec8));
+                    for (int e = 0; e < 8; ++e) v[e] = acc[g][k * 8 + e] + rf[e];
+                    o[g][k] = __builtin_bit_cast(uint4, DT::relu_pack(v));
                     if (l + 1 < p.nlayers) ws_store(g, k, o[g][k]);            // the next block's input
                 }
             }
         } else {
 #pragma unroll
             for (int g = 0; g < NT; ++g) {
-                const float hig = inside[g] ? 3.0e38f : 0.f;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     f32x8 v;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(acc[g][k * 8 + e], 0.f, hig);
-                    o[g][k] = __builtin_bit_cast(uint4, __builtin_convertvector(v, typename DT::vec8));
+                    for (int e = 0; e < 8; ++e) v[e] = acc[g][k * 8 + e];
+                    o[g][k] = __builtin_bit_cast(uint4, DT::relu_pack(v));
                 }
             }
         }

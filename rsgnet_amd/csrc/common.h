@@ -61,6 +61,12 @@ struct F16 {
     }
     static __device__ __host__ __forceinline__ float to_f32(elem v) { return (float)v; }
     static __device__ __host__ __forceinline__ elem from_f32(float v) { return (elem)v; }
+    // ReLU of 8 fp32 values as 16-bit: round first (v_cvt_pk_f16_f32), then v_pk_max_f16 with 0 -- one instruction
+    // per element for both, and max(round(x), 0) == round(max(x, 0))
+    static __device__ __forceinline__ vec8 relu_pack(f32x8 v) {
+        const vec8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        return __builtin_elementwise_max(__builtin_convertvector(v, vec8), z);
+    }
 };
 struct BF16 {
     typedef __bf16 elem;
@@ -70,6 +76,11 @@ struct BF16 {
     }
     static __device__ __host__ __forceinline__ float to_f32(elem v) { return (float)v; }
     static __device__ __host__ __forceinline__ elem from_f32(float v) { return (elem)v; }
+    static __device__ __forceinline__ vec8 relu_pack(f32x8 v) {      // no packed bf16 max on gfx950: ReLU in fp32
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        return __builtin_convertvector(v, vec8);
+    }
 };
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
