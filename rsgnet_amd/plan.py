@@ -674,6 +674,19 @@ class Plan:
             except Exception:
                 pass
 
+    def _bind_input(self, x: torch.Tensor):
+        """The first launch (layout conversion) reads the caller's fp32 NCHW tensor in place; it runs eagerly in
+        front of the captured graph, whose kernel arguments are frozen.  Anything else (other dtype, strides, the
+        explicit-DAG graph mode) goes through the static staging tensor as before."""
+        direct = x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and self.graph_mode != "dag" \
+            and x.device == self.x_static.device
+        if direct:
+            self._x_keep = x                   # alive until the next call
+            self._x_src = x.data_ptr()
+        else:
+            self.x_static.copy_(x)
+            self._x_src = self.x_static.data_ptr()
+
     def _replay(self):
         """RSGNET_HIP_GRAPH = 'capture' (default): stream capture of the single-stream launch order (the
         grouped launches already overlap independent work inside each grid); 'dag': explicit HIP graph with
@@ -688,10 +701,15 @@ class Plan:
                 self.launch_all()
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.launch_all()
+                first, self.ops = self.ops[0], self.ops[1:]               # the input conversion stays outside
+                try:
+                    with torch.cuda.graph(g):
+                        self.launch_all()
+                finally:
+                    self.ops = [first] + self.ops
                 self._lanes = lanes
                 self.graph = g
+            self.ops[0][1](torch.cuda.current_stream(self.device).cuda_stream)
             self.graph.replay()
             return
         if getattr(self, "_hipgraph", None) is None:
@@ -713,10 +731,10 @@ class _BackboneMixin:
         lib, B, dt = self.lib, self.batch, self.dtype
 
         def make():
-            src, dst = self.x_static.data_ptr(), x16.ptr()
+            dst = x16.ptr()
 
-            def launch(stream):
-                hip.check(lib.rsg_nchw_f32_to_nhwc16(src, dst, B, 3, H, W, 16, dt, stream), "nchw_to_nhwc16")
+            def launch(stream):       # reads the CALLER's tensor (self._x_src): no staging copy of the input
+                hip.check(lib.rsg_nchw_f32_to_nhwc16(self._x_src, dst, B, 3, H, W, 16, dt, stream), "nchw_to_nhwc16")
             return launch
 
         self.custom("input_to_nhwc16", [], [x16], make)
@@ -733,10 +751,10 @@ class _BackboneMixin:
         lib, B, dt = self.lib, self.batch, self.dtype
 
         def make():
-            src, dst = self.x_static.data_ptr(), xs.ptr()
+            dst = xs.ptr()
 
-            def launch(stream):
-                hip.check(lib.rsg_nchw_f32_to_s2d_nhwc16(src, dst, B, 3, H, W, dt, stream), "nchw_to_s2d")
+            def launch(stream):       # reads the CALLER's tensor (self._x_src): no staging copy of the input
+                hip.check(lib.rsg_nchw_f32_to_s2d_nhwc16(self._x_src, dst, B, 3, H, W, dt, stream), "nchw_to_s2d")
             return launch
 
         self.custom("input_to_s2d_nhwc16", [], [xs], make)
@@ -961,7 +979,7 @@ class HRNetPlan(Plan, _BackboneMixin):
         if x.shape != self.x_static.shape:
             raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_static.shape)} "
                              "(H, W must equal cfg.MODEL.IMAGE_SIZE)")
-        self.x_static.copy_(x)
+        self._bind_input(x)
         self._replay()
         return self.heat.clone() if clone else self.heat
 
@@ -978,7 +996,7 @@ class RSGNetPlan(Plan, _BackboneMixin):
     def run(self, x: torch.Tensor, clone: bool = True):
         if x.shape != self.x_static.shape:
             raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_static.shape)}")
-        self.x_static.copy_(x)
+        self._bind_input(x)
         self._replay()
         outs = (self.multi_up, self.kpt, self.limbs)
         return tuple(o.clone() for o in outs) if clone else outs
