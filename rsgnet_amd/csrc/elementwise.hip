@@ -50,13 +50,14 @@ extern "C" int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch,
 template <class DT>
 __global__ void __launch_bounds__(256) nchw_to_s2d16_kernel(const float* __restrict__ in, char* __restrict__ out,
                                                            int c, int h, int w, long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // one thread per output (half-res) pixel
+    // 32-bit index arithmetic throughout: a 64-bit division costs ~100 instructions on this hardware
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;       // one thread per output (half-res) pixel
     if (i >= total) return;
     const int w2 = w / 2, h2 = h / 2;
-    const int X = (int)(i % w2);
-    long t = i / w2;
-    const int Y = (int)(t % h2);
-    const long b = t / h2;
+    const unsigned t = i / (unsigned)w2;
+    const int X = (int)(i - t * w2);
+    const unsigned b = t / (unsigned)h2;
+    const int Y = (int)(t - b * h2);
     typename DT::elem v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = (typename DT::elem)0.f;
@@ -150,19 +151,21 @@ __global__ void __launch_bounds__(256) bilinear2x_kernel(const float* __restrict
     const int ow = 2 * w, oh = 2 * h;
     const float ry = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
     const float rx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-        const int ow4 = ow / 4;
-        const int x4 = (int)(i % ow4);
-        long t = i / ow4;
-        const int oy = (int)(t % oh);
-        const long pl = t / oh;
+    // 32-bit index arithmetic (total4 < 2^31 is checked on the host): two 64-bit divisions per thread made this
+    // kernel 3x slower than its 16-byte stores allow
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {
+        const unsigned ow4 = ow / 4;
+        const unsigned t = i / ow4;
+        const int x4 = (int)(i - t * ow4);
+        const unsigned pl = t / (unsigned)oh;
+        const int oy = (int)(t - pl * oh);
         const float sy = ry * oy;
         int y0 = (int)sy;
         if (y0 > h - 1) y0 = h - 1;
         const int y1 = y0 < h - 1 ? y0 + 1 : y0;
         const float wy = sy - (float)y0;
-        const float* r0 = in + (pl * h + y0) * w;
-        const float* r1 = in + (pl * h + y1) * w;
+        const float* r0 = in + ((size_t)pl * h + y0) * w;
+        const float* r1 = in + ((size_t)pl * h + y1) * w;
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -187,6 +190,7 @@ extern "C" int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t plan
                                        int32_t sigmoid, void* stream) {
     if (!in || !out || planes < 1 || h < 1 || w < 2 || (w % 2)) RSG_FAIL("bilinear2x: bad arguments");
     const long total4 = (long)planes * (2 * h) * (2 * w / 4);
+    if (total4 >= (1L << 31)) RSG_FAIL("bilinear2x: too many elements for 32-bit indexing");
     long blocks = (total4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     RSG_LAUNCH(bilinear2x_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, out, h, w,
@@ -209,15 +213,15 @@ struct FlipArgs {
 };
 
 __global__ void __launch_bounds__(256) flip_merge_kernel(const FlipArgs a) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += (long)gridDim.x * 256) {
-        const int x = (int)(i % a.W);
-        long t = i / a.W;
-        const int y = (int)(t % a.H);
-        t /= a.H;
-        const int j = (int)(t % a.J);
-        const long b = t / a.J;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)a.total; i += gridDim.x * 256u) {
+        unsigned t = i / (unsigned)a.W;
+        const int x = (int)(i - t * a.W);
+        unsigned u = t / (unsigned)a.H;
+        const int y = (int)(t - u * a.H);
+        const unsigned b = u / (unsigned)a.J;
+        const int j = (int)(u - b * a.J);
         const int xs = a.shift ? (x > 0 ? x - 1 : 0) : x;          // column of the un-shifted flipped-back map
-        const long src = ((b * a.J + a.perm[j]) * a.H + y) * a.W + (a.W - 1 - xs);
+        const size_t src = (((size_t)b * a.J + a.perm[j]) * a.H + y) * a.W + (a.W - 1 - xs);
         a.out[i] = 0.5f * (a.h[i] + a.hf[src]);
     }
 }
@@ -231,6 +235,7 @@ extern "C" int rsg_flip_merge_nchw_f32(const float* h, const float* h_flipped, c
     memset(&a, 0, sizeof(a));
     a.h = h; a.hf = h_flipped; a.out = out; a.J = joints; a.H = height; a.W = width; a.shift = shift_heatmap;
     a.total = (long)batch * joints * height * width;
+    if (a.total >= (1L << 31)) RSG_FAIL("flip_merge: too many elements for 32-bit indexing");
     for (int j = 0; j < joints; ++j) {
         if (perm_host[j] < 0 || perm_host[j] >= joints) RSG_FAIL("flip_merge: perm[%d]=%d", j, perm_host[j]);
         a.perm[j] = perm_host[j];

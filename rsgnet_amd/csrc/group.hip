@@ -20,11 +20,11 @@ struct GroupArgs {
     FuseArgs fuse[RSG_GROUP_MAX_FUSES];
 };
 
-// variant id = ((cinb_idx * 2 + taps_idx) * 5 + cfg_idx); cinb in {32,64}, taps in {1x1,3x3},
+// variant id = ((cinb_idx * 3 + taps_idx) * 5 + cfg_idx); cinb in {32,64}, taps in {1x1,3x3,2x2 (cinb 32 only)},
 // cfg in {(1,4,3),(1,4,1),(2,2,3),(2,2,1),(4,1,2)} = (WM,WN,NT)
 static int variant_id(int cinb, int taps, int wm, int nt) {
     const int ci = cinb == 32 ? 0 : (cinb == 64 ? 1 : -1);
-    const int ti = taps == 1 ? 0 : (taps == 9 ? 1 : -1);
+    const int ti = taps == 1 ? 0 : (taps == 9 ? 1 : (taps == 4 && cinb == 32 ? 2 : -1));
     int cf = -1;
     if (wm == 1 && nt == 3) cf = 0;
     else if (wm == 1 && nt == 1) cf = 1;
@@ -32,7 +32,7 @@ static int variant_id(int cinb, int taps, int wm, int nt) {
     else if (wm == 2 && nt == 1) cf = 3;
     else if (wm == 4 && nt == 2) cf = 4;
     if (ci < 0 || ti < 0 || cf < 0) return -1;
-    return (ci * 2 + ti) * 5 + cf;
+    return (ci * 3 + ti) * 5 + cf;
 }
 
 // The item table lives in device memory (built once per plan): indexing a by-value copy of it with the
@@ -82,8 +82,9 @@ __global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs* __r
     switch (g.variant[i]) {
         RSG_V5(0, 32, 1, 1)
         RSG_V5(5, 32, 3, 3)
-        RSG_V5(10, 64, 1, 1)
-        RSG_V5(15, 64, 3, 3)
+        RSG_V5(10, 32, 2, 2)
+        RSG_V5(15, 64, 1, 1)
+        RSG_V5(20, 64, 3, 3)
     }
 #undef RSG_V5
 #undef RSG_V

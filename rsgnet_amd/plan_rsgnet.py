@@ -148,9 +148,11 @@ def record_rsgnet(p: Plan, model) -> None:
     k = p._unit(cat2, model.kpt_net[0], model.kpt_net[1], relu=True, name="kpt_net")
     dc, dbn = model.predict_convtranspose[0], model.predict_convtranspose[1]
     k2 = p.new(2 * H4, 2 * W4, c0, name="deconv")       # the four phases store exactly c0 channels
+    p.begin_group()                                      # four independent sub-pixel convs: one launch
     for py, px, pad_y, pad_x, wph in deconv_phase_weights(dc.weight):
         p.conv(k, wph, dbn, None, relu=True, out=k2, pad=(pad_y, pad_x), up=(2, py, px),
                out_hw=(H4, W4), phys_hw=(2 * H4, 2 * W4), name=f"deconv.phase{py}{px}")
+    p.end_group("deconv")
     k3 = p._unit(k2, model.predict_net[0], model.predict_net[1], relu=True, name="predict_net")
     p.kpt = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
     fl = model.final_layer
