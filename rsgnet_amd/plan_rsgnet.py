@@ -154,25 +154,29 @@ def record_rsgnet(p: Plan, model) -> None:
                out_hw=(H4, W4), phys_hw=(2 * H4, 2 * W4), name=f"deconv.phase{py}{px}")
     p.end_group("deconv")
     k3 = p._unit(k2, model.predict_net[0], model.predict_net[1], relu=True, name="predict_net")
-    p.kpt = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
-    fl = model.final_layer
-    p.conv(k3, fl.weight, None, fl.bias, out_f32=p.kpt, want16=False, name="final_layer")
 
     # ---- limbs branch = SGM (:1003-1013)
+    p.kpt = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
     p.multi_up = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
     p.limbs = torch.zeros(B, L, 2 * H4, 2 * W4, **f32)
     p.limbs_lo = torch.zeros(B, L, H4, W4, **f32)
+    from .plan import OutSlot
+    p.kpt_slot, p.multi_slot, p.limbs_slot = OutSlot(p.kpt), OutSlot(p.multi_up), OutSlot(p.limbs)
 
-    def make_up(src, dst, planes, sig):
-        a = (src.data_ptr(), dst.data_ptr(), planes, H4, W4, sig)
-        return lambda: (lambda s: hip.check(lib.rsg_bilinear2x_nchw_f32(*a, s), "bilinear2x"))
+    def make_up(src, slot, planes, sig):
+        a = (src.data_ptr(), planes, H4, W4, sig)
+        return lambda: (lambda s: hip.check(lib.rsg_bilinear2x_nchw_f32(a[0], slot.ptr, *a[1:], s), "bilinear2x"))
 
     with p.on_lane(1):      # independent of TRP and the joints-of-target branch: its own stream
         lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net")
         p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
-        p.custom("bilinear2x+sigmoid(limbs)", [p.limbs_lo], [p.limbs], make_up(p.limbs_lo, p.limbs, B * L, 1))
-    with p.on_lane(2):
-        p.custom("bilinear2x(multi)", [p.multi_lo], [p.multi_up], make_up(p.multi_lo, p.multi_up, B * J, 0))
+    # the three ops that write the model's outputs come last: they run eagerly behind the captured graph and write
+    # straight into the tensors a forward hands out (Plan.n_tail, OutSlot)
+    fl = model.final_layer
+    p.conv(k3, fl.weight, None, fl.bias, out_f32=p.kpt_slot, want16=False, name="final_layer")
+    p.custom("bilinear2x+sigmoid(limbs)", [p.limbs_lo], [p.limbs], make_up(p.limbs_lo, p.limbs_slot, B * L, 1))
+    p.custom("bilinear2x(multi)", [p.multi_lo], [p.multi_up], make_up(p.multi_lo, p.multi_slot, B * J, 0))
+    p.n_tail = 3
 
     # the constant location clue: filled once, right after allocation, for every crop slot
     orig_finalize = p.finalize
