@@ -70,6 +70,12 @@ int rsg_conv_igemm(const rsg_conv_desc* d, void* stream);
 
 /* what the auto-tiler picked for a descriptor (for logging / tuning): fills 8 ints
  * {CINB, WM, WN, NT, TH, TW, lds_bytes, grid_x} */
+/* Bottleneck conv2 -> conv3 (pose_hrnet.py:93-101) in one launch: `inner` = the 3x3 stride-1 conv with 64 output
+ * channels (BatchNorm folded, ReLU; its out16 / residual / relu fields are ignored), then a 1x1 conv to tail_out_c
+ * channels (weights from rsg_pack_conv_weights_host with kh = kw = 1, cin = 64) + residual + optional ReLU.  The
+ * 64-channel intermediate stays in LDS. */
+int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias, int32_t tail_out_c,
+                  const void* residual, int32_t res_ld, void* out16, int32_t out_ld, int32_t relu, void* stream);
 int rsg_conv_plan(const rsg_conv_desc* d, int32_t* out8);
 
 int32_t rsg_conv_padded_cin(int32_t cin);              /* 3->16, 17->32, multiples of 16 kept ... */

@@ -18,6 +18,11 @@ struct ConvArgs {
     int TH, TW, TIH, TIW, RP;
     int tiles_x, tiles_y;
     int nchunks, KS;
+    // fused 1x1 tail (conv_body<..., TAIL=true>, rsg_conv_pair): the conv above is an inner stage whose ReLU'd
+    // 64-channel result stays in LDS; out/res/ldo/ldr/relu/Cout/CoutStore describe the TAIL's output
+    const uint4* wpk2;
+    const float* bias2;
+    int C2;          // output channels of the tail (multiple of 32)
 };
 
 struct TilePlan {

@@ -19,7 +19,7 @@ static __device__ unsigned long long* g_conv_stamps = nullptr;      // [blocks][
 #define RSG_CSTAMP(slot) do {} while (0)
 #endif
 
-template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT>
+template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, const int block_y, char* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KPT = CINB / 16;       // k-steps per filter tap
@@ -143,6 +143,86 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
     }
 
     RSG_CSTAMP(3);
+    if constexpr (TAIL) {
+        // ---- fused 1x1 tail (Bottleneck conv2 -> conv3, pose_hrnet.py:93-101): h = ReLU(acc) goes to LDS as 16-bit
+        // [tile pixel][32*WM + 8 pad] -- every channel of a pixel comes from this workgroup (grid.y == 1) -- and is the
+        // B operand of a second GEMM with the tail's weights; the 64-channel map never goes to HBM.
+        constexpr int C1 = 32 * WM, PS2 = 2 * C1 + 16, KS2 = C1 / 16, NP2 = WN * NT;
+        __syncthreads();                                 // every wave has finished reading the staged input
+#pragma unroll
+        for (int g = 0; g < NT; ++g) {
+            const int q = (wn * NT + g) * 32 + n;
+            if (q < p.TH * p.TW) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f32x8 f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = acc[g][k * 8 + e];
+                    *reinterpret_cast<uint4*>(smem + q * PS2 + (wm * 32 + hh * 16 + k * 8) * 2) =
+                        __builtin_bit_cast(uint4, DT::relu_pack(f));
+                }
+            }
+        }
+        __syncthreads();
+        const int ntile2 = p.C2 / 32;
+        for (int ct2 = wave; ct2 < ntile2; ct2 += WM * WN) {
+            const int cb2 = ct2 * 32 + hh * 16;
+            uint4 a2[KS2];
+#pragma unroll
+            for (int k = 0; k < KS2; ++k) a2[k] = p.wpk2[((size_t)ct2 * KS2 + k) * 64 + lane];
+            f32x16 acc2[NP2];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias2 + cb2 + r4 * 4);
+#pragma unroll
+                for (int j = 0; j < NP2; ++j) {
+                    acc2[j][r4 * 4 + 0] = bv.x; acc2[j][r4 * 4 + 1] = bv.y;
+                    acc2[j][r4 * 4 + 2] = bv.z; acc2[j][r4 * 4 + 3] = bv.w;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KS2; ++k) {
+                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, a2[k]);
+#pragma unroll
+                for (int j = 0; j < NP2; ++j) {
+                    const int q = j * 32 + n;
+                    const uint4 bv = *reinterpret_cast<const uint4*>(smem + (q < p.TH * p.TW ? q : 0) * PS2 + k * 32 + hh * 16);
+                    acc2[j] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc2[j]);
+                }
+            }
+            const bool relu2 = (p.relu >> (ct2 & 31)) & 1;
+#pragma unroll
+            for (int j = 0; j < NP2; ++j) {
+                const int q = j * 32 + n;
+                const int py = q / p.TW, px = q - py * p.TW;
+                if (q >= p.TH * p.TW || y0 + py >= p.Hout || x0 + px >= p.Wout) continue;
+                const size_t op = (size_t)(b * p.Hout + y0 + py) * p.Wout + x0 + px;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc2[j][r];
+                if (p.res) {
+                    const char* rp = p.res + (op * p.ldr + cb2) * 2;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const uint4 rv = *reinterpret_cast<const uint4*>(rp + k * 16);
+                        const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv), f32x8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[k * 8 + e] += rf[e];
+                    }
+                }
+                char* dst = p.out + (op * p.ldo + cb2) * 2;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f32x8 f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = relu2 ? fmaxf(v[k * 8 + e], 0.f) : v[k * 8 + e];
+                    *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+                }
+            }
+        }
+        RSG_CSTAMP(4);
+        return;
+    }
     // ---- epilogue: (+ residual) (ReLU) -> 16-bit NHWC and/or fp32 NCHW; the branches are wave-uniform ----
     const bool relu = (p.relu >> (ct & 31)) & 1;
 #pragma unroll

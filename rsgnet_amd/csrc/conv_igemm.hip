@@ -198,7 +198,64 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     a.tiles_x = t.tiles_x; a.tiles_y = t.tiles_y;
     a.nchunks = d->in_c / t.CINB;
     a.KS = a.nchunks * d->kh * d->kw * (t.CINB / 16);
+    a.wpk2 = nullptr; a.bias2 = nullptr; a.C2 = 0;
     grid = dim3(d->batch * t.tiles_y * t.tiles_x, cout_pad / (32 * t.WM));
+    return 0;
+}
+
+template <class DT>
+__global__ void __launch_bounds__(256) conv_pair_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_body<DT, 64, 3, 3, 2, 2, 3, true>(p, blockIdx.x, 0, smem);
+}
+
+// 3x3 stride-1 conv (C1 = 64 outputs, BatchNorm folded, ReLU) followed by a 1x1 conv (+BN, +residual, ReLU) in one
+// launch: `inner` describes the 3x3 conv (its out16/residual are ignored), the other arguments the 1x1 tail.
+extern "C" int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias,
+                             int32_t tail_out_c, const void* residual, int32_t res_ld, void* out16, int32_t out_ld,
+                             int32_t relu, void* stream) {
+    if (!inner || !tail_w_packed || !tail_bias || !out16) RSG_FAIL("conv_pair: null pointer");
+    if (inner->kh != 3 || inner->kw != 3 || inner->stride != 1 || inner->out_c != 64 || inner->in_c % 64 ||
+        inner->up != 1 || inner->out_nchw_f32)
+        RSG_FAIL("conv_pair: the inner conv must be 3x3 stride 1 with 64 output channels and cin a multiple of 64");
+    if (tail_out_c < 32 || tail_out_c % 32 || out_ld < tail_out_c || out_ld % 8 || (residual && (res_ld < tail_out_c || res_ld % 8)))
+        RSG_FAIL("conv_pair: tail_out_c=%d out_ld=%d res_ld=%d", tail_out_c, out_ld, res_ld);
+    if (((uintptr_t)tail_w_packed | (uintptr_t)tail_bias | (uintptr_t)residual | (uintptr_t)out16) & 15)
+        RSG_FAIL("conv_pair: pointers must be 16-byte aligned");
+    rsg_conv_desc d = *inner;
+    d.out16 = out16;                   // placeholders for the shared validation; the tail's values are set below
+    d.out_ld = 64; d.residual = nullptr; d.relu = 1; d.relu_tile_mask = 0; d.out_c_store = 0;
+    // all 64 inner channels of a pixel in one workgroup: 2 x 2 waves, 3 pixel groups each
+    int best_h = 0, best_w = 0;
+    {
+        double best = -1;
+        static const int tws[] = {96, 64, 48, 32, 24, 16, 12, 8};
+        for (int tw : tws) {
+            if (tw > d.out_w) tw = d.out_w;
+            int th = 192 / tw;
+            if (th > d.out_h) th = d.out_h;
+            if (th < 1) continue;
+            const int tih = th + 2, tiw = tw + 2;
+            const int rp = tiw * 144 + ((((tw * 144) % 256) - (tiw * 144)) % 256 + 256) % 256;
+            if (tih * rp > g_conv_lds_limit) continue;
+            const double use = (double)d.out_h * d.out_w / ((double)ceil_div(d.out_h, th) * ceil_div(d.out_w, tw) * 192);
+            if (use > best) { best = use; best_h = th; best_w = tw; }
+        }
+        if (!best_h) RSG_FAIL("conv_pair: no tile fits");
+    }
+    d.tile_hint = 2 | (3 << 4) | (best_h << 8) | (best_w << 16);
+    ConvArgs a;
+    TilePlan t;
+    dim3 grid;
+    if (rsg_conv_prepare(&d, a, t, grid)) return 1;
+    if (grid.y != 1 || t.CINB != 64) RSG_FAIL("conv_pair: unexpected tiling");
+    a.out = (char*)out16; a.ldo = out_ld; a.res = (const char*)residual; a.ldr = res_ld;
+    a.relu = relu ? -1 : 0; a.Cout = tail_out_c; a.CoutStore = tail_out_c;
+    a.wpk2 = (const uint4*)tail_w_packed; a.bias2 = tail_bias; a.C2 = tail_out_c;
+    if (t.lds < t.TH * t.TW * 144) t.lds = t.TH * t.TW * 144;
+    if (inner->dtype == RSG_BF16) RSG_LAUNCH(conv_pair_kernel<BF16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+    else RSG_LAUNCH(conv_pair_kernel<F16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH("conv_pair");
     return 0;
 }
 

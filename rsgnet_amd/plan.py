@@ -269,6 +269,21 @@ class Plan:
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
 
+    def conv_pair(self, x: VT, conv_a, bn_a, conv_b, bn_b, residual: Optional[VT], name="") -> VT:
+        """Record Bottleneck conv2 (3x3, 64 outputs, BN, ReLU) + conv3 (1x1, BN, + residual, ReLU) as ONE launch
+        (rsg_conv_pair): the 64-channel map between them stays in LDS."""
+        sa, ha = self.bn_fold(bn_a)
+        wpa, boa, Ia, Oa = self.pack_conv(conv_a.weight, sa, ha, conv_a.bias)
+        sb, hb = self.bn_fold(bn_b)
+        wpb, bob, Ib, Ob = self.pack_conv(conv_b.weight, sb, hb, conv_b.bias)
+        out = self.new(x.H, x.W, _round_up(Ob, 32), name=name)
+        self._record(dict(kind="conv_pair", x=x, wp=wpa, bias=boa, wp2=wpb, bias2=bob, res=residual, out=out,
+                          out_f32=None, I=self.lib.rsg_conv_padded_cin(Ia), O=Oa, O2=Ob, kh=3, kw=3, stride=1, pad=(1, 1),
+                          up=(1, 0, 0), out_hw=(x.H, x.W), phys_hw=(x.H, x.W), relu=True, name=name),
+                     [x, residual], [out])
+        self.flops += 2 * self.batch * x.H * x.W * (Oa * Ia * 9 + Ob * Ib)
+        return out
+
     def conv_multi(self, x: VT, parts, name="") -> List[VT]:
         """Several convs that read the SAME input with the same geometry as ONE conv with concatenated output
         channels (fan-out fusion): parts = [(conv, bn, relu)], every cout a multiple of 32.  Returns one
@@ -491,6 +506,27 @@ class Plan:
                 hip.check(rc, nm)
 
         self.ops.append((r["name"], launch))
+
+    def _lower_conv_pair(self, r):
+        rr = dict(r)
+        rr["out"] = None                      # the inner descriptor carries no output of its own
+        rr["res"] = None
+        d = self._conv_desc(rr, fake_ptrs=False)
+        d.out16 = r["out"].ptr()              # placeholder (validated, then replaced by the tail's output)
+        d.out_ld = 64
+        self._keep.append(d)
+        out, res = r["out"], r["res"]
+        args = (C.byref(d), r["wp2"].data_ptr(), r["bias2"].data_ptr(), r["O2"], res.ptr() if res is not None else None,
+                res.ld if res is not None else 0, out.ptr(), out.ld, 1)
+        fn, nm = self.lib.rsg_conv_pair, r["name"]
+        self.conv_log.append(dict(name=nm, cin=r["I"], cout=r["O2"], k=3, s=1, hw=r["out_hw"], pair=True))
+
+        def launch(stream):
+            rc = fn(*args, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((nm, launch))
 
     def _fuse_item(self, r) -> "hip.FuseItem":
         same, low, out = r["same"], r["low"], r["out"]
@@ -815,6 +851,11 @@ class _BackboneMixin:
             res = self._unit(x, blk.downsample[0], blk.downsample[1], name=name + ".downsample")
         y = self._unit(x, blk.conv1, blk.bn1, relu=True, name=name + ".conv1")
         if hasattr(blk, "conv3"):
+            c2, c3 = blk.conv2, blk.conv3
+            if os.environ.get("RSGNET_HIP_PAIR", "1") != "0" and c2.kernel_size == (3, 3) and c2.stride == (1, 1) and \
+                    c2.out_channels == 64 and c2.in_channels % 64 == 0 and c3.kernel_size == (1, 1) and \
+                    c3.out_channels % 32 == 0 and y.C == c2.in_channels:
+                return self.conv_pair(y, c2, blk.bn2, c3, blk.bn3, res, name=name + ".conv2+conv3")
             y = self._unit(y, blk.conv2, blk.bn2, relu=True, name=name + ".conv2")
             return self._unit(y, blk.conv3, blk.bn3, relu=True, residual=res, name=name + ".conv3")
         return self._unit(y, blk.conv2, blk.bn2, relu=True, residual=res, name=name + ".conv2")

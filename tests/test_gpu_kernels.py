@@ -387,3 +387,48 @@ def test_chain_group_handoff_inside_one_launch():
     # the consumer must come after its producer
     items[1], items[2] = items[2], items[1]
     assert lib.rsg_basic_chain_group(items, 3, 0, _stream()) != 0
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 48, 256), (3, 13, 9, 128), (1, 64, 48, 64)], ids=str)
+def test_conv_pair_equals_two_convs(shape):
+    """rsg_conv_pair (Bottleneck conv2 3x3 -> conv3 1x1 + residual + ReLU in one launch, the 64-channel map in LDS)
+    gives bit for bit what the two rsg_conv_igemm launches give."""
+    B, H, W, C2 = shape
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(H * W + C2)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w1 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    s1, h1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(C2, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    s2, h2 = torch.rand(C2, generator=g) * 0.4 + 0.1, torch.randn(C2, generator=g) * 0.1
+    res = torch.randn(B, C2, H, W, generator=g)
+    mid, _ = run_conv(x, w1, s1, h1, relu=True)
+    want, _ = run_conv(mid, w2, s2, h2, relu=True, residual=res)
+
+    def pack(w, s, h):
+        O, I, kh, kw = w.shape
+        wp = np.zeros(lib.rsg_conv_packed_bytes(I, O, kh, kw), np.uint8)
+        bo = np.zeros(O, np.float32)
+        hip.check(lib.rsg_pack_conv_weights_host(np.ascontiguousarray(w.numpy()).ctypes.data, s.numpy().ctypes.data,
+                                                 h.numpy().ctypes.data, None, I, O, kh, kw, 0, wp.ctypes.data, bo.ctypes.data))
+        return torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+
+    wp1, b1 = pack(w1, s1, h1)
+    wp2, b2 = pack(w2, s2, h2)
+    xin = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    rin = res.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    out = torch.full((B, H, W, C2), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.ConvDesc()
+    d.inp, d.w_packed, d.bias = xin.data_ptr(), wp1.data_ptr(), b1.data_ptr()
+    d.out16 = out.data_ptr()
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, H, W, 64, 64
+    d.out_h, d.out_w, d.out_c, d.out_ld = H, W, 64, 64
+    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = 3, 3, 1, 1, 1
+    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, H, W
+    d.relu, d.dtype = 1, 0
+    hip.check(lib.rsg_conv_pair(C.byref(d), wp2.data_ptr(), b2.data_ptr(), C2, rin.data_ptr(), C2, out.data_ptr(), C2, 1,
+                                _stream()), "conv_pair")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want[:, :C2])
