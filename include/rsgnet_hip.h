@@ -138,6 +138,9 @@ typedef struct rsg_chain_item {
     const void* wait_flags;        /* NULL, or the done_flags of an earlier item */
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
+/* Number of hand-off polls that gave up since the library was loaded (synchronises the device).  Non-zero means a
+ * consumer chain started without its producer's data: a bug or a dispatch order this design does not expect. */
+int rsg_chain_handoff_timeouts(uint32_t* count);
 
 /* ---- layout / elementwise -------------------------------------------------------------------- */
 /* x.float NCHW -> NHWC 16-bit with channels zero-padded to c_pad (input of the stem conv,

@@ -40,6 +40,10 @@ __device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][8 waves][
 #define RSG_STAMP(slot) do {} while (0)
 #endif
 
+// polls that gave up (a producer tile never signalled): the results of that launch are then wrong, and a host that
+// cares can find out (rsg_chain_handoff_timeouts); never seen in practice, workgroups are dispatched in index order
+__device__ unsigned g_chain_handoff_timeouts = 0;
+
 struct ChainArgs {
     const char* in;
     char* out;
@@ -133,8 +137,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         if (tid <= t_hi - t_lo) {
             const int tp = t_lo + tid;                                  // producer tile
             int* f = const_cast<int*>(p.wait) + (((block_id / p.tiles_y) * p.tiles_y + tp) * 3 + (tile - tp + 1));
-            for (int spin = 0; spin < (1 << 20) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+            int spin = 0;
+            for (; spin < (1 << 20) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
                 __builtin_amdgcn_s_sleep(8);
+            if (spin == (1 << 20)) atomicAdd(&g_chain_handoff_timeouts, 1u);     // read back by rsg_chain_handoff_timeouts
             __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
@@ -518,6 +524,15 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
         return 0;
     }
     return 1;
+}
+
+extern "C" int rsg_chain_handoff_timeouts(uint32_t* count) {
+    if (!count) RSG_FAIL("chain_handoff_timeouts: null pointer");
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_chain_handoff_timeouts), sizeof(v)) != hipSuccess)
+        RSG_FAIL("chain_handoff_timeouts: hipMemcpyFromSymbol failed");
+    *count = v;
+    return 0;
 }
 
 extern "C" int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,

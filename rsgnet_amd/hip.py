@@ -66,6 +66,7 @@ SYMBOLS = {
     "rsg_basic_chain": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rsg_basic_chain_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rsg_basic_chain_group": (C.c_int, [C.POINTER(ChainItem), _i, _i, _vp]),
+    "rsg_chain_handoff_timeouts": (C.c_int, [C.POINTER(C.c_uint32)]),
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_conv_groupable": (C.c_int, [C.POINTER(ConvDesc)]),
     "rsg_group_table_bytes": (C.c_size_t, []),

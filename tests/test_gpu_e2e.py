@@ -213,3 +213,8 @@ def test_forward_is_deterministic():
             if first is None:
                 first = y
             assert torch.equal(y, first), rep
+    import ctypes
+    from rsgnet_amd import hip
+    n = ctypes.c_uint32(99)
+    hip.check(hip.lib().rsg_chain_handoff_timeouts(ctypes.byref(n)))
+    assert n.value == 0           # no consumer chain ever gave up waiting for its producer
