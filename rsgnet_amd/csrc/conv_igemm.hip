@@ -68,11 +68,16 @@ static void tile_geometry(const rsg_conv_desc* d, TilePlan& t) {
     t.tiles_x = ceil_div(d->out_w, t.TW);
 }
 
+int g_conv_full_k = 1;                 // rsg_tune("conv_full_k", 0|1)
 int g_conv_lds_limit = 52 * 1024;      // rsg_tune("conv_lds_limit", bytes): LDS cap of the tile chooser
 #define LDS_LIMIT g_conv_lds_limit
 
 static int choose_tile(const rsg_conv_desc* d, TilePlan& best) {
-    const int cinb = pick_cinb(d->in_c);
+    int cinb = pick_cinb(d->in_c);
+    // 1x1 convs over 256 channels on the large maps (Bottleneck conv1, 100 MB of input at batch 64): the whole K of a
+    // 64-pixel tile in ONE staging round (34 KB, 4 workgroups per CU) instead of four 64-channel rounds in sequence:
+    // 128 KB in flight per CU instead of 74 KB, which is what an HBM-bound kernel lives on
+    if (g_conv_full_k && d->kh == 1 && d->kw == 1 && d->in_c == 256 && d->out_h * d->out_w >= 1024) cinb = 256;
     if (!cinb) RSG_FAIL("conv: in_c=%d is not a multiple of 16 (pad with rsg_conv_padded_cin)", d->in_c);
     const int cout_pad = round_up(d->out_c, 32);
     if (d->tile_hint) {
@@ -155,6 +160,7 @@ static conv_fn lookup(int cinb, int taps, int wm, int nt) {
     RSG_CFGS(16, 1, 1)
     RSG_CFGS(32, 1, 1)
     RSG_CFGS(64, 1, 1)
+    RSG_CFGS(256, 1, 1)
     RSG_CFGS(16, 2, 2)
     RSG_CFGS(32, 2, 2)
 #undef RSG_CFGS
