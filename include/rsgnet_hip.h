@@ -70,6 +70,13 @@ int rsg_conv_igemm(const rsg_conv_desc* d, void* stream);
 
 /* what the auto-tiler picked for a descriptor (for logging / tuning): fills 8 ints
  * {CINB, WM, WN, NT, TH, TW, lds_bytes, grid_x} */
+/* HRNet stem in one launch (pose_hrnet.py:285-291,429-434): conv1 3x3 s2 3->64 (+BN, ReLU) as a 2x2 conv over the
+ * space-to-depth input xs = rsg_nchw_f32_to_s2d_nhwc16(x) (or xs = NULL and x_nchw_f32 = the fp32 NCHW picture: the
+ * conversion then happens while staging), then conv2 3x3 s2 64->64 (+BN, ReLU); the half-resolution
+ * 64-channel map between them stays in LDS.  w1: packed 2x2 weights (cin 16, cout 64), w2: packed 3x3 (cin 64, cout 64);
+ * out16: [batch, h/4, w/4, out_ld] 16-bit NHWC, 64 channels written; h, w = input picture size (multiples of 4). */
+int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
+                   void* out16, int32_t out_ld, int32_t batch, int32_t h, int32_t w, int32_t dtype, void* stream);
 /* Bottleneck conv2 -> conv3 (pose_hrnet.py:93-101) in one launch: `inner` = the 3x3 stride-1 conv with 64 output
  * channels (BatchNorm folded, ReLU; its out16 / residual / relu fields are ignored), then a 1x1 conv to tail_out_c
  * channels (weights from rsg_pack_conv_weights_host with kh = kw = 1, cin = 64) + residual + optional ReLU.  The

@@ -1,0 +1,223 @@
+// Fused HRNet stem for gfx950 (MI355X):  conv1 (3x3 s2, 3 -> 64) + BN + ReLU -> conv2 (3x3 s2, 64 -> 64) + BN + ReLU
+// (pose_hrnet.py:285-291,429-434; pose_rsgnet.py:612-618) in ONE launch.  As two launches the 64-channel half-resolution
+// map between them (100 MB at batch 64) is written and read back: 78 us for 0.27 GFLOP/img.
+//
+// conv1 runs as a 2x2 stride-1 conv over the space-to-depth input (rsg_nchw_f32_to_s2d_nhwc16: 16 channels per
+// half-resolution pixel, 12 used; weights rearranged by the caller exactly as for the unfused path).  A workgroup owns a
+// TH2 x TW2 tile of conv2's output: it stages the (2*TH2+2) x (2*TW2+2) window of the s2d input, computes conv1 on the
+// (2*TH2+1) x (2*TW2+1) positions conv2 needs into LDS (16-bit, zero where conv2's padding lies), then conv2 from there.
+// conv1 positions on tile borders are recomputed by the neighbour (9/8 x 25/24 of the conv1 work, 1 % of the stem).
+#include "common.h"
+
+struct StemArgs {
+    const char* xs;            // s2d input NHWC16 [B, H1, W1, 16], or null:
+    const float* x32;          // the picture itself, fp32 NCHW [B, 3, 2*H1, 2*W1] (space-to-depth done while staging)
+    const uint4* w1;           // conv1 as 2x2 conv, packed (CINB 16: KS = 4), 64 outputs
+    const float* b1;
+    const uint4* w2;           // conv2 3x3, packed (CINB 64: KS = 36), 64 outputs
+    const float* b2;
+    char* out;                 // NHWC16 [B, H2, W2, ldo] (+ channel offset folded into the pointer)
+    int B, H1, W1, H2, W2, ldo;
+    int tiles_x, tiles_y;
+};
+
+template <class DT, int TH2, int TW2>
+__global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
+    constexpr int R1 = 2 * TH2 + 1, C1 = 2 * TW2 + 1;      // conv1 positions held
+    constexpr int RS = R1 + 1, CS = C1 + 1;                // s2d pixels staged
+    constexpr int PSS = 48;                                // s2d pixel: 16 ch * 2 B + 16 pad
+    constexpr int PS1 = 144;                               // conv1 pixel: 64 ch * 2 B + 16 pad
+    constexpr int RPS = CS * PSS, RP1 = C1 * PS1;
+    constexpr int NP1 = (R1 * C1 + 31) / 32;               // 32-pixel groups of the conv1 window
+    constexpr int NT1 = (NP1 + 1) / 2;                     // per wave column (WN = 2)
+    constexpr int NP2 = (TH2 * TW2 + 31) / 32, NT2 = (NP2 + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sS = smem;                                 // s2d window
+    char* const sH = smem + RS * RPS;                      // conv1 window
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;               // 2 output-channel tiles x 2 pixel columns
+    const int n = lane & 31, hh = lane >> 5;
+    int bx = blockIdx.x;
+    const int tix = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int tiy = bx % p.tiles_y;
+    const int b = bx / p.tiles_y;
+    const int y2 = tiy * TH2, x2 = tix * TW2;              // first conv2 output of the tile
+    const int y1 = 2 * y2 - 1, x1 = 2 * x2 - 1;            // first conv1 position held (may be -1: conv2's padding)
+    const int ys = y1 - 1, xs0 = x1 - 1;                   // first s2d pixel staged (conv1's own padding at -1)
+
+    // ---- stage the s2d window: 2 chunks of 16 B per pixel ------------------------------------------------------------
+    if (p.x32) {
+        // straight from the fp32 NCHW picture: s2d pixel (Y, X) = in[:, 2Y..2Y+1, 2X..2X+1], channel (py*2+px)*3 + k
+        const int H0 = 2 * p.H1, W0 = 2 * p.W1;
+        for (int pix = tid; pix < RS * CS; pix += 256) {
+            const int r = pix / CS, c = pix - r * CS;
+            const int y = ys + r, x = xs0 + c;
+            typename DT::elem v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = (typename DT::elem)0.f;
+            if (y >= 0 && y < p.H1 && x >= 0 && x < p.W1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float* pl = p.x32 + (((size_t)b * 3 + k) * H0 + 2 * y) * W0 + 2 * x;
+                    const float2 r0 = *reinterpret_cast<const float2*>(pl);
+                    const float2 r1 = *reinterpret_cast<const float2*>(pl + W0);
+                    v[0 * 3 + k] = (typename DT::elem)r0.x;
+                    v[1 * 3 + k] = (typename DT::elem)r0.y;
+                    v[2 * 3 + k] = (typename DT::elem)r1.x;
+                    v[3 * 3 + k] = (typename DT::elem)r1.y;
+                }
+            }
+            uint4 o[2];
+            __builtin_memcpy(o, v, 32);
+            *reinterpret_cast<uint4*>(sS + r * RPS + c * PSS) = o[0];
+            *reinterpret_cast<uint4*>(sS + r * RPS + c * PSS + 16) = o[1];
+        }
+    } else {
+        for (int id = tid; id < RS * CS * 2; id += 256) {
+            const int pix = id >> 1, cg = id & 1;
+            const int r = pix / CS, c = pix - r * CS;
+            const int y = ys + r, x = xs0 + c;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (y >= 0 && y < p.H1 && x >= 0 && x < p.W1)
+                v = *reinterpret_cast<const uint4*>(p.xs + ((((size_t)b * p.H1 + y) * p.W1 + x) * 16 + cg * 8) * 2);
+            *reinterpret_cast<uint4*>(sS + r * RPS + c * PSS + cg * 16) = v;
+        }
+    }
+    const int cbase = wm * 32 + hh * 16;
+    float4 bv1[4], bv2[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        bv1[r4] = *reinterpret_cast<const float4*>(p.b1 + cbase + r4 * 4);
+        bv2[r4] = *reinterpret_cast<const float4*>(p.b2 + cbase + r4 * 4);
+    }
+    uint4 a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a1[k] = p.w1[((size_t)wm * 4 + k) * 64 + lane];
+    __syncthreads();
+
+    // ---- conv1 on the R1 x C1 window: tap (a, b) of the 2x2 conv reads s2d pixel (r + a, c + b) --------------------------
+    {
+        f32x16 acc[NT1];
+        int so[NT1];
+#pragma unroll
+        for (int g = 0; g < NT1; ++g) {
+            const int q = (wn * NT1 + g) * 32 + n;
+            const int qq = q < R1 * C1 ? q : 0;
+            const int r = qq / C1, c = qq - r * C1;
+            so[g] = r * RPS + c * PSS + hh * 16;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                acc[g][r4 * 4 + 0] = bv1[r4].x; acc[g][r4 * 4 + 1] = bv1[r4].y;
+                acc[g][r4 * 4 + 2] = bv1[r4].z; acc[g][r4 * 4 + 3] = bv1[r4].w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, a1[k]);
+#pragma unroll
+            for (int g = 0; g < NT1; ++g) {
+                const uint4 bq = *reinterpret_cast<const uint4*>(sS + so[g] + (k >> 1) * RPS + (k & 1) * PSS);
+                acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq), acc[g]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NT1; ++g) {
+            const int q = (wn * NT1 + g) * 32 + n;
+            if (q >= R1 * C1) continue;
+            const int r = q / C1, c = q - r * C1;
+            const bool real = (y1 + r) >= 0 && (y1 + r) < p.H1 && (x1 + c) >= 0 && (x1 + c) < p.W1;   // else conv2's zero padding
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = real ? acc[g][k * 8 + e] : 0.f;
+                *reinterpret_cast<uint4*>(sH + r * RP1 + c * PS1 + (cbase + k * 8) * 2) = __builtin_bit_cast(uint4, DT::relu_pack(f));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 (3x3 stride 2) from the conv1 window: output (py, px) reads window pixels (2py + ky, 2px + kx) -----------
+    f32x16 acc2[NT2];
+    int ho[NT2];
+#pragma unroll
+    for (int g = 0; g < NT2; ++g) {
+        const int q = (wn * NT2 + g) * 32 + n;
+        const int qq = q < TH2 * TW2 ? q : 0;
+        const int py = qq / TW2, px = qq - py * TW2;
+        ho[g] = (2 * py) * RP1 + (2 * px) * PS1 + hh * 16;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            acc2[g][r4 * 4 + 0] = bv2[r4].x; acc2[g][r4 * 4 + 1] = bv2[r4].y;
+            acc2[g][r4 * 4 + 2] = bv2[r4].z; acc2[g][r4 * 4 + 3] = bv2[r4].w;
+        }
+    }
+    constexpr int NPF = 6;
+    const uint4* ap = p.w2 + (size_t)wm * 36 * 64 + lane;
+    uint4 aq[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
+    // B fragments NB - 1 k-steps ahead: one MFMA per step cannot cover an LDS read issued one step earlier
+    constexpr int NB = 4;
+    auto hoff = [&](int ks) { const int t = ks >> 2, c = ks & 3; return (t / 3) * RP1 + (t % 3) * PS1 + c * 32; };
+    uint4 bq[NB][NT2];
+#pragma unroll
+    for (int s0 = 0; s0 < NB - 1; ++s0)
+#pragma unroll
+        for (int g = 0; g < NT2; ++g) bq[s0][g] = *reinterpret_cast<const uint4*>(sH + ho[g] + hoff(s0));
+#pragma unroll
+    for (int ks = 0; ks < 36; ++ks) {
+        const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+        if (ks + NB - 1 < 36) {
+#pragma unroll
+            for (int g = 0; g < NT2; ++g)
+                bq[(ks + NB - 1) % NB][g] = *reinterpret_cast<const uint4*>(sH + ho[g] + hoff(ks + NB - 1));
+        }
+        if (ks + NPF < 36) aq[ks % NPF] = ap[(ks + NPF) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NT2; ++g) acc2[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks % NB][g]), acc2[g]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < NT2; ++g) {
+        const int q = (wn * NT2 + g) * 32 + n;
+        const int py = q / TW2, px = q - py * TW2;
+        if (q >= TH2 * TW2 || y2 + py >= p.H2 || x2 + px >= p.W2) continue;
+        char* dst = p.out + ((((size_t)b * p.H2 + y2 + py) * p.W2 + x2 + px) * p.ldo + cbase) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = acc2[g][k * 8 + e];
+            *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, DT::relu_pack(f));
+        }
+    }
+}
+
+// xs: output of rsg_nchw_f32_to_s2d_nhwc16 [batch, h/2, w/2, 16], or NULL with x_nchw_f32 = the fp32 NCHW picture
+// [batch, 3, h, w] itself (then the layout conversion happens while staging and needs no launch); w1/b1: the 2x2 s2d form of conv1 packed with
+// rsg_pack_conv_weights_host(cin 16, cout 64, 2x2); w2/b2: conv2 packed (cin 64, cout 64, 3x3); out16: [batch, h/4,
+// w/4, out_ld] 16-bit NHWC (64 channels written).  h, w: the INPUT picture size (multiples of 4).
+extern "C" int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1, const void* w2_packed,
+                              const float* bias2, void* out16, int32_t out_ld, int32_t batch, int32_t h, int32_t w,
+                              int32_t dtype, void* stream) {
+    if ((!xs && !x_nchw_f32) || !w1_packed || !bias1 || !w2_packed || !bias2 || !out16) RSG_FAIL("stem_fused: null pointer");
+    if ((uintptr_t)x_nchw_f32 & 7) RSG_FAIL("stem_fused: the picture must be 8-byte aligned");
+    if (batch < 1 || h < 4 || w < 4 || (h & 3) || (w & 3) || out_ld < 64 || (out_ld & 7)) RSG_FAIL("stem_fused: bad shape");
+    if (((uintptr_t)xs | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)out16) & 15) RSG_FAIL("stem_fused: alignment");
+    constexpr int TH2 = 4, TW2 = 12;
+    StemArgs a;
+    a.xs = (const char*)xs; a.x32 = xs ? nullptr : x_nchw_f32; a.w1 = (const uint4*)w1_packed; a.b1 = bias1; a.w2 = (const uint4*)w2_packed; a.b2 = bias2;
+    a.out = (char*)out16; a.B = batch; a.H1 = h / 2; a.W1 = w / 2; a.H2 = h / 4; a.W2 = w / 4; a.ldo = out_ld;
+    a.tiles_x = ceil_div(a.W2, TW2); a.tiles_y = ceil_div(a.H2, TH2);
+    const int lds = (2 * TH2 + 2) * (2 * TW2 + 2) * 48 + (2 * TH2 + 1) * (2 * TW2 + 1) * 144;
+    const dim3 grid(batch * a.tiles_x * a.tiles_y);
+    if (dtype == RSG_BF16) RSG_LAUNCH((stem_kernel<BF16, TH2, TW2>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    else RSG_LAUNCH((stem_kernel<F16, TH2, TW2>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH("stem_fused");
+    return 0;
+}

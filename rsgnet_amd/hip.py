@@ -51,6 +51,7 @@ SYMBOLS = {
     "rsg_version": (C.c_int, []),
     "rsg_tune": (C.c_int, [C.c_char_p, _i]),
     "rsg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
+    "rsg_stem_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_conv_pair": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     "rsg_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     "rsg_conv_padded_cin": (C.c_int32, [_i]),

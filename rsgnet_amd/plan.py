@@ -814,17 +814,23 @@ class _BackboneMixin:
         phases in[2Y+py, 2X+px], so tap (a,b) in {0,1}^2 of the 2x2 conv reads pixel (y+a-1, x+b-1) and the
         phase (py,px) of it carries w[2(a-1)+py+1, 2(b-1)+px+1] when that index is in [0,2], else 0."""
         self.x_static = torch.zeros(self.batch, 3, H, W, dtype=torch.float32, device=self.device)
-        xs = self.new(H // 2, W // 2, 16, name="x_s2d16")
+        fused = os.environ.get("RSGNET_HIP_STEM", "1") != "0" and m.conv1.out_channels == 64 and \
+            m.conv2.in_channels == 64 and m.conv2.out_channels == 64 and m.conv2.kernel_size == (3, 3) and \
+            m.conv2.stride == (2, 2) and H % 4 == 0 and W % 4 == 0
+        direct = fused and os.environ.get("RSGNET_HIP_STEM_DIRECT", "1") != "0"   # the stem reads the picture itself
+        xs = None
         lib, B, dt = self.lib, self.batch, self.dtype
+        if not direct:
+            xs = self.new(H // 2, W // 2, 16, name="x_s2d16")
 
-        def make():
-            dst = xs.ptr()
+            def make():
+                dst = xs.ptr()
 
-            def launch(stream):       # reads the CALLER's tensor (self._x_src): no staging copy of the input
-                hip.check(lib.rsg_nchw_f32_to_s2d_nhwc16(self._x_src, dst, B, 3, H, W, dt, stream), "nchw_to_s2d")
-            return launch
+                def launch(stream):       # reads the CALLER's tensor (self._x_src): no staging copy of the input
+                    hip.check(lib.rsg_nchw_f32_to_s2d_nhwc16(self._x_src, dst, B, 3, H, W, dt, stream), "nchw_to_s2d")
+                return launch
 
-        self.custom("input_to_s2d_nhwc16", [], [xs], make)
+            self.custom("input_to_s2d_nhwc16", [], [xs], make)
         w = m.conv1.weight.detach().float().cpu()                  # [64,3,3,3]
         O = w.shape[0]
         w2 = torch.zeros(O, 16, 2, 2)
@@ -838,8 +844,33 @@ class _BackboneMixin:
                         kx = 2 * (b - 1) + px + 1
                         if 0 <= kx <= 2:
                             w2[:, (py * 2 + px) * 3:(py * 2 + px) * 3 + 3, a, b] = w[:, :, ky, kx]
+        if fused:      # conv1 and conv2 in one launch: the caller names the destination (self.stem_to)
+            s1, h1 = self.bn_fold(m.bn1)
+            self._stem = (xs, self.pack_conv(w2, s1, h1, m.conv1.bias)[:2], H, W)
+            return None
         return self.conv(xs, w2, m.bn1, m.conv1.bias, relu=True, pad=(1, 1), out_hw=(H // 2, W // 2),
                          name="conv1(s2d 2x2)")
+
+    def stem_to(self: Plan, m, out: Optional[VT]) -> VT:
+        """Record the fused stem (rsg_stem_fused) writing conv2's output into ``out`` (a 64-channel view) or a new map."""
+        xs, (wp1, b1), H, W = self._stem
+        s2, h2 = self.bn_fold(m.bn2)
+        wp2, b2 = self.pack_conv(m.conv2.weight, s2, h2, m.conv2.bias)[:2]
+        if out is None:
+            out = self.new(H // 4, W // 4, 64, name="stem")
+        lib, B, dt = self.lib, self.batch, self.dtype
+
+        def make():
+            args = (wp1.data_ptr(), b1.data_ptr(), wp2.data_ptr(), b2.data_ptr(), out.ptr(), out.ld, B, H, W, dt)
+            src = xs.ptr() if xs is not None else None
+
+            def launch(stream):       # without an s2d map the kernel reads the CALLER's picture (self._x_src)
+                hip.check(lib.rsg_stem_fused(src, None if src else self._x_src, *args, stream), "stem_fused")
+            return launch
+
+        self.custom("stem(conv1+conv2)", [xs] if xs is not None else [], [out], make)
+        self.flops += 2 * B * ((H // 2) * (W // 2) * 64 * 27 + (H // 4) * (W // 4) * 64 * 64 * 9)
+        return out
 
     def _unit(self: Plan, x: VT, conv: nn.Conv2d, bn, **kw) -> VT:
         return self.conv(x, conv.weight, bn, conv.bias, stride=conv.stride[0], **kw)
@@ -993,9 +1024,13 @@ class _BackboneMixin:
             # with weights [s3*W3 | sd*Wd]: the projected residual (100 MB at batch 64) is never stored.
             # The stem's conv2 writes x straight into its half of the concat buffer.
             cm, cx = b0.conv3.in_channels, m.conv2.out_channels
-            cat = self.new(x.H // 2, x.W // 2, cm + cx, name="layer1.0.cat")
+            hq, wq = (H // 4, W // 4) if x is None else (x.H // 2, x.W // 2)
+            cat = self.new(hq, wq, cm + cx, name="layer1.0.cat")
             xv = cat.view(cm, cx)
-            self._unit(x, m.conv2, m.bn2, relu=True, out=xv, name="conv2")
+            if x is None:
+                self.stem_to(m, xv)
+            else:
+                self._unit(x, m.conv2, m.bn2, relu=True, out=xv, name="conv2")
             t = self._unit(xv, b0.conv1, b0.bn1, relu=True, name="layer1.0.conv1")
             self._unit(t, b0.conv2, b0.bn2, relu=True, out=cat.view(0, cm), name="layer1.0.conv2")
             s3, h3 = self.bn_fold(b0.bn3)
@@ -1007,7 +1042,7 @@ class _BackboneMixin:
             rest = list(m.layer1)[1:]
             k0 = 1
         else:
-            x = self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
+            x = self.stem_to(m, None) if x is None else self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
             rest, k0 = list(m.layer1), 0
         for k, blk in enumerate(rest, k0):
             x = self._residual_block(x, blk, f"layer1.{k}")

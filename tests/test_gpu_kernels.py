@@ -432,3 +432,25 @@ def test_conv_pair_equals_two_convs(shape):
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     assert torch.equal(got, want[:, :C2])
+
+
+def test_stem_fused_equals_two_convs():
+    """rsg_stem_fused (conv1 as 2x2 s2d conv + conv2 3x3 s2 in one launch) against the two-launch path, bit for bit,
+    through the model plan: RSGNET_HIP_STEM=0/1 on the same weights and input."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import load_case
+    outs = {}
+    for flag in ("0", "1"):
+        os.environ["RSGNET_HIP_STEM"] = flag
+        try:
+            cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+            model = model.cuda()
+            with torch.no_grad():
+                outs[flag] = model(x.cuda()).cpu()
+            names = [n for n, _ in list(model._plans.values())[0].ops]
+            assert ("stem(conv1+conv2)" in names) == (flag == "1")
+        finally:
+            os.environ.pop("RSGNET_HIP_STEM", None)
+    assert torch.equal(outs["0"], outs["1"])
