@@ -135,6 +135,8 @@ def family_table(plan, per_op):
     for e in plan.conv_log:
         if "tile" in e:      # a single convolution
             flops[e["name"]] = 2.0 * plan.batch * e["hw"][0] * e["hw"][1] * e["cin"] * e["cout"] * e["k"] ** 2
+        elif "flops" in e:   # a fused op that states its own algorithmic FLOPs (the stem)
+            flops[e["name"]] = e["flops"]
         elif e.get("pair"):  # Bottleneck conv2 (3x3, cin -> 64) + conv3 (1x1, 64 -> cout) in one launch
             flops[e["name"]] = 2.0 * plan.batch * e["hw"][0] * e["hw"][1] * (e["cin"] * 64 * 9 + 64 * e["cout"])
     chain = {}
@@ -153,7 +155,7 @@ def family_table(plan, per_op):
         elif ".fuse" in n:
             k, f = "conv_group_kernel (fuse layers)", flops.get(n, 0.0)
         elif n in flops:
-            k, f = "conv_igemm_kernel / conv_pair_kernel (stem, layer1, transitions, heads)", flops[n]
+            k, f = "conv_igemm / conv_pair / stem kernels (stem, layer1, transitions, heads)", flops[n]
         else:
             k, f = "other (layout, TRP, bilinear)", 0.0
         d = fams.setdefault(k, {"launches": 0, "us": 0.0, "gflop": 0.0})

@@ -869,7 +869,9 @@ class _BackboneMixin:
             return launch
 
         self.custom("stem(conv1+conv2)", [xs] if xs is not None else [], [out], make)
-        self.flops += 2 * B * ((H // 2) * (W // 2) * 64 * 27 + (H // 4) * (W // 4) * 64 * 64 * 9)
+        fl = 2 * B * ((H // 2) * (W // 2) * 64 * 27 + (H // 4) * (W // 4) * 64 * 64 * 9)
+        self.flops += fl
+        self.conv_log.append(dict(name="stem(conv1+conv2)", flops=float(fl)))
         return out
 
     def _unit(self: Plan, x: VT, conv: nn.Conv2d, bn, **kw) -> VT:
