@@ -64,6 +64,11 @@ typedef struct rsg_conv_desc {
     int32_t out_c_store;       /* 0 = write round_up(out_c,32) channels of out16; else only [0, out_c_store) (multiple
                                   of 8): for outputs that are a channel slice narrower than a 32-channel tile */
     int32_t reserved;
+    /* two more addends of the epilogue (same layout rules as `residual`; NULL = none): the HRNet fuse sum of the
+       lowest-resolution output rides on the last conv that feeds it (pose_hrnet.py:259-266) */
+    const void* residual2;
+    const void* residual3;
+    int32_t res2_ld, res3_ld;
 } rsg_conv_desc;
 
 int rsg_conv_igemm(const rsg_conv_desc* d, void* stream);

@@ -7,10 +7,12 @@ struct ConvArgs {
     const uint4* wpk;
     const float* bias;
     const char* res;
+    const char* res2;          // further addends of the epilogue (HRNet fuse sum folded into the conv), or null
+    const char* res3;
     char* out;
     float* out32;
     int B, Hin, Win, ldi;
-    int Hout, Wout, Cout, ldo, ldr;
+    int Hout, Wout, Cout, ldo, ldr, ldr2, ldr3;
     int CoutStore;   // channels [0, CoutStore) are written to the 16-bit output (multiple of 8)
     int SI, oy0, ox0;
     int up, upy, upx, Hp, Wp;

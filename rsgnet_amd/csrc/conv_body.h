@@ -232,14 +232,19 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[g][r];
         if (p.res) {
-            const char* rp = p.res + ((size_t)opix[g] * p.ldr + cbase) * 2;
+            auto add = [&](const char* base, int ld) {
+                const char* rp = base + ((size_t)opix[g] * ld + cbase) * 2;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(rp + k * 16);
-                const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv), f32x8);
+                for (int k = 0; k < 2; ++k) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(rp + k * 16);
+                    const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv), f32x8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[k * 8 + e] += rf[e];
-            }
+                    for (int e = 0; e < 8; ++e) v[k * 8 + e] += rf[e];
+                }
+            };
+            add(p.res, p.ldr);
+            if (p.res2) add(p.res2, p.ldr2);
+            if (p.res3) add(p.res3, p.ldr3);
         }
         if (relu) {
 #pragma unroll

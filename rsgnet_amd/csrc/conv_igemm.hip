@@ -183,6 +183,10 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     if (store % 8 || store > cout_pad || store < 8) RSG_FAIL("conv: out_c_store=%d", d->out_c_store);
     if (d->out16 && (d->out_ld < store || d->out_ld % 8)) RSG_FAIL("conv: out_ld=%d < stored channels %d", d->out_ld, store);
     if (d->residual && (d->res_ld < cout_pad || d->res_ld % 8)) RSG_FAIL("conv: res_ld=%d", d->res_ld);
+    if ((d->residual2 && (d->res2_ld < cout_pad || d->res2_ld % 8 || ((uintptr_t)d->residual2 & 15))) ||
+        (d->residual3 && (d->res3_ld < cout_pad || d->res3_ld % 8 || ((uintptr_t)d->residual3 & 15))))
+        RSG_FAIL("conv: residual2/3 stride or alignment");
+    if ((d->residual2 || d->residual3) && !d->residual) RSG_FAIL("conv: residual2/3 need residual");
     if (d->up < 1 || d->up_y < 0 || d->up_x < 0 || (d->out_h - 1) * d->up + d->up_y >= d->phys_h ||
         (d->out_w - 1) * d->up + d->up_x >= d->phys_w)
         RSG_FAIL("conv: output scatter (up=%d,%d,%d) exceeds %dx%d", d->up, d->up_y, d->up_x, d->phys_h, d->phys_w);
@@ -192,6 +196,7 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     if (choose_tile(d, t)) return 1;
     a.in = (const char*)d->in; a.wpk = (const uint4*)d->w_packed; a.bias = d->bias;
     a.res = (const char*)d->residual; a.out = (char*)d->out16; a.out32 = d->out_nchw_f32;
+    a.res2 = (const char*)d->residual2; a.res3 = (const char*)d->residual3; a.ldr2 = d->res2_ld; a.ldr3 = d->res3_ld;
     a.B = d->batch; a.Hin = d->in_h; a.Win = d->in_w; a.ldi = d->in_ld;
     a.Hout = d->out_h; a.Wout = d->out_w; a.Cout = d->out_c; a.ldo = d->out_ld; a.ldr = d->res_ld;
     a.CoutStore = store;

@@ -25,6 +25,7 @@ class ConvDesc(C.Structure):
         ("up", C.c_int32), ("up_y", C.c_int32), ("up_x", C.c_int32), ("phys_h", C.c_int32), ("phys_w", C.c_int32),
         ("relu", C.c_int32), ("dtype", C.c_int32), ("tile_hint", C.c_int32), ("relu_tile_mask", C.c_int32),
         ("out_c_store", C.c_int32), ("reserved", C.c_int32),
+        ("residual2", C.c_void_p), ("residual3", C.c_void_p), ("res2_ld", C.c_int32), ("res3_ld", C.c_int32),
     ]
 
 

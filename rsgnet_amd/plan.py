@@ -227,7 +227,7 @@ class Plan:
              relu=False, residual: Optional[VT] = None, out: Optional[VT] = None,
              out_f32: Optional[torch.Tensor] = None, want16=True, pad=None, up=(1, 0, 0),
              out_hw=None, phys_hw=None, name="", extra_shift=None, scale_shift=None,
-             relu_mask=0) -> Optional[VT]:
+             relu_mask=0, more_residuals: Sequence[VT] = ()) -> Optional[VT]:
         """Record conv(+BN)(+bias)(+residual)(+ReLU).  ``x.C`` must be the padded input channels."""
         scale, shift = self.bn_fold(bn) if scale_shift is None else scale_shift
         if extra_shift is not None:
@@ -262,10 +262,13 @@ class Plan:
         out_slot = None
         if isinstance(out_f32, OutSlot):
             out_slot, out_f32 = out_f32, out_f32.static
+        if len(more_residuals) > 2 or (more_residuals and residual is None):
+            raise ValueError(f"{name}: at most three residual operands")
         self._record(dict(kind="conv", x=x, wp=wp, bias=bo, res=residual, out=out, out_f32=out_f32, out_slot=out_slot,
                           I=cin_pad, O=O, kh=kh, kw=kw, stride=stride, pad=pad, up=up, out_hw=out_hw,
-                          phys_hw=phys_hw, relu=relu, relu_mask=relu_mask, store=store, name=name),
-                     [x, residual], [out, out_f32])
+                          phys_hw=phys_hw, relu=relu, relu_mask=relu_mask, store=store, name=name,
+                          res_more=list(more_residuals)),
+                     [x, residual, *more_residuals], [out, out_f32])
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
 
@@ -481,6 +484,11 @@ class Plan:
         d.out_c_store = r.get("store", 0)
         d.dtype = self.dtype
         d.tile_hint = 0
+        more = r.get("res_more") or []
+        if len(more) > 0:
+            d.residual2, d.res2_ld = (0x10000 if fake_ptrs else more[0].ptr()), more[0].ld
+        if len(more) > 1:
+            d.residual3, d.res3_ld = (0x10000 if fake_ptrs else more[1].ptr()), more[1].ld
         return d
 
     def _log_conv(self, r, d):
@@ -976,7 +984,16 @@ class _BackboneMixin:
         max_depth = max(depth.values()) if depth else 0
         outs: List[Optional[VT]] = [None] * n_out
         ready = {i: max([d for (ii, _), d in depth.items() if ii == i], default=0) for i in range(n_out)}
+        # output n_out-1 has no up-sampled addends and at most three others besides its longest chain: fold its sum
+        fold_into = None
+        last = n_out - 1
+        if os.environ.get("RSGNET_HIP_FOLD_SUM", "1") != "0" and not self.use_fanout and last >= 1 and last == len(xs) - 1 \
+                and last <= 3 and depth.get((last, 0), 0) == last:
+            fold_into = (last, 0)
+            ready[last] = -1                              # no separate sum for it
         for level in range(max_depth + 1):
+            if fold_into is not None and level == max_depth and not any(r == level for r in ready.values()):
+                break                                     # nothing left for a last, sum-only level
             self.begin_group()
             # convs of this level, bucketed by (input tensor, geometry): same-bucket convs share one launch
             # item with concatenated output channels (fan-out fusion: the input tile is staged once)
@@ -1000,8 +1017,17 @@ class _BackboneMixin:
                         cur[ij] = v
                 else:
                     for ij, xin, conv, bnm, relu in items:
-                        cur[ij] = self._unit(xin, conv, bnm, relu=relu,
-                                             name=f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level}"))
+                        nm = f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level}")
+                        if ij == fold_into and level == depth[ij] - 1:
+                            # the sum of the lowest-resolution output rides on the last conv that feeds it: every other
+                            # addend (the identity and the shorter strided chains) was finished at an earlier level
+                            i = ij[0]
+                            others = [xs[i]] + [cur[(i, j)] for j in range(1, i)]
+                            outs[i] = self._unit(xin, conv, bnm, relu=True, residual=others[0], more_residuals=others[1:],
+                                                 name=nm + "+sum")
+                            cur[ij] = outs[i]
+                            continue
+                        cur[ij] = self._unit(xin, conv, bnm, relu=relu, name=nm)
             for i in range(n_out):
                 if ready[i] == level:                    # every addend was finished by the previous level
                     same = [cur[(i, j)] for j in range(i)] + [xs[i]]
