@@ -189,12 +189,13 @@ typedef struct rsg_fuse_item {
     int32_t reserved;
 } rsg_fuse_item;
 int rsg_conv_groupable(const rsg_conv_desc* d);
-/* two steps: _plan (HOST) writes the launch table (rsg_group_table_bytes bytes) and launch2 = {grid
- * blocks, LDS bytes}; the caller copies the table to the device once; _run enqueues the launch. */
+/* two steps: _plan (HOST) writes the launch table (rsg_group_table_bytes bytes, HOST memory the caller keeps) and
+ * launch2 = {grid blocks, LDS bytes}; _run enqueues the launch with the table as the kernel argument (read from host
+ * memory at the call, like any argument). */
 size_t rsg_group_table_bytes(void);
 int rsg_conv_fuse_group_plan(const rsg_conv_desc* convs, int32_t n_convs, const rsg_fuse_item* fuses,
                              int32_t n_fuses, int32_t dtype, void* table_host, int32_t* launch2);
-int rsg_conv_fuse_group_run(const void* table_dev, int32_t blocks, int32_t lds, int32_t dtype, void* stream);
+int rsg_conv_fuse_group_run(const void* table_host, int32_t blocks, int32_t lds, int32_t dtype, void* stream);
 
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) [+ sigmoid] on fp32 NCHW
  * (pose_rsgnet.py:1009-1013) */

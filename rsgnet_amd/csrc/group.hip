@@ -14,8 +14,8 @@
 struct GroupArgs {
     int n_conv, n_fuse;
     int first[RSG_GROUP_MAX_CONVS + RSG_GROUP_MAX_FUSES + 1];
-    short variant[RSG_GROUP_MAX_CONVS];
-    short nbx[RSG_GROUP_MAX_CONVS];          // blocks along x of conv i (its grid.y is folded into x)
+    int variant[RSG_GROUP_MAX_CONVS];
+    int nbx[RSG_GROUP_MAX_CONVS];          // blocks along x of conv i (its grid.y is folded into x)
     ConvArgs conv[RSG_GROUP_MAX_CONVS];
     FuseArgs fuse[RSG_GROUP_MAX_FUSES];
 };
@@ -35,8 +35,9 @@ static int variant_id(int cinb, int taps, int wm, int nt) {
     return (ci * 3 + ti) * 5 + cf;
 }
 
-// The item table lives in device memory (built once per plan): indexing a by-value copy of it with the
-// runtime item id would spill the whole table to scratch.
+// The item table is the kernel argument (3.2 KB of the 4 KB kernarg segment): as a table in device memory every
+// workgroup spent 3.5-5 k cycles on a chain of dependent scalar loads before it could start (stamp build: 0.4-0.5 k for
+// the same conv launched alone with by-value arguments).
 #ifdef RSG_CONV_STAMPS
 extern "C" int rsg_conv_set_stamp_buffer(void* dev_ptr) {
     unsigned long long* p = (unsigned long long*)dev_ptr;
@@ -46,7 +47,7 @@ extern "C" int rsg_conv_set_stamp_buffer(void* dev_ptr) {
 #endif
 
 template <class DT>
-__global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs* __restrict__ gp) {
+__global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RSG_CSTAMP(0);
 #ifdef RSG_CONV_STAMPS
@@ -56,7 +57,6 @@ __global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs* __r
         g_conv_stamps[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
-    const GroupArgs& g = *gp;
     const int n = g.n_conv + g.n_fuse;
     // which item?  Constant indices, so the whole first[] table comes in with one batch of scalar loads (a while
     // loop made every step wait for its own load: 4-9 k cycles before the later items even started)
@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs* __r
         fuse_body<DT>(g.fuse[i - g.n_conv], local, g.first[i + 1] - g.first[i]);
         return;
     }
-    const ConvArgs& a = g.conv[i];
+    // one item's arguments into registers: a batch of scalar loads from the kernel-argument segment (a reference into
+    // the by-value table makes hipcc copy the whole table to scratch)
+    const ConvArgs a = g.conv[i];
     const int nbx = g.nbx[i];
     const int bx = local % nbx, by = local / nbx;
 #define RSG_V(ID, C, TH_, TW_, WM_, WN_, NT_) \
@@ -120,8 +122,8 @@ extern "C" int rsg_conv_fuse_group_plan(const rsg_conv_desc* convs, int32_t n_co
         if (rsg_conv_prepare(&convs[i], g.conv[i], t, grid)) return 1;
         const int v = variant_id(t.CINB, convs[i].kh * convs[i].kw, t.WM, t.NT);
         if (v < 0 || grid.x > 32767) RSG_FAIL("group: conv %d (CINB=%d k=%d WM=%d NT=%d) is not groupable", i, t.CINB, convs[i].kh, t.WM, t.NT);
-        g.variant[i] = (short)v;
-        g.nbx[i] = (short)grid.x;
+        g.variant[i] = v;
+        g.nbx[i] = (int)grid.x;
         g.first[i] = blocks;
         blocks += grid.x * grid.y;
         if (t.lds > lds) lds = t.lds;
@@ -142,10 +144,11 @@ extern "C" int rsg_conv_fuse_group_plan(const rsg_conv_desc* convs, int32_t n_co
     return 0;
 }
 
-extern "C" int rsg_conv_fuse_group_run(const void* table_dev, int32_t blocks, int32_t lds, int32_t dtype,
+extern "C" int rsg_conv_fuse_group_run(const void* table_host, int32_t blocks, int32_t lds, int32_t dtype,
                                        void* stream) {
-    if (!table_dev || blocks < 1 || lds < 0 || lds > 64 * 1024) RSG_FAIL("group_run: bad arguments");
-    const GroupArgs* g = (const GroupArgs*)table_dev;
+    if (!table_host || blocks < 1 || lds < 0 || lds > 64 * 1024) RSG_FAIL("group_run: bad arguments");
+    static_assert(sizeof(GroupArgs) <= 4096, "the launch table travels as the kernel argument");
+    const GroupArgs& g = *(const GroupArgs*)table_host;
     if (dtype == RSG_BF16)
         RSG_LAUNCH(conv_group_kernel<BF16>, dim3(blocks), dim3(256), lds, (hipStream_t)stream, g);
     else

@@ -567,8 +567,8 @@ class Plan:
         table = np.zeros(self.lib.rsg_group_table_bytes(), np.uint8)
         launch2 = (C.c_int32 * 2)()
         hip.check(self.lib.rsg_conv_fuse_group_plan(cd, len(convs), fi, len(fuses), dt, table.ctypes.data, launch2), nm)
-        tdev = self._dev(table)
-        fn, tptr, blocks, lds = self.lib.rsg_conv_fuse_group_run, tdev.data_ptr(), launch2[0], launch2[1]
+        self._keep.append(table)               # the table is the kernel ARGUMENT: read from host memory at every launch
+        fn, tptr, blocks, lds = self.lib.rsg_conv_fuse_group_run, table.ctypes.data, launch2[0], launch2[1]
         self.conv_log.append(dict(name=nm, group=[x["name"] for x in r["subs"]], blocks=blocks))
 
         def launch(stream):
