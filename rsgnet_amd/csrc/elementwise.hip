@@ -124,6 +124,7 @@ int rsg_fuse_prepare(const void* const* same, int n_same, const void* const* low
     a.n_same = n_same; a.n_low = n_low; a.out = (char*)out;
     a.h = h; a.w = w; a.c8 = c / 8;
     a.total = (long)batch * h * w * a.c8;
+    if (a.total >= (1L << 31)) RSG_FAIL("hr_fuse: too many elements for 32-bit indexing");
     long b = (a.total + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
     blocks = (int)b;

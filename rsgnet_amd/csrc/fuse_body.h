@@ -14,40 +14,52 @@ struct FuseArgs {
     long total;     // batch*h*w*c8 16-byte vectors
 };
 
+// One thread per 8 channels of a pixel.  32-bit index arithmetic (the host checks total < 2^31) and operand loops
+// unrolled over the fixed maxima with constant indices: the operand pointers and strides then come from the kernel
+// arguments once, and all loads of an element are in flight together.  (The first version divided 64-bit indices five
+// times per element and walked the operand lists with run-time indices: 19 us for a sum that moves 26 MB.)
 template <class DT>
 __device__ __forceinline__ void fuse_body(const FuseArgs& a, const int block, const int nblocks) {
-    for (long i = (long)block * 256 + threadIdx.x; i < a.total; i += (long)nblocks * 256) {
+    const unsigned total = (unsigned)a.total, c8 = (unsigned)a.c8, w = (unsigned)a.w, h = (unsigned)a.h;
+    const int n_same = a.n_same, n_low = a.n_low;
+    for (unsigned i = (unsigned)block * 256u + threadIdx.x; i < total; i += (unsigned)nblocks * 256u) {
+        const unsigned pix0 = i / c8, cg = i - pix0 * c8;
+        uint4 vs[4], vl[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n_same) vs[k] = reinterpret_cast<const uint4*>(a.same[k])[(size_t)pix0 * a.ld_same[k] + cg];
+        if (n_low) {
+            const unsigned t = pix0 / w, x = pix0 - t * w;
+            const unsigned b = t / h, y = t - b * h;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < n_low) {
+                    const int s = a.shift[k];
+                    const size_t src = (((size_t)b * (h >> s) + (y >> s)) * (w >> s) + (x >> s)) * a.ld_low[k] + cg;
+                    vl[k] = reinterpret_cast<const uint4*>(a.low[k])[src];
+                }
+        }
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-        const int cg0 = (int)(i % a.c8);
-        const long pix0 = i / a.c8;
-        for (int k = 0; k < a.n_same; ++k) {
-            const typename DT::vec8 v = __builtin_bit_cast(
-                typename DT::vec8, reinterpret_cast<const uint4*>(a.same[k])[pix0 * a.ld_same[k] + cg0]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
-        }
-        if (a.n_low) {
-            const int cg = (int)(i % a.c8);
-            long pix = i / a.c8;
-            const int x = (int)(pix % a.w);
-            pix /= a.w;
-            const int y = (int)(pix % a.h);
-            const long b = pix / a.h;
-            for (int k = 0; k < a.n_low; ++k) {
-                const int s = a.shift[k];
-                const long src = ((b * (a.h >> s) + (y >> s)) * (a.w >> s) + (x >> s)) * a.ld_low[k] + cg;
-                const typename DT::vec8 v =
-                    __builtin_bit_cast(typename DT::vec8, reinterpret_cast<const uint4*>(a.low[k])[src]);
+        for (int k = 0; k < 4; ++k)
+            if (k < n_same) {
+                const typename DT::vec8 v = __builtin_bit_cast(typename DT::vec8, vs[k]);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
             }
-        }
-        typename DT::vec8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (typename DT::elem)fmaxf(acc[e], 0.f);
-        reinterpret_cast<uint4*>(a.out)[i] = __builtin_bit_cast(uint4, o);
+        for (int k = 0; k < 3; ++k)
+            if (k < n_low) {
+                const typename DT::vec8 v = __builtin_bit_cast(typename DT::vec8, vl[k]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        f32x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = acc[e];
+        reinterpret_cast<uint4*>(a.out)[i] = __builtin_bit_cast(uint4, DT::relu_pack(f));
     }
 }
 
