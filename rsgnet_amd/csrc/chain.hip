@@ -434,8 +434,9 @@ template <class DT>
 __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned pf = chain_prefetch_weights(g);
-    int i = 0;
-    while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+    int i = 0;       // constant indices: first[] arrives with one batch of scalar loads (see group.hip)
+#pragma unroll
+    for (int j = 1; j < RSG_CHAIN_GROUP_MAX; ++j) i += (j < g.n && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
     const int bid = blockIdx.x - g.first[i];
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
