@@ -266,6 +266,24 @@ int rsg_relation_target_vec(const float* target, float* out, int32_t batch, int3
 int rsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
 
+/* ---- crop producer ---------------------------------------------------------------
+ * One person box per entry: `cv2.warpAffine(img, trans, (out_w, out_h), flags=INTER_LINEAR)` (constant border 0)
+ * followed by ToTensor + Normalize (lib/dataset/CPJointsDataset.py:1281-1290; JointsDataset the same;
+ * tools/test.py:105-112), OpenCV's fixed-point bilinear arithmetic restated bit for bit.  The descriptor array
+ * lives in DEVICE memory; `image` points at a device uint8 picture, HWC with 3 interleaved channels. */
+struct rsg_crop_desc {
+    const void* image;
+    int32_t height, width;   /* source picture */
+    int32_t stride;          /* bytes per source row */
+    int32_t reserved;
+    double m[6];             /* forward 2x3 map source -> crop, row-major (get_affine_transform, transforms.py:64) */
+};
+/* out: fp32 [batch,3,out_h,out_w]; mean3/std3: HOST arrays of 3 (per output channel); swap_rb != 0 reverses the
+ * channel order on the way (cv2.COLOR_BGR2RGB, DATASET.COLOR_RGB). */
+int rsg_crop_warp_affine(const struct rsg_crop_desc* crops_dev, float* out_nchw, int32_t batch, int32_t out_h,
+                         int32_t out_w, const float* mean3_host, const float* std3_host, int32_t swap_rb,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

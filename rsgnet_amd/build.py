@@ -48,6 +48,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     extra = {f: vgpr_form for f in ("trp.hip", "chain.hip", "group.hip", "conv_igemm.hip")}
     for f in os.environ.get("RSGNET_HIP_NO_VGPR_FORM", "").split(","):  # experiment switch
         extra.pop(f, None)
+    # the crop producer reproduces OpenCV's separately rounded double arithmetic: no fused multiply-adds there
+    # (-ffp-contract=fast fuses in the backend and ignores `#pragma clang fp contract(off)`)
+    extra["crops.hip"] = ["-ffp-contract=off"]
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")

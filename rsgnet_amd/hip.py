@@ -45,6 +45,12 @@ class ChainItem(C.Structure):
                 ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p)]
 
 
+class CropDesc(C.Structure):
+    """struct rsg_crop_desc (include/rsgnet_hip.h)."""
+    _fields_ = [("image", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("stride", C.c_int32),
+                ("reserved", C.c_int32), ("m", C.c_double * 6)]
+
+
 # every symbol include/rsgnet_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _fp = C.c_void_p, C.c_int32, C.c_void_p
 SYMBOLS = {
@@ -92,6 +98,7 @@ SYMBOLS = {
     "rsg_bce_loss": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, _vp, _i, _vp, _vp, _vp]),
     "rsg_relation_target_vec": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _vp]),
+    "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

@@ -218,3 +218,42 @@ def test_forward_is_deterministic():
     n = ctypes.c_uint32(99)
     hip.check(hip.lib().rsg_chain_handoff_timeouts(ctypes.byref(n)))
     assert n.value == 0           # no consumer chain ever gave up waiting for its producer
+
+
+def test_eval_pipeline_picture_to_keypoints():
+    """Picture -> person crops -> flip-test forward -> decode -> OKS-NMS with everything between the uint8 picture
+    and the 3 floats per joint on the device, against the oracle run stage by stage on the CPU
+    (lib/core/function.py:368-470 + lib/dataset/coco.py:296-360)."""
+    from oracle import crop_oracle as co
+    from rsgnet_amd import crops, nms
+    from rsgnet_amd.decode import get_final_preds
+    from rsgnet_amd.flip import forward_flip_test
+    cfg, model, sd, _, _ = load_case("hrnet_w32_256x192")
+    model = model.cuda()
+    rs = np.random.RandomState(21)
+    ys, xs = np.mgrid[0:360, 0:480]
+    pic = np.clip(np.stack([127 + 100 * np.sin(xs / 17.0 + c) * np.cos(ys / 23.0 - c) for c in range(3)], 2)
+                  + rs.normal(0, 8, (360, 480, 3)), 0, 255).astype(np.uint8)
+    boxes = [[40, 30, 120, 260], [46, 34, 118, 255], [250, 60, 150, 280], [300, 10, 90, 200]]
+    cs = [crops.box_to_center_scale(b, 192 / 256) for b in boxes]
+    centers, scales = np.stack([c for c, _ in cs]), np.stack([s for _, s in cs])
+    x = crops.CropProducer((192, 256))([torch.from_numpy(pic).cuda()], [0] * 4, centers, scales)
+    want_x = torch.from_numpy(np.stack([co.to_tensor_normalize(co.warp_affine_u8(
+        np.ascontiguousarray(pic[:, :, ::-1]), crops.get_affine_transform(centers[i], scales[i], 0, (192, 256)), 192, 256))
+        for i in range(4)]))
+    assert torch.equal(x.cpu(), want_x)
+    with torch.no_grad():
+        hm = forward_flip_test(model, x, COCO_FLIP_PAIRS)
+        preds, maxvals = get_final_preds(hm, centers, scales)
+    want_hm = po.flip_test_merge(po.hrnet_forward(sd, cfg, want_x), po.hrnet_forward(sd, cfg, want_x.flip(3)),
+                                 COCO_FLIP_PAIRS)
+    assert _stats("pipeline heatmaps", hm.cpu(), want_hm.numpy()) < REL_TOL * float(want_hm.std())
+    got = np.concatenate([preds.cpu().numpy(), maxvals.cpu().numpy().reshape(4, 17, 1)], axis=2)
+    assert np.isfinite(got).all()
+    # decode of the device heatmaps through the oracle: same argmax cells, same coordinates
+    want_p, want_m = po.final_preds(hm.cpu().numpy(), centers, scales, True)
+    assert maxabs(torch.from_numpy(got[:, :, :2]), want_p) < 1e-3
+    db = [{"score": 1.0, "keypoints": got[i], "area": float(scales[i, 0] * 200 * scales[i, 1] * 200)} for i in range(4)]
+    kept = nms.rescore_and_nms(db, 17, 0.0, 0.9)
+    want_keep = co.oks_nms(got, co.rescore(got, [1.0] * 4, 0.0), [d["area"] for d in db], 0.9)
+    assert [id(k) for k in kept] == [id(db[i]) for i in want_keep]
