@@ -88,6 +88,16 @@ int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const void* w1_packe
  * 64-channel intermediate stays in LDS. */
 int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias, int32_t tail_out_c,
                   const void* residual, int32_t res_ld, void* out16, int32_t out_ld, int32_t relu, void* stream);
+/* A whole Bottleneck without downsample branch (pose_hrnet.py:85-101: conv1 1x1 256->64, conv2 3x3, conv3 1x1
+ * 64->256, each + BatchNorm, + x, ReLU) in ONE launch: conv1 is evaluated per tile (with its one-pixel halo) straight
+ * into LDS, so neither 64-channel map ever reaches HBM.  x: 256-channel NHWC map (pixel stride x_ld elements), also
+ * the residual; inner: the 3x3 conv (64 -> 64; its `in` is ignored); head_w_packed: conv1 packed by
+ * rsg_pack_conv_weights_host AFTER permuting its input channels, packed channel l = x channel
+ * rsg_bottleneck_head_perm(l); out16: [batch,h,w,256] with pixel stride out_ld, must not alias x. */
+int32_t rsg_bottleneck_head_perm(int32_t l);
+int rsg_bottleneck_fused(const struct rsg_conv_desc* inner, const void* x, int32_t x_ld, const void* head_w_packed,
+                         const float* head_bias, const void* tail_w_packed, const float* tail_bias, void* out16,
+                         int32_t out_ld, void* stream);
 int rsg_conv_plan(const rsg_conv_desc* d, int32_t* out8);
 
 int32_t rsg_conv_padded_cin(int32_t cin);              /* 3->16, 17->32, multiples of 16 kept ... */

@@ -25,6 +25,12 @@ struct ConvArgs {
     const uint4* wpk2;
     const float* bias2;
     int C2;          // output channels of the tail (multiple of 32)
+    // fused 1x1 head (conv_body<..., HEAD=true>, rsg_bottleneck_fused): the conv's 64-channel input tile is not read
+    // from `in` but computed in place, ReLU(conv1x1(in0) + bias0), from a 256-channel map (Bottleneck conv1)
+    const char* in0;
+    const uint4* wpk0;      // packed with the head's channel permutation (rsg_bottleneck_head_perm)
+    const float* bias0;
+    int ldi0;
 };
 
 struct TilePlan {

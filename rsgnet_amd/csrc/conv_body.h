@@ -19,7 +19,7 @@ static __device__ unsigned long long* g_conv_stamps = nullptr;      // [blocks][
 #define RSG_CSTAMP(slot) do {} while (0)
 #endif
 
-template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false>
+template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false, int HEAD = 0>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, const int block_y, char* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KPT = CINB / 16;       // k-steps per filter tap
@@ -57,6 +57,84 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         opix[g] = valid ? ((b * p.Hp + (y0 + py) * p.up + p.upy) * p.Wp + (x0 + px) * p.up + p.upx) : -1;
     }
 
+    if constexpr (HEAD) {
+        // ---- fused 1x1 head (Bottleneck conv1, pose_hrnet.py:85-87): the 64-channel input tile (+halo) of the 3x3 conv
+        // is computed here from the 256-channel block input and written to LDS where the staging loop would have put
+        // it.  The B operand needs no LDS: with the input channels permuted at pack time (logical k = 16j + 8h + e <->
+        // channel 128h + 8j + e) a lane's 16 k-steps are 256 contiguous bytes of its pixel.  Positions outside the
+        // picture are the 3x3 conv's zero padding, not conv1(0).
+        static_assert(CINB == 32 * WM, "the head produces every input channel of the inner conv");
+        constexpr int KS0 = 16;
+        const int total_px = p.TIH * p.TIW;
+        const int ngroups = (total_px + 31) >> 5;
+        const int iy00 = y0 * p.SI + p.oy0, ix00 = x0 * p.SI + p.ox0;
+        uint4 a0[KS0];
+#pragma unroll
+        for (int k = 0; k < KS0; ++k) a0[k] = p.wpk0[((size_t)wm * KS0 + k) * 64 + lane];
+        float bias0[16];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias0 + wm * 32 + hh * 16 + r4 * 4);
+            bias0[r4 * 4 + 0] = bv.x; bias0[r4 * 4 + 1] = bv.y; bias0[r4 * 4 + 2] = bv.z; bias0[r4 * 4 + 3] = bv.w;
+        }
+        // one pixel group: addresses, the 16 loads of its 256 B per lane, then 16 MFMAs and the LDS write
+        struct Grp { int lo; bool live, inside; };
+        auto issue = [&](int g, uint4 (&bq0)[KS0]) -> Grp {
+            const int id = g * 32 + n;
+            const int ty = id / p.TIW, tx = id - ty * p.TIW;
+            const int iy = iy00 + ty, ix = ix00 + tx;
+            Grp r;
+            r.live = id < total_px;
+            r.inside = r.live && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            r.lo = ty * p.RP + tx * PS + (wm * 32 + hh * 16) * 2;
+            const char* src = p.in0 + (((size_t)b * p.Hin * p.Win + (r.inside ? iy * p.Win + ix : 0)) * p.ldi0 + hh * 128) * 2;
+#pragma unroll
+            for (int k = 0; k < KS0; ++k) bq0[k] = *reinterpret_cast<const uint4*>(src + k * 16);
+            return r;
+        };
+        auto finish = [&](const Grp& r, const uint4 (&bq0)[KS0]) {
+            f32x16 h;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) h[q] = bias0[q];
+#pragma unroll
+            for (int k = 0; k < KS0; ++k)
+                h = DT::mfma(__builtin_bit_cast(typename DT::vec8, a0[k]), __builtin_bit_cast(typename DT::vec8, bq0[k]), h);
+            if (r.live) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f32x8 f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = h[k * 8 + e];
+                    uint4 v = __builtin_bit_cast(uint4, DT::relu_pack(f));
+                    if (!r.inside) v = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(smem + r.lo + k * 16) = v;
+                }
+            }
+        };
+        if constexpr (HEAD == 1) {
+            for (int g = wn; g < ngroups; g += WN) {
+                uint4 bq0[KS0];
+                const Grp r = issue(g, bq0);
+                finish(r, bq0);
+            }
+        } else {
+            // two groups in flight: the loads of the next group are issued before the MFMAs of the current one
+            uint4 bA[KS0], bB[KS0];
+            Grp rA = issue(wn, bA), rB = rA;
+            for (int g = wn; g < ngroups; g += 2 * WN) {
+                const bool hasB = g + WN < ngroups;          // wave-uniform
+                if (hasB) rB = issue(g + WN, bB);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(rA, bA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 * WN < ngroups) rA = issue(g + 2 * WN, bA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (hasB) finish(rB, bB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
     // accumulators start at the folded-BN bias of this lane's 16 output channels
     const int cbase = ct * 32 + hh * 16;
     f32x16 acc[NT];
@@ -88,7 +166,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
 #pragma unroll
         for (int k = 0; k < NPF; ++k) aq[k] = apc[k * 64];
         // ---- stage CINB channels of the input tile (+halo) into LDS, zero outside the image ------
-        for (int base = 0; base < total; base += NTHR * NLD) {
+        for (int base = 0; base < (HEAD ? 0 : total); base += NTHR * NLD) {
             uint4 r[NLD];
             int lo[NLD];
 #pragma unroll
@@ -165,58 +243,68 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         }
         __syncthreads();
         const int ntile2 = p.C2 / 32;
+        // the pixel groups of the tile in two passes: half the accumulators, and the residual of a pass is requested
+        // before its MFMAs so that it lands under them (3 workgroups per CU need <= 168 registers)
+        constexpr int NPH = (NP2 + 1) / 2;
         for (int ct2 = wave; ct2 < ntile2; ct2 += WM * WN) {
             const int cb2 = ct2 * 32 + hh * 16;
             uint4 a2[KS2];
 #pragma unroll
             for (int k = 0; k < KS2; ++k) a2[k] = p.wpk2[((size_t)ct2 * KS2 + k) * 64 + lane];
-            f32x16 acc2[NP2];
+            float bias2[16];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const float4 bv = *reinterpret_cast<const float4*>(p.bias2 + cb2 + r4 * 4);
-#pragma unroll
-                for (int j = 0; j < NP2; ++j) {
-                    acc2[j][r4 * 4 + 0] = bv.x; acc2[j][r4 * 4 + 1] = bv.y;
-                    acc2[j][r4 * 4 + 2] = bv.z; acc2[j][r4 * 4 + 3] = bv.w;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KS2; ++k) {
-                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, a2[k]);
-#pragma unroll
-                for (int j = 0; j < NP2; ++j) {
-                    const int q = j * 32 + n;
-                    const uint4 bv = *reinterpret_cast<const uint4*>(smem + (q < p.TH * p.TW ? q : 0) * PS2 + k * 32 + hh * 16);
-                    acc2[j] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc2[j]);
-                }
+                bias2[r4 * 4 + 0] = bv.x; bias2[r4 * 4 + 1] = bv.y; bias2[r4 * 4 + 2] = bv.z; bias2[r4 * 4 + 3] = bv.w;
             }
             const bool relu2 = (p.relu >> (ct2 & 31)) & 1;
 #pragma unroll
-            for (int j = 0; j < NP2; ++j) {
-                const int q = j * 32 + n;
-                const int py = q / p.TW, px = q - py * p.TW;
-                if (q >= p.TH * p.TW || y0 + py >= p.Hout || x0 + px >= p.Wout) continue;
-                const size_t op = (size_t)(b * p.Hout + y0 + py) * p.Wout + x0 + px;
-                float v[16];
+            for (int half = 0; half < 2; ++half) {
+                int op[NPH];
+                uint4 rv[NPH][2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc2[j][r];
-                if (p.res) {
-                    const char* rp = p.res + (op * p.ldr + cb2) * 2;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const uint4 rv = *reinterpret_cast<const uint4*>(rp + k * 16);
-                        const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv), f32x8);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[k * 8 + e] += rf[e];
+                for (int j = 0; j < NPH; ++j) {
+                    const int q = (half * NPH + j) * 32 + n;
+                    const int py = q / p.TW, px = q - py * p.TW;
+                    const bool ok = half * NPH + j < NP2 && q < p.TH * p.TW && y0 + py < p.Hout && x0 + px < p.Wout;
+                    op[j] = ok ? (b * p.Hout + y0 + py) * p.Wout + x0 + px : -1;
+                    rv[j][0] = rv[j][1] = make_uint4(0, 0, 0, 0);
+                    if (p.res && ok) {
+                        const char* rp = p.res + ((size_t)op[j] * p.ldr + cb2) * 2;
+                        rv[j][0] = *reinterpret_cast<const uint4*>(rp);
+                        rv[j][1] = *reinterpret_cast<const uint4*>(rp + 16);
                     }
                 }
-                char* dst = p.out + (op * p.ldo + cb2) * 2;
+                f32x16 acc2[NPH];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    f32x8 f;
+                for (int j = 0; j < NPH; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = relu2 ? fmaxf(v[k * 8 + e], 0.f) : v[k * 8 + e];
-                    *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+                    for (int r = 0; r < 16; ++r) acc2[j][r] = bias2[r];
+#pragma unroll
+                for (int k = 0; k < KS2; ++k) {
+                    const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, a2[k]);
+#pragma unroll
+                    for (int j = 0; j < NPH; ++j) {
+                        const int q = (half * NPH + j) * 32 + n;
+                        const uint4 bv = *reinterpret_cast<const uint4*>(smem + (q < p.TH * p.TW ? q : 0) * PS2 + k * 32 + hh * 16);
+                        acc2[j] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc2[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NPH; ++j) {
+                    if (op[j] < 0) continue;
+                    char* dst = p.out + ((size_t)op[j] * p.ldo + cb2) * 2;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv[j][k]), f32x8);
+                        f32x8 f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = acc2[j][k * 8 + e] + rf[e];
+                            f[e] = relu2 ? fmaxf(v, 0.f) : v;
+                        }
+                        *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+                    }
                 }
             }
         }

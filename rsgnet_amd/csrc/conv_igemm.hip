@@ -210,6 +210,7 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     a.nchunks = d->in_c / t.CINB;
     a.KS = a.nchunks * d->kh * d->kw * (t.CINB / 16);
     a.wpk2 = nullptr; a.bias2 = nullptr; a.C2 = 0;
+    a.in0 = nullptr; a.wpk0 = nullptr; a.bias0 = nullptr; a.ldi0 = 0;
     grid = dim3(d->batch * t.tiles_y * t.tiles_x, cout_pad / (32 * t.WM));
     return 0;
 }
@@ -220,11 +221,21 @@ __global__ void __launch_bounds__(256) conv_pair_kernel(const ConvArgs p) {
     conv_body<DT, 64, 3, 3, 2, 2, 3, true>(p, blockIdx.x, 0, smem);
 }
 
+// Whole Bottleneck (pose_hrnet.py:85-101) in one launch: conv1 1x1 (head, into LDS) -> conv2 3x3 -> conv3 1x1 + x.
+template <class DT, int HEAD>
+__global__ void __launch_bounds__(256) bottleneck_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_body<DT, 64, 3, 3, 2, 2, 3, true, HEAD>(p, blockIdx.x, 0, smem);
+}
+int g_bottleneck_head = 2;     // rsg_tune("bottleneck_head", 1|2): 2 = two pixel groups in flight
+int g_bottleneck_debug = 0;    // rsg_tune("bottleneck_debug", 1): timing experiment, no residual read (WRONG results)
+
 // 3x3 stride-1 conv (C1 = 64 outputs, BatchNorm folded, ReLU) followed by a 1x1 conv (+BN, +residual, ReLU) in one
 // launch: `inner` describes the 3x3 conv (its out16/residual are ignored), the other arguments the 1x1 tail.
-extern "C" int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias,
-                             int32_t tail_out_c, const void* residual, int32_t res_ld, void* out16, int32_t out_ld,
-                             int32_t relu, void* stream) {
+static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t head_ld, const void* head_w,
+                       const float* head_bias, const void* tail_w_packed, const float* tail_bias,
+                       int32_t tail_out_c, const void* residual, int32_t res_ld, void* out16, int32_t out_ld,
+                       int32_t relu, void* stream) {
     if (!inner || !tail_w_packed || !tail_bias || !out16) RSG_FAIL("conv_pair: null pointer");
     if (inner->kh != 3 || inner->kw != 3 || inner->stride != 1 || inner->out_c != 64 || inner->in_c % 64 ||
         inner->up != 1 || inner->out_nchw_f32)
@@ -264,10 +275,53 @@ extern "C" int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_pack
     a.relu = relu ? -1 : 0; a.Cout = tail_out_c; a.CoutStore = tail_out_c;
     a.wpk2 = (const uint4*)tail_w_packed; a.bias2 = tail_bias; a.C2 = tail_out_c;
     if (t.lds < t.TH * t.TW * 144) t.lds = t.TH * t.TW * 144;
-    if (inner->dtype == RSG_BF16) RSG_LAUNCH(conv_pair_kernel<BF16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
-    else RSG_LAUNCH(conv_pair_kernel<F16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+    if (head_x) {
+        a.in0 = (const char*)head_x; a.ldi0 = head_ld; a.wpk0 = (const uint4*)head_w; a.bias0 = head_bias;
+        if (g_bottleneck_debug & 1) a.res = nullptr;
+        if (g_bottleneck_head == 1) {
+            if (inner->dtype == RSG_BF16) RSG_LAUNCH((bottleneck_kernel<BF16, 1>), dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+            else RSG_LAUNCH((bottleneck_kernel<F16, 1>), dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+        } else {
+            if (inner->dtype == RSG_BF16) RSG_LAUNCH((bottleneck_kernel<BF16, 2>), dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+            else RSG_LAUNCH((bottleneck_kernel<F16, 2>), dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+        }
+    } else {
+        if (inner->dtype == RSG_BF16) RSG_LAUNCH(conv_pair_kernel<BF16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+        else RSG_LAUNCH(conv_pair_kernel<F16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+    }
     RSG_CHECK_LAUNCH("conv_pair");
     return 0;
+}
+
+
+extern "C" int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias,
+                             int32_t tail_out_c, const void* residual, int32_t res_ld, void* out16, int32_t out_ld,
+                             int32_t relu, void* stream) {
+    return pair_launch(inner, nullptr, 0, nullptr, nullptr, tail_w_packed, tail_bias, tail_out_c, residual, res_ld,
+                       out16, out_ld, relu, stream);
+}
+
+// logical input channel l of the head's packed weights <-> channel of x (see conv_body HEAD)
+extern "C" int32_t rsg_bottleneck_head_perm(int32_t l) { return 128 * ((l >> 3) & 1) + 8 * (l >> 4) + (l & 7); }
+
+// Bottleneck without a downsample branch (pose_hrnet.py:85-101) in one launch.  x: [batch,h,w] pixels of 256
+// channels (stride x_ld); `inner` describes the 3x3 conv on the 64-channel map conv1 would have produced (its inp is
+// ignored); head_w_packed: conv1's weights, input channels permuted by rsg_bottleneck_head_perm before packing.
+extern "C" int rsg_bottleneck_fused(const rsg_conv_desc* inner, const void* x, int32_t x_ld, const void* head_w_packed,
+                                    const float* head_bias, const void* tail_w_packed, const float* tail_bias,
+                                    void* out16, int32_t out_ld, void* stream) {
+    if (!inner || !x || !head_w_packed || !head_bias) RSG_FAIL("bottleneck_fused: null pointer");
+    if (inner->in_c != 64 || inner->in_h != inner->out_h || inner->in_w != inner->out_w || inner->pad_y != 1 ||
+        inner->pad_x != 1)
+        RSG_FAIL("bottleneck_fused: the inner conv must be 3x3, stride 1, pad 1, 64 -> 64 channels");
+    if (x_ld < 256 || x_ld % 8 || (((uintptr_t)x | (uintptr_t)head_w_packed | (uintptr_t)head_bias) & 15))
+        RSG_FAIL("bottleneck_fused: x_ld=%d / alignment", x_ld);
+    if (x == out16) RSG_FAIL("bottleneck_fused: in-place operation is not supported (tiles read their neighbours' halo)");
+    rsg_conv_desc d = *inner;
+    d.in = x;                          // placeholder for the shared validation
+    d.in_ld = x_ld;
+    return pair_launch(&d, x, x_ld, head_w_packed, head_bias, tail_w_packed, tail_bias, 256, x, x_ld, out16, out_ld, 1,
+                       stream);
 }
 
 extern "C" int rsg_conv_igemm(const rsg_conv_desc* d, void* stream) {

@@ -60,6 +60,8 @@ SYMBOLS = {
     "rsg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "rsg_stem_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_conv_pair": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "rsg_bottleneck_head_perm": (C.c_int32, [_i]),
+    "rsg_bottleneck_fused": (C.c_int, [C.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "rsg_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     "rsg_conv_padded_cin": (C.c_int32, [_i]),
     "rsg_conv_packed_bytes": (C.c_size_t, [_i, _i, _i, _i]),
@@ -126,7 +128,8 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad"),
                          ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit"), ("RSGNET_HIP_CHAIN_PREFETCH", b"chain_prefetch"),
-                         ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k")):
+                         ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
+                         ("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug")):
             if os.environ.get(env):
                 l.rsg_tune(key, int(os.environ[env]))
         _lib = l

@@ -287,6 +287,24 @@ class Plan:
         self.flops += 2 * self.batch * x.H * x.W * (Oa * Ia * 9 + Ob * Ib)
         return out
 
+    def bottleneck(self, x: VT, blk, name="") -> VT:
+        """Record a whole Bottleneck without downsample branch (pose_hrnet.py:85-101) as ONE launch
+        (rsg_bottleneck_fused): conv1 is evaluated per tile into LDS, conv2 reads it there, conv3 adds x."""
+        s1, h1 = self.bn_fold(blk.bn1)
+        perm = [self.lib.rsg_bottleneck_head_perm(l) for l in range(256)]
+        w1 = blk.conv1.weight.detach().float().cpu()[:, perm].contiguous()
+        wp0, bo0, _, _ = self.pack_conv(w1, s1, h1, blk.conv1.bias)
+        sa, ha = self.bn_fold(blk.bn2)
+        wpa, boa, Ia, Oa = self.pack_conv(blk.conv2.weight, sa, ha, blk.conv2.bias)
+        sb, hb = self.bn_fold(blk.bn3)
+        wpb, bob, Ib, Ob = self.pack_conv(blk.conv3.weight, sb, hb, blk.conv3.bias)
+        out = self.new(x.H, x.W, 256, name=name)
+        self._record(dict(kind="bottleneck", x=x, wp0=wp0, bias0=bo0, wp=wpa, bias=boa, wp2=wpb, bias2=bob, res=None,
+                          out=out, out_f32=None, I=64, O=64, O2=256, kh=3, kw=3, stride=1, pad=(1, 1), up=(1, 0, 0),
+                          out_hw=(x.H, x.W), phys_hw=(x.H, x.W), relu=True, name=name), [x], [out])
+        self.flops += 2 * self.batch * x.H * x.W * (64 * 256 + 64 * 64 * 9 + 256 * 64)
+        return out
+
     def conv_multi(self, x: VT, parts, name="") -> List[VT]:
         """Several convs that read the SAME input with the same geometry as ONE conv with concatenated output
         channels (fan-out fusion): parts = [(conv, bn, relu)], every cout a multiple of 32.  Returns one
@@ -528,6 +546,29 @@ class Plan:
                 res.ld if res is not None else 0, out.ptr(), out.ld, 1)
         fn, nm = self.lib.rsg_conv_pair, r["name"]
         self.conv_log.append(dict(name=nm, cin=r["I"], cout=r["O2"], k=3, s=1, hw=r["out_hw"], pair=True))
+
+        def launch(stream):
+            rc = fn(*args, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((nm, launch))
+
+    def _lower_bottleneck(self, r):
+        x, out = r["x"], r["out"]
+        d = hip.ConvDesc()
+        d.inp, d.w_packed, d.bias, d.out16 = x.ptr(), r["wp"].data_ptr(), r["bias"].data_ptr(), out.ptr()
+        d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = self.batch, x.H, x.W, 64, 64
+        d.out_h, d.out_w, d.out_c, d.out_ld = x.H, x.W, 64, 64
+        d.kh, d.kw, d.stride, d.pad_y, d.pad_x = 3, 3, 1, 1, 1
+        d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, x.H, x.W
+        d.relu, d.dtype = 1, self.dtype
+        self._keep.append(d)
+        args = (C.byref(d), x.ptr(), x.ld, r["wp0"].data_ptr(), r["bias0"].data_ptr(), r["wp2"].data_ptr(),
+                r["bias2"].data_ptr(), out.ptr(), out.ld)
+        fn, nm = self.lib.rsg_bottleneck_fused, r["name"]
+        self.conv_log.append(dict(name=nm, cin=256, cout=256, k=3, s=1, hw=r["out_hw"], pair=True,
+                                  flops=float(2 * self.batch * x.H * x.W * (64 * 256 + 64 * 64 * 9 + 256 * 64))))
 
         def launch(stream):
             rc = fn(*args, stream)
@@ -890,6 +931,13 @@ class _BackboneMixin:
         res = x
         if blk.downsample is not None:
             res = self._unit(x, blk.downsample[0], blk.downsample[1], name=name + ".downsample")
+        # whole-Bottleneck fusion (rsg_bottleneck_fused) is opt-in: measured equal to conv1 + conv_pair in step time
+        # (both are bound by exposed latency at 2 workgroups per CU), so the proven pair stays
+        if hasattr(blk, "conv3") and blk.downsample is None and os.environ.get("RSGNET_HIP_BOTTLENECK", "0") == "1" and \
+                x.C == 256 and x.coff == 0 and blk.conv1.kernel_size == (1, 1) and blk.conv1.in_channels == 256 and \
+                blk.conv1.out_channels == 64 and blk.conv2.kernel_size == (3, 3) and blk.conv2.stride == (1, 1) and \
+                blk.conv2.out_channels == 64 and blk.conv3.kernel_size == (1, 1) and blk.conv3.out_channels == 256:
+            return self.bottleneck(x, blk, name=name + ".conv1+conv2+conv3")
         y = self._unit(x, blk.conv1, blk.bn1, relu=True, name=name + ".conv1")
         if hasattr(blk, "conv3"):
             c2, c3 = blk.conv2, blk.conv3

@@ -434,6 +434,61 @@ def test_conv_pair_equals_two_convs(shape):
     assert torch.equal(got, want[:, :C2])
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 48), (3, 13, 9), (1, 96, 72), (1, 5, 70)], ids=str)
+def test_bottleneck_fused_equals_three_convs(shape):
+    """rsg_bottleneck_fused (conv1 1x1 evaluated per tile into LDS -> conv2 3x3 -> conv3 1x1 + x, one launch) against
+    the three rsg_conv_igemm launches.  The head sums its 256 input channels in a different order, so the 16-bit
+    64-channel map may differ by one rounding step here and there: a few fp16 ulps on the output, not bit for bit."""
+    B, H, W = shape
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, 256, H, W, generator=g)
+    w0 = torch.randn(64, 256, 1, 1, generator=g) * (2.0 / 256) ** 0.5
+    s0, h0 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w1 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    s1, h1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    s2, h2 = torch.rand(256, generator=g) * 0.4 + 0.1, torch.randn(256, generator=g) * 0.1
+    m0, _ = run_conv(x, w0, s0, h0, relu=True)
+    m1, _ = run_conv(m0, w1, s1, h1, relu=True)
+    want, _ = run_conv(m1, w2, s2, h2, relu=True, residual=x)
+
+    def pack(w, s, h):
+        O, I, kh, kw = w.shape
+        wp = np.zeros(lib.rsg_conv_packed_bytes(I, O, kh, kw), np.uint8)
+        bo = np.zeros(O, np.float32)
+        hip.check(lib.rsg_pack_conv_weights_host(np.ascontiguousarray(w.numpy()).ctypes.data, s.numpy().ctypes.data,
+                                                 h.numpy().ctypes.data, None, I, O, kh, kw, 0, wp.ctypes.data, bo.ctypes.data))
+        return torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+
+    perm = [lib.rsg_bottleneck_head_perm(l) for l in range(256)]
+    assert sorted(perm) == list(range(256))
+    wp0, b0 = pack(w0[:, perm].contiguous(), s0, h0)
+    wp1, b1 = pack(w1, s1, h1)
+    wp2, b2 = pack(w2, s2, h2)
+    xin = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    out = torch.full((B, H, W, 256), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.ConvDesc()
+    d.inp, d.w_packed, d.bias = xin.data_ptr(), wp1.data_ptr(), b1.data_ptr()
+    d.out16 = out.data_ptr()
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, H, W, 64, 64
+    d.out_h, d.out_w, d.out_c, d.out_ld = H, W, 64, 64
+    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = 3, 3, 1, 1, 1
+    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, H, W
+    d.relu, d.dtype = 1, 0
+    hip.check(lib.rsg_bottleneck_fused(C.byref(d), xin.data_ptr(), 256, wp0.data_ptr(), b0.data_ptr(), wp2.data_ptr(),
+                                       b2.data_ptr(), out.data_ptr(), 256, _stream()), "bottleneck_fused")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    diff = (got - want).abs()
+    print(f"bottleneck {shape}: max diff {float(diff.max()):.3e}, differing {float((diff > 0).float().mean()):.4f}")
+    assert torch.allclose(got, want, rtol=4e-3, atol=4e-3)
+    assert float(diff.mean()) < 2e-4 * float(want.std())
+    assert lib.rsg_bottleneck_fused(C.byref(d), xin.data_ptr(), 256, wp0.data_ptr(), b0.data_ptr(), wp2.data_ptr(),
+                                    b2.data_ptr(), xin.data_ptr(), 256, _stream()) != 0          # in place: refused
+
+
 def test_stem_fused_equals_two_convs():
     """rsg_stem_fused (conv1 as 2x2 s2d conv + conv2 3x3 s2 in one launch) against the two-launch path, bit for bit,
     through the model plan: RSGNET_HIP_STEM=0/1 on the same weights and input."""
@@ -454,3 +509,26 @@ def test_stem_fused_equals_two_convs():
         finally:
             os.environ.pop("RSGNET_HIP_STEM", None)
     assert torch.equal(outs["0"], outs["1"])
+
+
+def test_bottleneck_fused_through_the_plan():
+    """RSGNET_HIP_BOTTLENECK=1 (opt-in) replaces conv1 + conv_pair of layer1's plain Bottlenecks by one launch each;
+    heatmaps stay within the golden tolerance of the default path."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import load_case
+    outs = {}
+    for flag in ("0", "1"):
+        os.environ["RSGNET_HIP_BOTTLENECK"] = flag
+        try:
+            cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+            model = model.cuda()
+            with torch.no_grad():
+                outs[flag] = model(x.cuda()).cpu()
+            names = [n for n, _ in list(model._plans.values())[0].ops]
+            assert sum("conv1+conv2+conv3" in n for n in names) == (3 if flag == "1" else 0)
+        finally:
+            os.environ.pop("RSGNET_HIP_BOTTLENECK", None)
+    scale = float(outs["0"].std())
+    assert float((outs["0"] - outs["1"]).abs().max()) < 5e-3 * scale
