@@ -79,6 +79,44 @@ def box_to_center_scale(box, aspect_ratio, pixel_std=200):
     return center, scale
 
 
+_DESC_DTYPE = np.dtype([("image", np.uint64), ("height", np.int32), ("width", np.int32), ("stride", np.int32),
+                        ("reserved", np.int32), ("m", np.float64, (6,))])      # struct rsg_crop_desc
+assert _DESC_DTYPE.itemsize == C.sizeof(hip.CropDesc)
+
+
+def affine_maps(centers, scales, rots, output_size) -> np.ndarray:
+    """``get_affine_transform`` for a batch of boxes at once: [n,2,3] float64.  Same float32 roundings of the point
+    triples as the scalar function (which the tests compare it with)."""
+    c = np.asarray(centers, np.float32).reshape(-1, 2)
+    sc = np.asarray(scales, np.float32).reshape(-1, 2)
+    n = len(c)
+    a = np.pi * (np.zeros(n) if rots is None else np.asarray(rots, np.float64)) / 180
+    ow, oh = output_size[0], output_size[1]
+    half = (sc[:, 0] * np.float32(200.0)) * -0.5                      # float32 * python float, as the reference
+    direction = np.stack([0 * np.cos(a) - half * np.sin(a), 0 * np.sin(a) + half * np.cos(a)], axis=1)     # float64
+    src = np.zeros((n, 3, 2), np.float32)
+    dst = np.zeros((n, 3, 2), np.float32)
+    src[:, 0] = c
+    src[:, 1] = c + direction
+    dst[:, 0] = [ow * 0.5, oh * 0.5]
+    dst[:, 1] = np.array([ow * 0.5, oh * 0.5]) + np.array([0, ow * -0.5], np.float32)
+    for t in (src, dst):
+        d = t[:, 0] - t[:, 1]
+        t[:, 2] = t[:, 1] + np.stack([-d[:, 1], d[:, 0]], axis=1)
+    p, q = src.astype(np.float64), dst.astype(np.float64)
+    x0, y0, x1, y1, x2, y2 = p[:, 0, 0], p[:, 0, 1], p[:, 1, 0], p[:, 1, 1], p[:, 2, 0], p[:, 2, 1]
+    det = x0 * (y1 - y2) - y0 * (x1 - x2) + (x1 * y2 - x2 * y1)
+    if np.any(det == 0):
+        raise ValueError("get_affine_transform: degenerate box (zero scale)")
+    out = np.empty((n, 2, 3))
+    for r in range(2):
+        u0, u1, u2 = q[:, 0, r], q[:, 1, r], q[:, 2, r]
+        out[:, r, 0] = (u0 * (y1 - y2) - y0 * (u1 - u2) + (u1 * y2 - u2 * y1)) / det
+        out[:, r, 1] = (x0 * (u1 - u2) - u0 * (x1 - x2) + (x1 * u2 - x2 * u1)) / det
+        out[:, r, 2] = (x0 * (y1 * u2 - y2 * u1) - y0 * (x1 * u2 - x2 * u1) + u0 * (x1 * y2 - x2 * y1)) / det
+    return out
+
+
 class CropProducer:
     """Batches of network inputs from uint8 pictures in device memory.
 
@@ -99,19 +137,17 @@ class CropProducer:
         centers = np.asarray(centers, np.float32).reshape(n, 2)
         scales = np.asarray(scales, np.float32).reshape(n, 2)
         dev = pictures[0].device
-        desc = (hip.CropDesc * n)()
+        maps = affine_maps(centers, scales, rots, (self.out_w, self.out_h))
+        rec = np.zeros(n, dtype=_DESC_DTYPE)
         for i, k in enumerate(picture_of_box):
             p = pictures[k]
             if p.device != dev or p.device.type != "cuda" or p.dtype != torch.uint8 or p.dim() != 3 \
                     or p.shape[2] != 3 or p.stride(2) != 1 or p.stride(1) != 3:
                 raise ValueError("CropProducer expects uint8 CUDA pictures [H,W,3] with interleaved channels")
-            m = get_affine_transform(centers[i], scales[i], 0.0 if rots is None else float(rots[i]),
-                                     (self.out_w, self.out_h))
-            d = desc[i]
-            d.image, d.height, d.width, d.stride = p.data_ptr(), p.shape[0], p.shape[1], p.stride(0)
-            for j, v in enumerate(m.reshape(6)):
-                d.m[j] = float(v)
-        table = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
+            rec[i] = (p.data_ptr(), p.shape[0], p.shape[1], p.stride(0), 0, 0)
+        rec["m"] = maps.reshape(n, 6)
+        desc = rec
+        table = torch.from_numpy(desc.view(np.uint8)).to(dev, non_blocking=False)
         if out is None:
             out = torch.empty(n, 3, self.out_h, self.out_w, dtype=torch.float32, device=dev)
         elif out.shape != (n, 3, self.out_h, self.out_w) or out.dtype != torch.float32 or not out.is_contiguous():

@@ -167,6 +167,16 @@ __global__ void __launch_bounds__(256) bilinear2x_kernel(const float* __restrict
         const float wy = sy - (float)y0;
         const float* r0 = in + ((size_t)pl * h + y0) * w;
         const float* r1 = in + ((size_t)pl * h + y1) * w;
+        // the 4 outputs read source columns a .. a+3 at most (rx < 1/2): 4 loads per row instead of 8
+        int a = (int)(rx * (float)(x4 * 4));
+        if (a > w - 1) a = w - 1;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = a + k < w ? a + k : w - 1;
+            s0[k] = r0[c];
+            s1[k] = r1[c];
+        }
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -176,9 +186,14 @@ __global__ void __launch_bounds__(256) bilinear2x_kernel(const float* __restrict
             if (xa > w - 1) xa = w - 1;
             const int xb = xa < w - 1 ? xa + 1 : xa;
             const float wx = sx - (float)xa;
+            const int da = xa - a, db = xb - a;           // 0..2 and 0..3
+            const float ta = da == 0 ? s0[0] : da == 1 ? s0[1] : s0[2];
+            const float tb = db == 0 ? s0[0] : db == 1 ? s0[1] : db == 2 ? s0[2] : s0[3];
+            const float ba = da == 0 ? s1[0] : da == 1 ? s1[1] : s1[2];
+            const float bb = db == 0 ? s1[0] : db == 1 ? s1[1] : db == 2 ? s1[2] : s1[3];
             // same association as ATen's upsample_bilinear2d: lerp in x on both rows, then in y
-            const float top = r0[xa] * (1.f - wx) + r0[xb] * wx;
-            const float bot = r1[xa] * (1.f - wx) + r1[xb] * wx;
+            const float top = ta * (1.f - wx) + tb * wx;
+            const float bot = ba * (1.f - wx) + bb * wx;
             float v = top * (1.f - wy) + bot * wy;
             if (sigmoid) v = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
             o[k] = v;

@@ -101,6 +101,14 @@ def test_affine_transform_mirror_matches_oracle():
     m = crops.get_affine_transform(np.array([50, 60], np.float32), np.array([0.96, 1.28], np.float32), 0, (192, 256))
     np.testing.assert_allclose(m, [[1.0, 0, 96 - 50], [0, 1.0, 128 - 60]], atol=1e-5)
     np.testing.assert_allclose(crops.affine_transform((50, 60), m), (96, 128), atol=1e-5)
+    # the batched form the producer uses is the scalar function, bit for bit
+    rs = np.random.RandomState(1)
+    c, s = rs.uniform(0, 500, (40, 2)).astype(np.float32), rs.uniform(0.2, 3, (40, 2)).astype(np.float32)
+    r = rs.uniform(-80, 80, 40)
+    r[::3] = 0
+    batched = crops.affine_maps(c, s, r, (192, 256))
+    for i in range(40):
+        assert np.array_equal(batched[i], crops.get_affine_transform(c[i], s[i], float(r[i]), (192, 256)))
     for box in ([10, 20, 50, 120], [0, 0, 300, 100]):
         c0, s0 = co.xywh_to_center_scale(*box, aspect_ratio=0.75)
         c1, s1 = crops.box_to_center_scale(box, 0.75)

