@@ -53,7 +53,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         const int py = q / p.TW, px = q - py * p.TW;
         const bool in_tile = q < p.TH * p.TW;
         const bool valid = in_tile && (y0 + py) < p.Hout && (x0 + px) < p.Wout;
-        pixoff[g] = (in_tile ? (py * p.SI) * p.RP + (px * p.SI) * PS : 0) + hh * 16;
+        pixoff[g] = (in_tile ? (py * p.SI) * p.RP + px * PS : 0) + hh * 16;     // columns: see `deint` below
         opix[g] = valid ? ((b * p.Hp + (y0 + py) * p.up + p.upy) * p.Wp + (x0 + px) * p.up + p.upx) : -1;
     }
 
@@ -154,6 +154,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
             for (int r = 0; r < 16; ++r) acc[g][r] = bias[r];
     }
 
+    // Stride-2 convs keep the even and the odd input columns of a tile row in two halves (slot = (x & 1) * HW + x / 2):
+    // consecutive output pixels then read consecutive slots for every tap, as at stride 1.  With the columns left
+    // interleaved the lanes of a read are two pixel pitches apart, a 2-way bank conflict on every B-operand read
+    // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.40-0.46 on exactly these kernels, profiles/r01i_sq_summary.json).
+    const bool deint = p.SI == 2;
+    const int HW = (p.TIW + 1) >> 1;
     const uint4* ap = p.wpk + (size_t)ct * p.KS * 64 + lane;
     const int total = p.TIH * p.TIW * CPP;
     const int iy0 = y0 * p.SI + p.oy0, ix0 = x0 * p.SI + p.ox0;
@@ -178,7 +184,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
                     const int pix = id / CPP, cg = id - pix * CPP;
                     const int ty = pix / p.TIW, tx = pix - ty * p.TIW;
                     const int iy = iy0 + ty, ix = ix0 + tx;
-                    lo[j] = ty * p.RP + tx * PS + cg * 16;
+                    lo[j] = ty * p.RP + (deint ? (tx & 1) * HW + (tx >> 1) : tx) * PS + cg * 16;
                     if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) {
                         const size_t e = (img + (size_t)iy * p.Win + ix) * p.ldi + ch * CINB + cg * 8;
                         r[j] = *reinterpret_cast<const uint4*>(p.in + e * 2);
@@ -195,8 +201,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         // ---- MFMA over the taps of this channel block: one scheduling region per k-step (A loads NPF
         // steps ahead, LDS reads one step ahead), else the compiler sinks the loads next to their uses
         auto boff = [&](int ks) {
-            const int t = ks / KPT, c = ks % KPT;
-            return (t / TAPW) * p.RP + (t % TAPW) * PS + c * 32;
+            const int t = ks / KPT, c = ks % KPT, kx = t % TAPW;
+            return (t / TAPW) * p.RP + (deint ? (kx & 1) * HW + (kx >> 1) : kx) * PS + c * 32;
         };
         uint4 bq[2][NT];
 #pragma unroll

@@ -63,6 +63,11 @@ static void tile_geometry(const rsg_conv_desc* d, TilePlan& t) {
     // bank progression (see chain.hip); >= the dense pitch
     const int base = t.TIW * PS, want = (t.TW * PS) % 256;
     t.RP = base + ((want - base) % 256 + 256) % 256;
+    if (d->stride == 2 && t.TW % 2 == 0) {
+        // de-interleaved columns (conv_body): an output row ends TW slots on, the next one starts 2 rows down
+        const int want2 = (t.TW * PS / 2) % 128;
+        t.RP = base + ((want2 - base) % 128 + 128) % 128;
+    }
     t.lds = t.TIH * t.RP;
     t.tiles_y = ceil_div(d->out_h, t.TH);
     t.tiles_x = ceil_div(d->out_w, t.TW);
