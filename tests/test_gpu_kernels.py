@@ -126,6 +126,27 @@ def test_conv_igemm_matches_cpu(case):
         assert float(got16[:, Cout:].abs().max()) == 0.0, "padding channels must be written as zeros"
 
 
+def test_conv_stride2_shape_sweep():
+    """Stride-2 3x3 convs keep even and odd input columns in separate LDS halves (conv_body `deint`): seeded random
+    shapes with odd/even sizes, tiles narrower than the map, every channel-block width."""
+    rs = np.random.RandomState(2)
+    for it in range(14):
+        H, W = int(rs.randint(2, 41)), int(rs.randint(2, 41))
+        Cin = int(rs.choice([3, 32, 64, 128, 256]))
+        Cout = int(rs.choice([32, 64, 128, 256]))
+        B = int(rs.randint(1, 4))
+        g = torch.Generator().manual_seed(100 + it)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+        scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+        got16, got32 = run_conv(x, w, scale, shift, None, stride=2, relu=bool(it & 1), want_f32=True)
+        want = ref_conv(x, w, scale, shift, None, 2, bool(it & 1), None)
+        tol32 = 1e-4 * float(want.abs().max()) + 1e-5
+        assert float((got32.double() - want).abs().max()) <= tol32, (it, B, Cin, Cout, H, W)
+        err16 = (got16[:, :Cout].double() - want).abs()
+        assert float((err16 - want.abs() * 2.0 ** -10).max()) <= tol32, (it, B, Cin, Cout, H, W)
+
+
 def test_conv_bias_only_classifier_and_bf16():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(2, 32, 16, 12, generator=g)
