@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flip-test", action="store_true",
                     help="a step = flip-tested heatmaps: one forward over [x ; x mirrored] + the fused merge")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="a step = person boxes -> crops (rsg_crop_warp_affine) -> flip-tested heatmaps -> decoded "
+                         "keypoints, from uint8 pictures resident in HBM (SURVEY 8(f) #1, #3, #4 around the forward)")
     ap.add_argument("--per-op", default="", help="write a per-op timing table (JSON) to this path")
     a = ap.parse_args()
 
@@ -220,11 +223,28 @@ def main():
     x = synth_input(batch, wh, seed=rank).to(dev)          # resident in HBM before the timed region
 
     joints = WORKLOADS[a.workload][3]
+    if a.pipeline:
+        a.flip_test = True
     if a.flip_test:
         from rsgnet_amd.flip import forward_flip_test
+    if a.pipeline:
+        import numpy as np
+        from rsgnet_amd import crops as crops_
+        from rsgnet_amd.decode import get_final_preds
+        rs = np.random.RandomState(rank)
+        pictures = [torch.from_numpy(rs.randint(0, 256, (480, 640, 3)).astype(np.uint8)).to(dev) for _ in range(8)]
+        which = [i % 8 for i in range(batch)]
+        cs = [crops_.box_to_center_scale([rs.uniform(0, 400), rs.uniform(0, 200), rs.uniform(60, 200),
+                                          rs.uniform(120, 280)], wh[0] / wh[1]) for _ in range(batch)]
+        centers, scales = np.stack([c for c, _ in cs]), np.stack([s_ for _, s_ in cs])
+        producer = crops_.CropProducer(wh)
 
     def step():
         with torch.no_grad():
+            if a.pipeline:
+                xin = producer(pictures, which, centers, scales, out=x)
+                hm = forward_flip_test(model, xin, FLIP_PAIRS[joints])
+                return get_final_preds(hm, centers, scales)[0]
             if a.flip_test:
                 return forward_flip_test(model, x, FLIP_PAIRS[joints])
             return model(x)
@@ -275,7 +295,8 @@ def main():
         ach = dom["gflop"] / (dom["us"] / 1e3)                   # GFLOP / ms = TFLOP/s
         line = {
             "metric": {"hrnet_w32_256x192": "images/sec HRNet-W32 256x192 bs64 fwd"}.get(
-                a.workload, f"images/sec {a.workload} bs{batch} fwd") + (" flip-test" if a.flip_test else ""),
+                a.workload, f"images/sec {a.workload} bs{batch} fwd") + (" flip-test" if a.flip_test else "")
+                + (" boxes->crops->keypoints" if a.pipeline else ""),
             "value": round(imgs, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": model.compute_dtype, "data": "synthetic",

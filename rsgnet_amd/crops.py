@@ -147,7 +147,11 @@ class CropProducer:
             rec[i] = (p.data_ptr(), p.shape[0], p.shape[1], p.stride(0), 0, 0)
         rec["m"] = maps.reshape(n, 6)
         desc = rec
-        table = torch.from_numpy(desc.view(np.uint8)).to(dev, non_blocking=False)
+        # pinned staging + asynchronous copy: the host never waits for the stream (torch's host allocator keeps the
+        # pinned block alive until the copy has run)
+        staged = torch.empty(desc.nbytes, dtype=torch.uint8, pin_memory=True)
+        staged.numpy()[:] = desc.view(np.uint8)
+        table = staged.to(dev, non_blocking=True)
         if out is None:
             out = torch.empty(n, 3, self.out_h, self.out_w, dtype=torch.float32, device=dev)
         elif out.shape != (n, 3, self.out_h, self.out_w) or out.dtype != torch.float32 or not out.is_contiguous():

@@ -16,8 +16,12 @@ def get_final_preds(batch_heatmaps: torch.Tensor, center, scale, post_process: b
         raise ValueError("get_final_preds expects an fp32 NCHW CUDA tensor")
     h = h.contiguous()
     B, J, H, W = h.shape
-    c = torch.as_tensor(center, dtype=torch.float32).reshape(B, 2).to(h.device).contiguous()
-    s = torch.as_tensor(scale, dtype=torch.float32).reshape(B, 2).to(h.device).contiguous()
+    def upload(v):      # host arrays go through pinned memory, asynchronously: the caller's thread does not wait for the stream
+        t = torch.as_tensor(v, dtype=torch.float32).reshape(B, 2)
+        if t.device.type == "cpu":
+            t = t.contiguous().pin_memory().to(h.device, non_blocking=True)
+        return t.to(h.device).contiguous()
+    c, s = upload(center), upload(scale)
     preds = torch.empty(B, J, 2, dtype=torch.float32, device=h.device)
     maxvals = torch.empty(B, J, 1, dtype=torch.float32, device=h.device)
     st = torch.cuda.current_stream(h.device).cuda_stream
