@@ -28,6 +28,9 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
     constexpr int PSS = 48;                                // s2d pixel: 16 ch * 2 B + 16 pad
     constexpr int PS1 = 144;                               // conv1 pixel: 64 ch * 2 B + 16 pad
     constexpr int RPS = CS * PSS, RP1 = C1 * PS1;
+    // conv2 has stride 2: the conv1 window keeps its even and odd columns in two halves of a row (slot = (c & 1) * HW1 +
+    // c / 2), so that consecutive output pixels read consecutive slots (no 2-way LDS bank conflict; cf. conv_body `deint`)
+    constexpr int HW1 = (C1 + 1) / 2;
     constexpr int NP1 = (R1 * C1 + 31) / 32;               // 32-pixel groups of the conv1 window
     constexpr int NT1 = (NP1 + 1) / 2;                     // per wave column (WN = 2)
     constexpr int NP2 = (TH2 * TW2 + 31) / 32, NT2 = (NP2 + 1) / 2;
@@ -134,7 +137,8 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
                 f32x8 f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = real ? acc[g][k * 8 + e] : 0.f;
-                *reinterpret_cast<uint4*>(sH + r * RP1 + c * PS1 + (cbase + k * 8) * 2) = __builtin_bit_cast(uint4, DT::relu_pack(f));
+                *reinterpret_cast<uint4*>(sH + r * RP1 + ((c & 1) * HW1 + (c >> 1)) * PS1 + (cbase + k * 8) * 2) =
+                    __builtin_bit_cast(uint4, DT::relu_pack(f));
             }
         }
     }
@@ -148,7 +152,7 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
         const int q = (wn * NT2 + g) * 32 + n;
         const int qq = q < TH2 * TW2 ? q : 0;
         const int py = qq / TW2, px = qq - py * TW2;
-        ho[g] = (2 * py) * RP1 + (2 * px) * PS1 + hh * 16;
+        ho[g] = (2 * py) * RP1 + px * PS1 + hh * 16;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             acc2[g][r4 * 4 + 0] = bv2[r4].x; acc2[g][r4 * 4 + 1] = bv2[r4].y;
@@ -162,7 +166,10 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
     for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
     // B fragments NB - 1 k-steps ahead: one MFMA per step cannot cover an LDS read issued one step earlier
     constexpr int NB = 4;
-    auto hoff = [&](int ks) { const int t = ks >> 2, c = ks & 3; return (t / 3) * RP1 + (t % 3) * PS1 + c * 32; };
+    auto hoff = [&](int ks) {
+        const int t = ks >> 2, c = ks & 3, kx = t % 3;
+        return (t / 3) * RP1 + ((kx & 1) * HW1 + (kx >> 1)) * PS1 + c * 32;
+    };
     uint4 bq[NB][NT2];
 #pragma unroll
     for (int s0 = 0; s0 < NB - 1; ++s0)
