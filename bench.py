@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="a step = person boxes -> crops (rsg_crop_warp_affine) -> flip-tested heatmaps -> decoded "
                          "keypoints, from uint8 pictures resident in HBM (SURVEY 8(f) #1, #3, #4 around the forward)")
+    ap.add_argument("--from-host", action="store_true",
+                    help="a step starts from the fp32 batch in pinned HOST memory (PCIe-inclusive rate; never the "
+                         "headline value, which has inputs resident in HBM)")
     ap.add_argument("--per-op", default="", help="write a per-op timing table (JSON) to this path")
     a = ap.parse_args()
 
@@ -239,8 +242,12 @@ def main():
         centers, scales = np.stack([c for c, _ in cs]), np.stack([s_ for _, s_ in cs])
         producer = crops_.CropProducer(wh)
 
+    x_host = x.cpu().pin_memory() if a.from_host else None
+
     def step():
         with torch.no_grad():
+            if a.from_host:
+                x.copy_(x_host, non_blocking=True)
             if a.pipeline:
                 xin = producer(pictures, which, centers, scales, out=x)
                 hm = forward_flip_test(model, xin, FLIP_PAIRS[joints])
@@ -296,7 +303,7 @@ def main():
         line = {
             "metric": {"hrnet_w32_256x192": "images/sec HRNet-W32 256x192 bs64 fwd"}.get(
                 a.workload, f"images/sec {a.workload} bs{batch} fwd") + (" flip-test" if a.flip_test else "")
-                + (" boxes->crops->keypoints" if a.pipeline else ""),
+                + (" boxes->crops->keypoints" if a.pipeline else "") + (" from host memory" if a.from_host else ""),
             "value": round(imgs, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": model.compute_dtype, "data": "synthetic",
