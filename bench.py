@@ -241,6 +241,7 @@ def main():
                                           rs.uniform(120, 280)], wh[0] / wh[1]) for _ in range(batch)]
         centers, scales = np.stack([c for c, _ in cs]), np.stack([s_ for _, s_ in cs])
         producer = crops_.CropProducer(wh)
+        x2 = torch.empty(2 * batch, 3, wh[1], wh[0], device=dev)
 
     x_host = x.cpu().pin_memory() if a.from_host else None
 
@@ -249,8 +250,8 @@ def main():
             if a.from_host:
                 x.copy_(x_host, non_blocking=True)
             if a.pipeline:
-                xin = producer(pictures, which, centers, scales, out=x)
-                hm = forward_flip_test(model, xin, FLIP_PAIRS[joints])
+                xin = producer(pictures, which, centers, scales, out=x2, with_flip=True)
+                hm = forward_flip_test(model, xin, FLIP_PAIRS[joints], prepared=True)
                 return get_final_preds(hm, centers, scales)[0]
             if a.flip_test:
                 return forward_flip_test(model, x, FLIP_PAIRS[joints])

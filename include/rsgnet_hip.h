@@ -288,10 +288,11 @@ struct rsg_crop_desc {
     int32_t reserved;
     double m[6];             /* forward 2x3 map source -> crop, row-major (get_affine_transform, transforms.py:64) */
 };
-/* out: fp32 [batch,3,out_h,out_w]; mean3/std3: HOST arrays of 3 (per output channel); swap_rb != 0 reverses the
- * channel order on the way (cv2.COLOR_BGR2RGB, DATASET.COLOR_RGB). */
-int rsg_crop_warp_affine(const struct rsg_crop_desc* crops_dev, float* out_nchw, int32_t batch, int32_t out_h,
-                         int32_t out_w, const float* mean3_host, const float* std3_host, int32_t swap_rb,
+/* out: fp32 [batch,3,out_h,out_w]; out_flipped (may be NULL): the same crops mirrored left-right, i.e. `input.flip(3)`
+ * of the flip test (lib/core/function.py:400-402), written in the same pass; mean3/std3: HOST arrays of 3 (per output
+ * channel); swap_rb != 0 reverses the channel order on the way (cv2.COLOR_BGR2RGB, DATASET.COLOR_RGB). */
+int rsg_crop_warp_affine(const struct rsg_crop_desc* crops_dev, float* out_nchw, float* out_flipped_nchw, int32_t batch,
+                         int32_t out_h, int32_t out_w, const float* mean3_host, const float* std3_host, int32_t swap_rb,
                          void* stream);
 
 #ifdef __cplusplus

@@ -130,7 +130,10 @@ class CropProducer:
         self.color_rgb = bool(color_rgb)
 
     def __call__(self, pictures: Sequence[torch.Tensor], picture_of_box: Sequence[int], centers, scales,
-                 rots: Optional[Sequence[float]] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 rots: Optional[Sequence[float]] = None, out: Optional[torch.Tensor] = None,
+                 with_flip: bool = False) -> torch.Tensor:
+        """Returns the input batch [n,3,H,W]; with_flip: [2n,3,H,W] = [crops ; crops mirrored left-right], the batch the
+        flip test forwards in one go (rsgnet_amd.flip.forward_flip_test(..., prepared=True))."""
         n = len(picture_of_box)
         if n == 0:
             raise ValueError("CropProducer: empty batch")
@@ -152,12 +155,14 @@ class CropProducer:
         staged = torch.empty(desc.nbytes, dtype=torch.uint8, pin_memory=True)
         staged.numpy()[:] = desc.view(np.uint8)
         table = staged.to(dev, non_blocking=True)
+        rows = 2 * n if with_flip else n
         if out is None:
-            out = torch.empty(n, 3, self.out_h, self.out_w, dtype=torch.float32, device=dev)
-        elif out.shape != (n, 3, self.out_h, self.out_w) or out.dtype != torch.float32 or not out.is_contiguous():
-            raise ValueError("CropProducer: out must be a contiguous fp32 [n,3,H,W] tensor")
+            out = torch.empty(rows, 3, self.out_h, self.out_w, dtype=torch.float32, device=dev)
+        elif out.shape != (rows, 3, self.out_h, self.out_w) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("CropProducer: out must be a contiguous fp32 [n,3,H,W] tensor ([2n,3,H,W] with_flip)")
         st = torch.cuda.current_stream(dev).cuda_stream
-        hip.check(hip.lib().rsg_crop_warp_affine(table.data_ptr(), out.data_ptr(), n, self.out_h, self.out_w,
+        hip.check(hip.lib().rsg_crop_warp_affine(table.data_ptr(), out.data_ptr(), out[n:].data_ptr() if with_flip else None,
+                                                 n, self.out_h, self.out_w,
                                                  self._mean, self._std, int(self.color_rgb), st), "crop_warp_affine")
         table.record_stream(torch.cuda.current_stream(dev))
         return out

@@ -22,7 +22,8 @@ __device__ __forceinline__ int sat_rint(double v) {
 }
 
 __global__ void __launch_bounds__(256) crop_warp_kernel(const rsg_crop_desc* __restrict__ crops,
-                                                        float* __restrict__ out, int out_h, int out_w, int swap_rb,
+                                                        float* __restrict__ out, float* __restrict__ out_flip, int out_h, int out_w,
+                                                        int swap_rb,
                                                         float mean0, float mean1, float mean2, float std0,
                                                         float std1, float std2) {
     const int x = blockIdx.x * 64 + threadIdx.x;            // a wave covers 64 pixels of one row
@@ -66,13 +67,15 @@ __global__ void __launch_bounds__(256) crop_warp_kernel(const rsg_crop_desc* __r
     for (int k = 0; k < 3; ++k) {
         const int v = min(swap_rb ? acc[2 - k] : acc[k], 255);
         // ToTensor: uint8 -> float / 255; Normalize: (t - mean) / std, each correctly rounded in fp32
-        o[k * plane] = ((float)v / 255.f - mean[k]) / sd[k];
+        const float t = ((float)v / 255.f - mean[k]) / sd[k];
+        o[k * plane] = t;
+        if (out_flip) out_flip[((long)b * 3 + k) * plane + (long)y * out_w + (out_w - 1 - x)] = t;   // x.flip(3)
     }
 }
 
-extern "C" int rsg_crop_warp_affine(const struct rsg_crop_desc* crops_dev, float* out_nchw, int32_t batch, int32_t out_h,
-                                    int32_t out_w, const float* mean3_host, const float* std3_host,
-                                    int32_t swap_rb, void* stream) {
+extern "C" int rsg_crop_warp_affine(const struct rsg_crop_desc* crops_dev, float* out_nchw, float* out_flipped_nchw,
+                                    int32_t batch, int32_t out_h, int32_t out_w, const float* mean3_host,
+                                    const float* std3_host, int32_t swap_rb, void* stream) {
     if (!crops_dev || !out_nchw || !mean3_host || !std3_host) RSG_FAIL("crop_warp_affine: null pointer");
     if (batch < 1 || batch > 65535 || out_h < 1 || out_h > 262140 || out_w < 1 || out_w > 32767)
         RSG_FAIL("crop_warp_affine: batch=%d size=%dx%d out of range", batch, out_h, out_w);
@@ -80,7 +83,7 @@ extern "C" int rsg_crop_warp_affine(const struct rsg_crop_desc* crops_dev, float
         if (!(std3_host[k] != 0.f)) RSG_FAIL("crop_warp_affine: std[%d] is zero", k);
     static_assert(sizeof(rsg_crop_desc) == 72, "rsg_crop_desc layout");
     RSG_LAUNCH(crop_warp_kernel, dim3((out_w + 63) / 64, (out_h + 3) / 4, batch), dim3(64, 4), 0, (hipStream_t)stream,
-               crops_dev, out_nchw, out_h, out_w, swap_rb ? 1 : 0, mean3_host[0],
+               crops_dev, out_nchw, out_flipped_nchw, out_h, out_w, swap_rb ? 1 : 0, mean3_host[0],
                mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
     RSG_CHECK_LAUNCH("crop_warp_affine");
     return 0;

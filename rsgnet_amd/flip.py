@@ -36,12 +36,13 @@ def flip_merge(h: torch.Tensor, h_flipped: torch.Tensor, flip_pairs, shift_heatm
     return out
 
 
-def forward_flip_test(model, x: torch.Tensor, flip_pairs, shift_heatmap: bool = True) -> torch.Tensor:
+def forward_flip_test(model, x: torch.Tensor, flip_pairs, shift_heatmap: bool = True, prepared: bool = False) -> torch.Tensor:
     """Flip-tested joint heatmaps [B,J,h,w]: one forward over [x ; x mirrored] and the fused merge.
+    prepared: ``x`` already is that 2B batch (``CropProducer(..., with_flip=True)`` writes both halves in its one pass).
 
     For ``pose_rsgnet`` the merged map is ``kpt_scores`` (item 1 of the 4-tuple), as in
     ``rsgnet_validate`` (lib/core/function.py:389-427)."""
-    B = x.shape[0]
-    out = model(torch.cat((x, x.flip(3)), dim=0))
+    B = x.shape[0] // 2 if prepared else x.shape[0]
+    out = model(x if prepared else torch.cat((x, x.flip(3)), dim=0))
     heat = out if torch.is_tensor(out) else out[1]
     return flip_merge(heat[:B], heat[B:], flip_pairs, shift_heatmap)

@@ -100,7 +100,7 @@ SYMBOLS = {
     "rsg_bce_loss": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, _vp, _i, _vp, _vp, _vp]),
     "rsg_relation_target_vec": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _vp]),
-    "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
+    "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

@@ -149,5 +149,8 @@ def test_crop_kernel_feeds_the_network_input_shape():
     out = crops.CropProducer((288, 384))([pic], [0, 0], [c, c], [s, s])
     assert out.shape == (2, 3, 384, 288) and out.dtype == torch.float32
     assert torch.equal(out[0], out[1])
+    both = crops.CropProducer((288, 384))([pic], [0, 0], [c, c], [s, s], with_flip=True)     # [crops ; crops.flip(3)]
+    assert both.shape == (4, 3, 384, 288)
+    assert torch.equal(both[:2], out) and torch.equal(both[2:], out.flip(3))
     with pytest.raises(ValueError):
         crops.CropProducer((192, 256))([pic.cpu()], [0], [c], [s])

@@ -245,6 +245,8 @@ def test_eval_pipeline_picture_to_keypoints():
     with torch.no_grad():
         hm = forward_flip_test(model, x, COCO_FLIP_PAIRS)
         preds, maxvals = get_final_preds(hm, centers, scales)
+        x2 = crops.CropProducer((192, 256))([torch.from_numpy(pic).cuda()], [0] * 4, centers, scales, with_flip=True)
+        assert torch.equal(forward_flip_test(model, x2, COCO_FLIP_PAIRS, prepared=True), hm)
     want_hm = po.flip_test_merge(po.hrnet_forward(sd, cfg, want_x), po.hrnet_forward(sd, cfg, want_x.flip(3)),
                                  COCO_FLIP_PAIRS)
     assert _stats("pipeline heatmaps", hm.cpu(), want_hm.numpy()) < REL_TOL * float(want_hm.std())

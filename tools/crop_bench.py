@@ -37,7 +37,7 @@ table = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).cuda()
 st = torch.cuda.current_stream().cuda_stream
 e0.record()
 for _ in range(N):
-    hip.lib().rsg_crop_warp_affine(table.data_ptr(), out.data_ptr(), B, 256, 192, prod._mean, prod._std, 1, st)
+    hip.lib().rsg_crop_warp_affine(table.data_ptr(), out.data_ptr(), None, B, 256, 192, prod._mean, prod._std, 1, st)
 e1.record()
 torch.cuda.synchronize()
 k_us = e0.elapsed_time(e1) * 1e3 / N
