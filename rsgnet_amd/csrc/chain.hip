@@ -393,7 +393,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 template <class DT, int C, int WM, int WN, int NT>
 __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    chain_body<DT, C, WM, WN, NT>(p, blockIdx.x, smem);
+    chain_body<DT, C, WM, WN, NT>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), smem);      // both row bands of an image on one XCD
 }
 
 // Grouped launch: up to 4 chains (different branches of one HighResolutionModule) in ONE grid; the
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     int i = 0;       // constant indices: first[] arrives with one batch of scalar loads (see group.hip)
 #pragma unroll
     for (int j = 1; j < RSG_CHAIN_GROUP_MAX; ++j) i += (j < g.n && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
-    const int bid = blockIdx.x - g.first[i];
+    const int bid = rsg_xcd_tile(blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);   // an item's row bands of one image on one XCD
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
             if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6>(g.a[i], bid, smem, pf);

@@ -85,3 +85,19 @@ struct BF16 {
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// XCD-aware tile order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own
+// 4 MB L2, so neighbouring tiles of one picture (which share halo rows) and the two row bands of a chain image would
+// land in 8 different L2s.  This permutation gives every XCD one contiguous range of the n logical tiles instead:
+// residue class c = l % 8 (one XCD, whatever the phase of the first id) takes tiles [start(c), start(c) + size(c)).
+#ifndef RSG_XCD_SWIZZLE
+#define RSG_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ int rsg_xcd_tile(int l, int n) {
+#if RSG_XCD_SWIZZLE
+    const int c = l & 7, per = n >> 3, rem = n & 7;
+    return c * per + (c < rem ? c : rem) + (l >> 3);
+#else
+    return l;
+#endif
+}

@@ -35,7 +35,10 @@ template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT>
 __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RSG_CSTAMP(0);
-    conv_body<DT, CINB, TAPH, TAPW, WM, WN, NT>(p, blockIdx.x, blockIdx.y, smem);
+    // the XCD of a workgroup follows blockIdx.x + blockIdx.y * gridDim.x: with gridDim.x a multiple of 8 (or one row)
+    // that is blockIdx.x mod 8, and every output-channel tile of an input tile stays on the input tile's XCD
+    const bool swz = gridDim.y == 1 || (gridDim.x & 7) == 0;
+    conv_body<DT, CINB, TAPH, TAPW, WM, WN, NT>(p, swz ? rsg_xcd_tile(blockIdx.x, gridDim.x) : (int)blockIdx.x, blockIdx.y, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -223,14 +226,14 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
 template <class DT>
 __global__ void __launch_bounds__(256) conv_pair_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv_body<DT, 64, 3, 3, 2, 2, 3, true>(p, blockIdx.x, 0, smem);
+    conv_body<DT, 64, 3, 3, 2, 2, 3, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 
 // Whole Bottleneck (pose_hrnet.py:85-101) in one launch: conv1 1x1 (head, into LDS) -> conv2 3x3 -> conv3 1x1 + x.
 template <class DT, int HEAD>
 __global__ void __launch_bounds__(256) bottleneck_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    conv_body<DT, 64, 3, 3, 2, 2, 3, true, HEAD>(p, blockIdx.x, 0, smem);
+    conv_body<DT, 64, 3, 3, 2, 2, 3, true, HEAD>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 int g_bottleneck_head = 2;     // rsg_tune("bottleneck_head", 1|2): 2 = two pixel groups in flight
 int g_bottleneck_debug = 0;    // rsg_tune("bottleneck_debug", 1): timing experiment, no residual read (WRONG results)

@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs g) {
     // the by-value table makes hipcc copy the whole table to scratch)
     const ConvArgs a = g.conv[i];
     const int nbx = g.nbx[i];
-    const int bx = local % nbx, by = local / nbx;
+    const int tile = rsg_xcd_tile(local, g.first[i + 1] - g.first[i]);      // an item's neighbouring tiles on one XCD
+    const int bx = tile % nbx, by = tile / nbx;
 #define RSG_V(ID, C, TH_, TW_, WM_, WN_, NT_) \
     case ID: conv_body<DT, C, TH_, TW_, WM_, WN_, NT_>(a, bx, by, smem); break;
 #define RSG_V5(BASE, C, TH_, TW_)        \

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;               // 2 output-channel tiles x 2 pixel columns
     const int n = lane & 31, hh = lane >> 5;
-    int bx = blockIdx.x;
+    int bx = rsg_xcd_tile(blockIdx.x, gridDim.x);          // the tiles of a picture on one XCD (shared halo in its L2)
     const int tix = bx % p.tiles_x;
     bx /= p.tiles_x;
     const int tiy = bx % p.tiles_y;
