@@ -95,6 +95,22 @@ def test_batch_sharding_is_invariant():
     assert torch.equal(full, halves)
 
 
+@pytest.mark.parametrize("name", ["hrnet_w32_256x192", "rsgnet_w32_256x192_coco"])
+def test_ragged_batches_agree_with_each_other(name):
+    """Batches of 1, 3 and 7 crops (fewer workgroups than XCDs, odd tile counts, the last workgroup of a two-image
+    chain half empty) give, crop by crop, the bits a batch of 11 gives."""
+    cfg, model, sd, x, gold = load_case(name)
+    from rsgnet_amd.weights import synth_input
+    x11 = synth_input(11, (192, 256), 4).cuda()
+    model = model.cuda()
+    pick = (lambda o: o) if name.startswith("hrnet") else (lambda o: o[1])
+    with torch.no_grad():
+        full = pick(model(x11)).clone()
+        parts = torch.cat([pick(model(x11[:1])).clone(), pick(model(x11[1:4])).clone(), pick(model(x11[4:])).clone()])
+    assert torch.isfinite(full).all()
+    assert torch.equal(full, parts)
+
+
 @pytest.mark.parametrize("tag", ["rsgnet_w32_256x192_coco", "rsgnet_w32_256x192_crowdpose",
                                  "rsgnet_w48_384x288_coco"])
 def test_rsgnet_w32_golden(tag):
