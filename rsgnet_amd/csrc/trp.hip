@@ -73,41 +73,50 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
     // pieces (coalesced) into a double-buffered LDS tile; per-wave scattered global loads of the same
     // data saturated the address path (295 -> 145 us at S = 3072).  Rows are padded to an odd number of
     // 16-byte slots so the 16-lane ds_read_b128 groups hit 16 different banks.
-    __shared__ uint4 tk[2][32 * RSK];
-    __shared__ uint4 tg[2][CP * 5];
+    // A stage is KT tiles of 32 keys: one barrier per stage.  A barrier per 32-key tile (~450 issue cycles of work per
+    // wave) cost as much as a quarter of the loop.
+    constexpr int KT = 4;
+    __shared__ uint4 tk[2][KT][32 * RSK];
+    __shared__ uint4 tg[2][KT][CP * 5];
     constexpr int NPIECE = NKP + (MODE == TRP_ATTN ? NGP : 0);
-    constexpr int PPT = (NPIECE + 255) / 256;             // pieces per thread
+    constexpr int PPT = (NPIECE + 255) / 256;             // pieces per thread and tile
     if (MODE == TRP_ATTN)
-        for (int i = threadIdx.x; i < 2 * CP * 5; i += 256) (&tg[0][0])[i] = make_uint4(0, 0, 0, 0);
-    auto fetch = [&](int j0, uint4 (&v)[PPT]) {
+        for (int i = threadIdx.x; i < 2 * KT * CP * 5; i += 256) (&tg[0][0][0])[i] = make_uint4(0, 0, 0, 0);
+    auto fetch = [&](int jstage, uint4 (&v)[KT][PPT]) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int p = threadIdx.x + k * 256;
-            v[k] = make_uint4(0, 0, 0, 0);
-            if (p < NKP) {
-                const int row = p / PK, piece = p % PK;
-                v[k] = *reinterpret_cast<const uint4*>(xb + ((size_t)(j0 + row) * a.ldx + piece * 8) * 2);
-            } else if (p < NPIECE) {
-                const int q = p - NKP, row = q >> 2, piece = q & 3;
-                v[k] = *reinterpret_cast<const uint4*>(a.gT + (((size_t)b * C + row) * a.S + j0 + piece * 8) * 2);
+        for (int u = 0; u < KT; ++u) {
+            const int j0 = jstage + u * 32;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = threadIdx.x + k * 256;
+                v[u][k] = make_uint4(0, 0, 0, 0);
+                if (p < NKP) {
+                    const int row = p / PK, piece = p % PK;
+                    v[u][k] = *reinterpret_cast<const uint4*>(xb + ((size_t)(j0 + row) * a.ldx + piece * 8) * 2);
+                } else if (p < NPIECE) {
+                    const int q = p - NKP, row = q >> 2, piece = q & 3;
+                    v[u][k] = *reinterpret_cast<const uint4*>(a.gT + (((size_t)b * C + row) * a.S + j0 + piece * 8) * 2);
+                }
             }
         }
     };
-    auto stash = [&](int buf, const uint4 (&v)[PPT]) {
+    auto stash = [&](int buf, const uint4 (&v)[KT][PPT]) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int p = threadIdx.x + k * 256;
-            if (p < NKP) tk[buf][(p / PK) * RSK + p % PK] = v[k];
-            else if (p < NPIECE) tg[buf][((p - NKP) >> 2) * 5 + ((p - NKP) & 3)] = v[k];
-        }
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int p = threadIdx.x + k * 256;
+                if (p < NKP) tk[buf][u][(p / PK) * RSK + p % PK] = v[u][k];
+                else if (p < NPIECE) tg[buf][u][((p - NKP) >> 2) * 5 + ((p - NKP) & 3)] = v[u][k];
+            }
     };
-    auto do_tile = [&](int j0, int buf) {
+    auto do_tile = [&](int j0, const uint4* tkb, const uint4* tgb) {
         f32x16 xacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) xacc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KQ; ++s)
-            xacc = DT::mfma(__builtin_bit_cast(typename DT::vec8, tk[buf][n * RSK + 2 * s + hh]), qf[s], xacc);
+            xacc = DT::mfma(__builtin_bit_cast(typename DT::vec8, tkb[n * RSK + 2 * s + hh]), qf[s], xacc);
         // xacc[r] = <x_key, x_query>, key = j0 + (r&3) + 8*(r>>2) + 4*hh, query = q0 + n
         float pr[16];
 #pragma unroll
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
                 for (int e = 0; e < 8; ++e) pf[e] = (typename DT::elem)pr[8 * s + e];
 #pragma unroll
                 for (int m = 0; m < MY; ++m)
-                    y[m] = DT::mfma(__builtin_bit_cast(typename DT::vec8, tg[buf][(32 * m + n) * 5 + 2 * s + hh]), pf, y[m]);
+                    y[m] = DT::mfma(__builtin_bit_cast(typename DT::vec8, tgb[(32 * m + n) * 5 + 2 * s + hh]), pf, y[m]);
             }
         } else if (MODE == TRP_SCORES) {
 #pragma unroll
@@ -137,17 +146,18 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
             }
         }
     };
-    // one barrier per tile: fetch tile t+1 into registers, compute tile t from LDS, stash, barrier
-    const int ntiles = a.S / 32;
-    uint4 nxt[PPT];
+    // one barrier per stage: fetch stage t+1 into registers, compute the KT tiles of stage t from LDS, stash, barrier
+    const int nstages = a.S / (32 * KT);
+    uint4 nxt[KT][PPT];
     fetch(0, nxt);
     __syncthreads();                                       // the zero fill of tg is complete
     stash(0, nxt);
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const bool more = t + 1 < ntiles;
-        if (more) fetch((t + 1) * 32, nxt);
-        do_tile(t * 32, t & 1);
+    for (int t = 0; t < nstages; ++t) {
+        const bool more = t + 1 < nstages;
+        if (more) fetch((t + 1) * 32 * KT, nxt);
+#pragma unroll
+        for (int u = 0; u < KT; ++u) do_tile((t * KT + u) * 32, tk[t & 1][u], tg[t & 1][u]);
         if (more) stash((t + 1) & 1, nxt);
         __syncthreads();
     }
