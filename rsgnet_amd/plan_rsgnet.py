@@ -92,11 +92,12 @@ def record_rsgnet(p: Plan, model) -> None:
     # ---- multi-joint scores: fp32 NCHW for the output path, 16-bit NHWC (J padded to 32) for the type conv
     p.multi_lo = torch.zeros(B, J, H4, W4, **f32)
     mfl = model.multi_final_layer
-    scores16 = p.conv(vis, mfl.weight, None, mfl.bias, out_f32=p.multi_lo, name="multi_final_layer")
-
     # ---- the three clues land in one [.,96] buffer (torch.cat at :982 becomes a channel offset)
     cat = p.new(H4, W4, 3 * c0, pinned=True, name="clues")
+    p.begin_group()                                      # both read the backbone output: one launch
+    scores16 = p.conv(vis, mfl.weight, None, mfl.bias, out_f32=p.multi_lo, name="multi_final_layer")
     p._unit(vis, model.vis_conv[0], model.vis_conv[1], relu=True, out=cat.view(0, c0), name="vis_conv")
+    p.end_group("multi_final_layer+vis_conv")
     # the conv reads the first padded_cin(J) channels of the 32-wide score map (14 -> 16, 17 -> 32)
     p.conv(scores16.view(0, lib.rsg_conv_padded_cin(J)), folded_type_conv_weight(model), model.type_conv[1], None, relu=True,
            out=cat.view(c0, c0), name="type_conv(folded)")
