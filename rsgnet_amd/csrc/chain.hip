@@ -464,6 +464,7 @@ static const int kChainMaxNT = 8;      // workspace slots are sized for the wide
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
 static int g_chain_max_ni = 1;
 static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
+static int g_chain_debug = 0;      // rsg_tune("chain_debug", 1): timing experiment, every layer reads layer 0's weights (WRONG results)
 static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
 static int chain_row_pitch(int C, int W) {
     const int PS = 2 * C + 16;
@@ -481,6 +482,7 @@ extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "chain_max_ni") && value >= 1) { g_chain_max_ni = value; return 0; }
     if (key && !strcmp(key, "chain_pitch_pad")) { g_chain_pitch_pad = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "chain_prefetch")) { g_chain_prefetch = value ? 1 : 0; return 0; }
+    if (key && !strcmp(key, "chain_debug")) { g_chain_debug = value; return 0; }
     RSG_FAIL("tune: unknown key or bad value");
 }
 
@@ -585,7 +587,7 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
     a.done = nullptr; a.wait = nullptr;
     for (int l = 0; l < nlayers; ++l) {
         if (!w_packed[l] || !bias[l]) RSG_FAIL("basic_chain: null weights for layer %d", l);
-        a.wpk[l] = (const uint4*)w_packed[l];
+        a.wpk[l] = (const uint4*)w_packed[g_chain_debug & 1 ? 0 : l];
         a.bias[l] = bias[l];
     }
     const int npix = a.NI * a.R * w;
@@ -632,7 +634,7 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         }
         for (int l = 0; l < it.nlayers; ++l) {
             if (!it.w_packed[l] || !it.bias[l]) RSG_FAIL("chain_group: null weights (item %d layer %d)", i, l);
-            a.wpk[l] = (const uint4*)it.w_packed[l];
+            a.wpk[l] = (const uint4*)it.w_packed[g_chain_debug & 1 ? 0 : l];
             a.bias[l] = it.bias[l];
         }
         // prefetch range: the item's layers when the caller packed them back to back (the plan does)
