@@ -64,6 +64,7 @@ struct ChainArgs {
     // Both null for an ordinary chain.
     int* done;
     const int* wait;
+    int debug;    // timing experiments (rsg_tune("chain_debug")): bit 2 = no block-input fetch (WRONG results)
 };
 
 template <class DT, int C, int WM, int WN, int NT>
@@ -235,6 +236,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         constexpr int NRE = NT >= 7 ? 3 : NT;
 #endif
         auto fetch_res = [&](int g0, int g1) {
+            if (p.debug & 2) {                           // timing experiment only
+#pragma unroll
+                for (int g = g0; g < g1; ++g) res[g][0] = res[g][1] = make_uint4(0, 0, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
                 res[g][0] = ws_load(g, 0);
@@ -464,7 +470,7 @@ static const int kChainMaxNT = 8;      // workspace slots are sized for the wide
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
 static int g_chain_max_ni = 1;
 static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
-static int g_chain_debug = 0;      // rsg_tune("chain_debug", 1): timing experiment, every layer reads layer 0's weights (WRONG results)
+static int g_chain_debug = 0;      // rsg_tune("chain_debug", bits): timing experiments with WRONG results: 1 = every layer reads layer 0's weights, 2 = no block-input fetch
 static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
 static int chain_row_pitch(int C, int W) {
     const int PS = 2 * C + 16;
@@ -584,7 +590,7 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
         RSG_FAIL("basic_chain: unsupported shape C=%d %dx%d L=%d", c, h, w, nlayers);
     a.in = (const char*)in; a.out = (char*)out; a.nlayers = nlayers; a.B = batch; a.H = h; a.W = w;
     a.ws = (uint4*)workspace;
-    a.done = nullptr; a.wait = nullptr;
+    a.done = nullptr; a.wait = nullptr; a.debug = g_chain_debug;
     for (int l = 0; l < nlayers; ++l) {
         if (!w_packed[l] || !bias[l]) RSG_FAIL("basic_chain: null weights for layer %d", l);
         a.wpk[l] = (const uint4*)w_packed[g_chain_debug & 1 ? 0 : l];
@@ -620,6 +626,7 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         a.ws = (uint4*)it.workspace;
         a.done = (int*)it.done_flags;
         a.wait = (const int*)it.wait_flags;
+        a.debug = g_chain_debug;
         if (it.wait_flags) {
             // the producer must come EARLIER in the grid (workgroups are dispatched in index order, so every
             // producer is running or finished before a consumer can occupy a CU), write what this item reads and
