@@ -64,10 +64,11 @@ struct ChainArgs {
     // Both null for an ordinary chain.
     int* done;
     const int* wait;
+    int dual;     // 1: two LDS images (ping-pong): a layer reads one and writes the other, the block input stays in LDS
     int debug;    // timing experiments (rsg_tune("chain_debug")): bit 2 = no block-input fetch (WRONG results)
 };
 
-template <class DT, int C, int WM, int WN, int NT>
+template <class DT, int C, int WM, int WN, int NT, bool DUAL = false>
 __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_id, char* smem, const unsigned pf = 0) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int CINB = (C % 64 == 0) ? 64 : 32;      // same k order as rsg_pack_conv_weights_host
@@ -108,6 +109,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     // lies inside the picture (clamped window), so the interior is overwritten by the staging below; only an image
     // slot past the end of the batch is zeroed as a whole.
     const int lds_bytes = p.NI * slot_rows * RP;
+    // ping-pong mode is a separate instantiation: as a run-time switch inside one body it made the in-place path of the
+    // same kernel give different results from run to run (two barriers, one of them conditional, in one unswitched loop)
+    constexpr bool dual = DUAL;
     {
         const int row_chunks = RP / 16;                  // RP is a multiple of 16
         const int per_slot = 2 * row_chunks + R * 2 * CPP;
@@ -120,11 +124,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
                 off = (r + 1) * RP + (c < CPP ? 0 : (W + 1) * PS) + (c % CPP) * 16;
             }
             *reinterpret_cast<uint4*>(smem + i * slot_rows * RP + off) = make_uint4(0, 0, 0, 0);
+            if (dual) *reinterpret_cast<uint4*>(smem + lds_bytes + i * slot_rows * RP + off) = make_uint4(0, 0, 0, 0);
         }
         for (int i = 0; i < p.NI; ++i)
             if (b0 + i >= p.B)
-                for (int o = tid * 16; o < slot_rows * RP; o += NTHR * 16)
+                for (int o = tid * 16; o < slot_rows * RP; o += NTHR * 16) {
                     *reinterpret_cast<uint4*>(smem + i * slot_rows * RP + o) = make_uint4(0, 0, 0, 0);
+                    if (dual) *reinterpret_cast<uint4*>(smem + lds_bytes + i * slot_rows * RP + o) = make_uint4(0, 0, 0, 0);
+                }
     }
     RSG_STAMP(1);
     if (p.wait) {
@@ -182,7 +189,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     }
 
     // folded-BN biases of every layer, behind the image (read back at each layer top: LDS, not L2, latency)
-    float* sbias = reinterpret_cast<float*>(smem + lds_bytes);
+    float* sbias = reinterpret_cast<float*>(smem + (dual ? 2 : 1) * lds_bytes);
     for (int l = 0; l < p.nlayers; ++l)
         for (int c = tid; c < C; c += NTHR) sbias[l * C + c] = p.bias[l][c];
 
@@ -221,12 +228,18 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ws_rsrc, ws_lane, (g * 2 + k) * NTHR * 16, 0);
     };
     const int own_delta = cbase * 2 - hh * 16;           // pixoff -> this lane's 16 channels of the pixel
+    if (!dual) {
 #pragma unroll
-    for (int g = 0; g < NT; ++g) {                       // the first block's input, from the staged image
-        ws_store(g, 0, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta));
-        ws_store(g, 1, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta + 16));
+        for (int g = 0; g < NT; ++g) {                   // the first block's input, from the staged image
+            ws_store(g, 0, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta));
+            ws_store(g, 1, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta + 16));
+        }
     }
     for (int l = 0; l < p.nlayers; ++l) {
+        // ping-pong mode: layer l reads image (l & 1) and writes the other one -- which still holds this block's input
+        // at an odd l, read back by its owner lane just before it is overwritten.  No workspace, one barrier per layer.
+        const char* const rd = smem + (dual ? (l & 1) * lds_bytes : 0);
+        char* const wr = smem + (dual ? ((l + 1) & 1) * lds_bytes : 0);
         uint4 res[NT][2];                               // block input at this lane's pixels/channels (odd layers)
         // fetched in two parts: the first NRE pixel groups one k-step before the k-loop ends (all the registers
         // the widest variant has left there), the others right after it; the epilogue consumes them in order
@@ -239,6 +252,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             if (p.debug & 2) {                           // timing experiment only
 #pragma unroll
                 for (int g = g0; g < g1; ++g) res[g][0] = res[g][1] = make_uint4(0, 0, 0, 0);
+                return;
+            }
+            if (dual) {
+#pragma unroll
+                for (int g = g0; g < g1; ++g) {
+                    res[g][0] = *reinterpret_cast<const uint4*>(wr + pixoff[g] + own_delta);
+                    res[g][1] = *reinterpret_cast<const uint4*>(wr + pixoff[g] + own_delta + 16);
+                }
                 return;
             }
 #pragma unroll
@@ -283,7 +304,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             // narrow tiles: two register sets, reads one whole k-step ahead, two scheduling regions per step
             uint4 bq[2][NT];
 #pragma unroll
-            for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
+            for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(rd + pixoff[g] + boff(0));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (NRE > 0 && ks == KS - RES_LEAD && (l & 1)) fetch_res(0, NRE);
@@ -291,7 +312,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
                 if (ks + 1 < KS) {
 #pragma unroll
                     for (int g = 0; g < NT; ++g)
-                        bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
+                        bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(rd + pixoff[g] + boff(ks + 1));
                 }
                 aq[ks % NPF] = (ks + NPF < KS) ? ap[(ks + NPF) * 64] : apn[(ks + NPF - KS) * 64];
                 __builtin_amdgcn_sched_barrier(0);
@@ -305,7 +326,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             // the MFMA that consumed it, so it has (NT-1) MFMAs = 128+ cycles to land (1 MFMA : 1 DS_READ)
             uint4 bq[NT];
 #pragma unroll
-            for (int g = 0; g < NT; ++g) bq[g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
+            for (int g = 0; g < NT; ++g) bq[g] = *reinterpret_cast<const uint4*>(rd + pixoff[g] + boff(0));
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (NRE > 0 && ks == KS - RES_LEAD && (l & 1)) fetch_res(0, NRE);
@@ -314,7 +335,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 #pragma unroll
                 for (int g = 0; g < NT; ++g) {
                     acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[g]), acc[g]);
-                    if (ks + 1 < KS) bq[g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(ks + 1));
+                    if (ks + 1 < KS) bq[g] = *reinterpret_cast<const uint4*>(rd + pixoff[g] + boff(ks + 1));
                 }
                 __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // the A prefetch (VMEM read)
 #pragma unroll
@@ -343,7 +364,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = acc[g][k * 8 + e] + rf[e];
                     o[g][k] = __builtin_bit_cast(uint4, DT::relu_pack(v));
-                    if (l + 1 < p.nlayers) ws_store(g, k, o[g][k]);            // the next block's input
+                    if (l + 1 < p.nlayers && !dual) ws_store(g, k, o[g][k]); // the next block's input
                 }
             }
         } else {
@@ -359,14 +380,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             }
         }
         RSG_STAMP(4 + 3 * l);
-        __syncthreads();                                 // every wave has finished reading the image
+        if (!dual) __syncthreads();                    // in place: every wave has finished reading the image
         int wd = own_delta;
         asm volatile("" : "+v"(wd));                     // keep the 2*NT write addresses out of the loop preheader
 #pragma unroll
         for (int g = 0; g < NT; ++g) {
             if (live[g]) {
-                *reinterpret_cast<uint4*>(smem + pixoff[g] + wd) = o[g][0];
-                *reinterpret_cast<uint4*>(smem + pixoff[g] + wd + 16) = o[g][1];
+                *reinterpret_cast<uint4*>(wr + pixoff[g] + wd) = o[g][0];
+                *reinterpret_cast<uint4*>(wr + pixoff[g] + wd + 16) = o[g][1];
             }
         }
         __syncthreads();                                 // the new image is complete
@@ -396,10 +417,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     RSG_STAMP(30);
 }
 
-template <class DT, int C, int WM, int WN, int NT>
+template <class DT, int C, int WM, int WN, int NT, bool DUAL = false>
 __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    chain_body<DT, C, WM, WN, NT>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), smem);      // both row bands of an image on one XCD
+    chain_body<DT, C, WM, WN, NT, DUAL>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), smem);      // both row bands of an image on one XCD
 }
 
 // Grouped launch: up to 4 chains (different branches of one HighResolutionModule) in ONE grid; the
@@ -451,11 +472,14 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
             break;
         case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem, pf); break;
         case 128:  // 16x12 maps: one image = 6 pixel groups over 2 wave columns; two images per workgroup = 12
-            chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem, pf);
+            if (g.a[i].dual) chain_body<DT, 128, 4, 2, 3, true>(g.a[i], bid, smem, pf);
+            else chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem, pf);
             break;
         case 256:   // NT follows the pixels a workgroup owns (1 image = 48 px = 2 groups, 2 images = 3 groups)
-            if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) chain_body<DT, 256, 8, 1, 2>(g.a[i], bid, smem, pf);
-            else chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem, pf);
+            if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) {
+                if (g.a[i].dual) chain_body<DT, 256, 8, 1, 2, true>(g.a[i], bid, smem, pf);
+                else chain_body<DT, 256, 8, 1, 2>(g.a[i], bid, smem, pf);
+            } else chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem, pf);
             break;
     }
 }
@@ -471,6 +495,7 @@ static const int kChainMaxNT = 8;      // workspace slots are sized for the wide
 static int g_chain_max_ni = 1;
 static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
 static int g_chain_debug = 0;      // rsg_tune("chain_debug", bits): timing experiments with WRONG results: 1 = every layer reads layer 0's weights, 2 = no block-input fetch
+static int g_chain_dual = 1;       // rsg_tune("chain_dual", 0|1): ping-pong LDS images for the whole-image chains that fit twice
 static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
 static int chain_row_pitch(int C, int W) {
     const int PS = 2 * C + 16;
@@ -489,12 +514,18 @@ extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "chain_pitch_pad")) { g_chain_pitch_pad = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "chain_prefetch")) { g_chain_prefetch = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "chain_debug")) { g_chain_debug = value; return 0; }
+    if (key && !strcmp(key, "chain_dual")) { g_chain_dual = value ? 1 : 0; return 0; }
     RSG_FAIL("tune: unknown key or bad value");
 }
 
 typedef void (*chain_fn)(const ChainArgs);
 template <class DT>
-static chain_fn chain_lookup(int C, int npix) {
+static chain_fn chain_lookup(int C, int npix, int dual) {
+    if (dual) {
+        if (C == 256 && npix <= 64) return chain_kernel<DT, 256, 8, 1, 2, true>;
+        if (C == 128) return chain_kernel<DT, 128, 4, 1, 6, true>;
+        return nullptr;
+    }
     if (C == 256 && npix <= 64) return chain_kernel<DT, 256, 8, 1, 2>;
     if (C == 32 && npix <= 1536) return chain_kernel<DT, 32, 1, 8, 6>;
     switch (C) {
@@ -525,6 +556,10 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
         while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > ni_want)) --ni;
         a.TH = H; a.R = H; a.halo = 0; a.NI = ni; a.tiles_y = 1;
         lds = bytes(ni, H);
+        // two images (ping-pong) where they fit: 16x12x128 and 8x6x256 (73 / 45 KB each)
+        const int image = ni * (H + 2) * RP;
+        a.dual = g_chain_dual && (C == 128 || (C == 256 && ni * H * W <= 64)) && lds + image <= CHAIN_LDS_LIMIT ? 1 : 0;
+        if (a.dual) lds += image;
         return 0;
     }
     // row tiles with halo recompute: the fewest tiles whose window (TH rows + an L-row halo on every side
@@ -534,7 +569,7 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
         const int R = TH + (tiles == 2 ? 1 : 2) * nlayers;
         if (TH < 4) break;
         if (R > H || R * W > cap || bytes(1, R) > CHAIN_LDS_LIMIT) continue;
-        a.TH = TH; a.R = R; a.halo = nlayers; a.NI = 1; a.tiles_y = ceil_div(H, TH);
+        a.TH = TH; a.R = R; a.halo = nlayers; a.NI = 1; a.tiles_y = ceil_div(H, TH); a.dual = 0;
         lds = bytes(1, R);
         return 0;
     }
@@ -597,7 +632,7 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
         a.bias[l] = bias[l];
     }
     const int npix = a.NI * a.R * w;
-    chain_fn fn = dtype == RSG_BF16 ? chain_lookup<BF16>(c, npix) : chain_lookup<F16>(c, npix);
+    chain_fn fn = dtype == RSG_BF16 ? chain_lookup<BF16>(c, npix, a.dual) : chain_lookup<F16>(c, npix, a.dual);
     if (!fn) RSG_FAIL("basic_chain: no kernel for C=%d", c);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         RSG_FAIL("basic_chain: cannot reserve %d B of LDS", lds);

@@ -129,7 +129,7 @@ def lib() -> C.CDLL:
         for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad"),
                          ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit"), ("RSGNET_HIP_CHAIN_PREFETCH", b"chain_prefetch"),
                          ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
-                         ("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug")):
+                         ("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug"), ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual")):
             if os.environ.get(env):
                 l.rsg_tune(key, int(os.environ[env]))
         _lib = l
