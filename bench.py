@@ -266,6 +266,7 @@ def main():
     wall, dev_ms = timed_steps(step, a.steps, dist, dev)
 
     plan = model.plan_for(torch.cat((x, x)) if a.flip_test else x)
+    plan.check_handoff()        # the in-launch hand-off's error word, read back (raises if any poll gave up)
     # per-launch timing pass (outside the timed region, rank 0): the launch list runs IN ORDER, eagerly, with a HIP
     # event pair around every launch on the launch stream, several passes; each launch therefore meets the caches
     # in the state the real forward leaves them (timing a launch repeated back to back flattered the chain

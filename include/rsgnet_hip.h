@@ -145,9 +145,10 @@ int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, 
  * workgroups of items[0] are dispatched first, so put the longest chain there.
  * A branch whose map needs row tiles (halo grows with the chain) can be cut in two items that hand over inside
  * the launch: the first sets done_flags[workgroup] after its stores, the second (later in the array, same
- * shape, in == the first's out) names those flags in wait_flags, polls the tiles it reads and clears what it
- * saw.  done_flags: int32[3 * workgroups of the item], zeroed ONCE by the caller (a launch leaves every word
- * that is polled at zero again). */
+ * shape, in == the first's out) names those flags in wait_flags, polls the tiles it reads (bounded) and clears
+ * what it saw.  done_flags: int32[3 * workgroups of the item], zeroed by the caller before the first launch (a
+ * launch leaves every word that was seen at zero again) and again whenever rsg_chain_handoff_timeouts reports a
+ * poll that gave up. */
 typedef struct rsg_chain_item {
     const void* in;
     void* out;
@@ -160,9 +161,18 @@ typedef struct rsg_chain_item {
     const void* wait_flags;        /* NULL, or the done_flags of an earlier item */
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
-/* Number of hand-off polls that gave up since the library was loaded (synchronises the device).  Non-zero means a
- * consumer chain started without its producer's data: a bug or a dispatch order this design does not expect. */
+/* Sticky error word of the hand-off: the number of polls that gave up since the library was loaded on the current
+ * device.  An increase means a consumer chain staged without its producer's data: that launch's output is wrong and
+ * the flag words it was waiting on must be re-zeroed by the caller before the next launch.
+ * rsg_chain_handoff_timeouts synchronises the device; the _async form enqueues a 4-byte copy into PINNED host
+ * memory on `stream` (the caller reads it once an event behind it has completed), which is how the production path
+ * watches the word without stalling (rsgnet_amd/plan.py).
+ * rsg_basic_chain_handoff_max_waiters: the launch is deadlock-free whatever the dispatch order as long as fewer
+ * workgroups than this + 1 wait on flags (one chain workgroup is resident per compute unit, so at least one unit
+ * always runs workgroups that never block); rsg_basic_chain_group refuses a launch with more. */
 int rsg_chain_handoff_timeouts(uint32_t* count);
+int rsg_chain_handoff_timeouts_async(uint32_t* pinned_host, void* stream);
+int rsg_basic_chain_handoff_max_waiters(void);
 
 /* ---- layout / elementwise -------------------------------------------------------------------- */
 /* x.float NCHW -> NHWC 16-bit with channels zero-padded to c_pad (input of the stem conv,
@@ -275,6 +285,62 @@ int rsg_relation_target_vec(const float* target, float* out, int32_t batch, int3
  * grad_scale folds the data-parallel 1/world average into the update. */
 int rsg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream);
+
+/* ---- training step: BatchNorm with batch statistics, backward kernels -------------------
+ * `model.train()` forward + backward of pose_hrnet (lib/core/function.py:27-80 drives the reference; its arithmetic is
+ * torch autograd over pose_hrnet.py).  Maps are dense NHWC 16-bit; statistics, affine parameters, gradients fp32.
+ * Convolutions themselves run through rsg_conv_igemm (forward: weights packed WITHOUT BatchNorm folding; data
+ * gradient: the same kernel with the transposed, flipped weights, stride-2 convs behind rsg_zero_insert2x).
+ * Every reduction has a fixed order: no float atomics, bit-reproducible gradients. */
+/* One launch packs every conv weight of the model from its fp32 master copy (device) into the MFMA fragment order of
+ * rsg_pack_conv_weights_host (no scale/shift): item k owns blocks [first_block, next item's first_block) of
+ * rsg_pack_item_blocks(packed cin, packed cout, kh, kw) 256-thread blocks.  transpose = 1: the data-gradient form
+ * W'[i][o][ky][kx] = W[o][i][kh-1-ky][kw-1-kx] (packed cin = cout of W, packed cout = cin of W). */
+typedef struct rsg_pack_item {
+    const float* w;            /* [cout][cin][kh][kw] fp32, device */
+    void* dst;                 /* rsg_conv_packed_bytes(packed cin, packed cout, kh, kw) bytes, device */
+    int32_t cin, cout, kh, kw; /* of the weight tensor as stored */
+    int32_t transpose;
+    int32_t first_block;
+} rsg_pack_item;
+int32_t rsg_pack_item_blocks(int32_t cin, int32_t cout, int32_t kh, int32_t kw);
+int rsg_pack_conv_weights_device(const rsg_pack_item* items_device, int32_t n_items, int32_t total_blocks,
+                                 int32_t dtype, void* stream);
+/* nn.BatchNorm2d in training mode (pose_hrnet.py:37 etc.; momentum 0.1, eps 1e-5): per-channel mean and
+ * 1/sqrt(biased var + eps) of y [pixels][c], running statistics updated in place (unbiased variance; NULL = skip).
+ * c: a power of two in [8, 256].  workspace: rsg_bn_workspace_bytes(c). */
+size_t rsg_bn_workspace_bytes(int32_t c);
+int rsg_bn_stats(const void* y, int64_t pixels, int32_t c, int32_t dtype, float* workspace, float* mean, float* invstd,
+                 float* running_mean, float* running_var, float momentum, float eps, void* stream);
+/* out = [ReLU]( gamma * (y - mean) * invstd + beta [+ residual] ) */
+int rsg_bn_apply(const void* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                 const void* residual, int32_t relu, void* out, int64_t pixels, int32_t c, int32_t dtype, void* stream);
+/* Backward of the unit above.  dz: gradient of the unit's output; z: that output (ReLU mask; NULL = the unit had no
+ * ReLU); y: the conv output the BatchNorm normalised.  Writes dy (gradient of y), dgamma, dbeta and, when dres is
+ * not NULL, the masked gradient g = dz * (z > 0), which is the gradient of the residual operand. */
+int rsg_bn_backward(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                    const float* gamma, void* dy, void* dres, float* dgamma, float* dbeta, float* workspace,
+                    int64_t pixels, int32_t c, int32_t dtype, void* stream);
+/* g = dout * (out > 0): the ReLU that ends a fuse sum (pose_hrnet.py:266);  out = a + b: a map with two consumers */
+int rsg_relu_backward(const void* dout, const void* out, void* g, int64_t n, int32_t dtype, void* stream);
+int rsg_add16(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);
+/* backward of nn.Upsample(scale_factor = 2^shift, 'nearest') (pose_hrnet.py:213): grad_lo [batch,h_lo,w_lo,c] =
+ * sum of the 2^shift x 2^shift block of grad_hi [batch, h_lo << shift, w_lo << shift, c] */
+int rsg_upsample_nearest_backward(const void* grad_hi, void* grad_lo, int32_t batch, int32_t h_lo, int32_t w_lo,
+                                  int32_t c, int32_t shift, int32_t dtype, void* stream);
+/* out [batch, 2h, 2w, c] = in [batch, h, w, c] on the even positions, zeros elsewhere (data gradient of stride-2 convs) */
+int rsg_zero_insert2x(const void* in, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
+/* out[c] = sum over batch and pixels of x [batch, c, hw] fp32 (bias gradient of the classifier conv) */
+int rsg_channel_sum_nchw_f32(const float* x, float* out, int32_t batch, int32_t c, int32_t hw, void* stream);
+/* Weight gradient of nn.Conv2d (3x3 pad 1 or 1x1 pad 0, stride 1 or 2) on the matrix cores:
+ *   dw[o][i][ky][kx] (fp32, nn.Conv2d layout, cout x cin real channels) = sum dy[b,r,c,o] * x[b, r*s+ky-p, c*s+kx-p, i]
+ * x: [batch,in_h,in_w,cin_pad], dy: [batch,out_h,out_w,cout_pad] dense NHWC 16-bit (padding channels are ignored).
+ * workspace: rsg_conv_wgrad_workspace_bytes(...) bytes (0 = unsupported geometry). */
+size_t rsg_conv_wgrad_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t cin_pad, int32_t out_h,
+                                      int32_t out_w, int32_t cout_pad, int32_t kh, int32_t kw, int32_t stride, int32_t pad);
+int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, int32_t batch, int32_t in_h, int32_t in_w,
+                   int32_t cin, int32_t cin_pad, int32_t out_h, int32_t out_w, int32_t cout, int32_t cout_pad, int32_t kh,
+                   int32_t kw, int32_t stride, int32_t pad, int32_t dtype, void* stream);
 
 /* ---- crop producer ---------------------------------------------------------------
  * One person box per entry: `cv2.warpAffine(img, trans, (out_w, out_h), flags=INTER_LINEAR)` (constant border 0)

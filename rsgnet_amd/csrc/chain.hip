@@ -40,8 +40,11 @@ __device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][8 waves][
 #define RSG_STAMP(slot) do {} while (0)
 #endif
 
-// polls that gave up (a producer tile never signalled): the results of that launch are then wrong, and a host that
-// cares can find out (rsg_chain_handoff_timeouts); never seen in practice, workgroups are dispatched in index order
+// Sticky error word: polls that gave up (a producer tile never signalled within the bound).  The results of that
+// launch are then wrong.  The production path reads it back (rsg_chain_handoff_timeouts / _async: rsgnet_amd/plan.py
+// polls it without stalling the stream, re-zeroes the plan's flags and raises).  Forward progress does NOT rest on
+// the dispatch order: rsg_basic_chain_group refuses a launch whose waiting workgroups could fill the machine (see
+// there), so a producer always finds a CU; the bound only turns a bug into an error instead of a hung GPU.
 __device__ unsigned g_chain_handoff_timeouts = 0;
 
 struct ChainArgs {
@@ -65,7 +68,7 @@ struct ChainArgs {
     int* done;
     const int* wait;
     int dual;     // 1: two LDS images (ping-pong): a layer reads one and writes the other, the block input stays in LDS
-    int debug;    // timing experiments (rsg_tune("chain_debug")): bit 2 = no block-input fetch (WRONG results)
+    int debug;    // experiments (rsg_tune("chain_debug")): bit 2 = no block-input fetch (WRONG results), bit 4 = producers never signal
 };
 
 template <class DT, int C, int WM, int WN, int NT, bool DUAL = false>
@@ -148,8 +151,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             int spin = 0;
             for (; spin < (1 << 20) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
                 __builtin_amdgcn_s_sleep(8);
-            if (spin == (1 << 20)) atomicAdd(&g_chain_handoff_timeouts, 1u);     // read back by rsg_chain_handoff_timeouts
-            __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a flag that was never seen is NOT cleared (a late producer would set it behind the clear and the stale 1
+            // would let every later replay through without waiting): the host re-zeroes all flags when it finds the
+            // error word raised
+            if (spin == (1 << 20)) atomicAdd(&g_chain_handoff_timeouts, 1u);
+            else __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
     }
@@ -412,7 +418,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     if (p.done) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores have left the CU
         __syncthreads();
-        if (tid < 3) __hip_atomic_store(p.done + block_id * 3 + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 3 && !(p.debug & 4))     // debug bit 4 (tests): the producer never signals, every consumer poll gives up
+            __hip_atomic_store(p.done + block_id * 3 + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     RSG_STAMP(30);
 }
@@ -494,7 +501,7 @@ static const int kChainMaxNT = 8;      // workspace slots are sized for the wide
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
 static int g_chain_max_ni = 1;
 static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
-static int g_chain_debug = 0;      // rsg_tune("chain_debug", bits): timing experiments with WRONG results: 1 = every layer reads layer 0's weights, 2 = no block-input fetch
+static int g_chain_debug = 0;      // rsg_tune("chain_debug", bits): experiments with WRONG results: 1 = every layer reads layer 0's weights, 2 = no block-input fetch, 4 = hand-off producers never signal (exercises the error word)
 static int g_chain_dual = 1;       // rsg_tune("chain_dual", 0|1): ping-pong LDS images for the whole-image chains that fit twice
 static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
 static int chain_row_pitch(int C, int W) {
@@ -585,6 +592,34 @@ extern "C" int rsg_chain_handoff_timeouts(uint32_t* count) {
     return 0;
 }
 
+extern "C" int rsg_chain_handoff_timeouts_async(uint32_t* pinned_host, void* stream) {
+    if (!pinned_host) RSG_FAIL("chain_handoff_timeouts_async: null pointer");
+    if (hipMemcpyFromSymbolAsync(pinned_host, HIP_SYMBOL(g_chain_handoff_timeouts), sizeof(unsigned), 0,
+                                 hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+        RSG_FAIL("chain_handoff_timeouts_async: hipMemcpyFromSymbolAsync failed");
+    return 0;
+}
+
+// Compute units of the current device (cached per device id); 0 when the query fails.
+static int chain_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) cus[dev] = v;
+    }
+    return cus[dev];
+}
+
+extern "C" int rsg_basic_chain_handoff_max_waiters(void) {
+    // every chain workgroup holds more than half a CU's LDS, so one is resident per CU; as long as FEWER workgroups
+    // than CUs can wait on flags, at least one CU always runs workgroups that never block, every producer gets its
+    // turn whatever the dispatch order, and the launch cannot deadlock
+    const int cus = chain_device_cus();
+    return cus > 0 ? cus - 1 : 0;
+}
+
 extern "C" int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
                                          int32_t* info4) {
     ChainArgs a;
@@ -623,6 +658,8 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
     int lds = 0, nthr = 0;
     if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr))
         RSG_FAIL("basic_chain: unsupported shape C=%d %dx%d L=%d", c, h, w, nlayers);
+    if ((long long)batch * h * w * c * 2 >= (1LL << 31))
+        RSG_FAIL("basic_chain: map of %lld bytes exceeds the 32-bit buffer offsets", (long long)batch * h * w * c * 2);
     a.in = (const char*)in; a.out = (char*)out; a.nlayers = nlayers; a.B = batch; a.H = h; a.W = w;
     a.ws = (uint4*)workspace;
     a.done = nullptr; a.wait = nullptr; a.debug = g_chain_debug;
@@ -647,7 +684,7 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
     ChainGroupArgs g;
     memset(&g, 0, sizeof(g));
     g.n = n;
-    int lds_max = 0, blocks = 0;
+    int lds_max = 0, blocks = 0, waiters = 0;
     for (int i = 0; i < n; ++i) {
         const rsg_chain_item& it = items[i];
         if (!it.in || !it.out || !it.w_packed || !it.bias || it.in == it.out) RSG_FAIL("chain_group: bad pointers in item %d", i);
@@ -657,15 +694,17 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr, true, it.images_per_workgroup))
             RSG_FAIL("chain_group: unsupported shape C=%d %dx%d L=%d", it.c, it.h, it.w, it.nlayers);
         if ((!it.workspace || ((uintptr_t)it.workspace & 15))) RSG_FAIL("chain_group: item %d needs a workspace", i);
+        if ((long long)it.batch * it.h * it.w * it.c * 2 >= (1LL << 31))
+            RSG_FAIL("chain_group: item %d: map of %lld bytes exceeds the 32-bit buffer offsets", i,
+                     (long long)it.batch * it.h * it.w * it.c * 2);
         a.in = (const char*)it.in; a.out = (char*)it.out; a.nlayers = it.nlayers; a.B = it.batch; a.H = it.h; a.W = it.w;
         a.ws = (uint4*)it.workspace;
         a.done = (int*)it.done_flags;
         a.wait = (const int*)it.wait_flags;
         a.debug = g_chain_debug;
         if (it.wait_flags) {
-            // the producer must come EARLIER in the grid (workgroups are dispatched in index order, so every
-            // producer is running or finished before a consumer can occupy a CU), write what this item reads and
-            // cut the map into the same tiles
+            // the producer comes EARLIER in the grid (in-order dispatch then makes the wait short; correctness does
+            // not need it, see the waiter bound below), writes what this item reads and cuts the map into the same tiles
             int j = 0;
             while (j < i && items[j].done_flags != it.wait_flags) ++j;
             if (j == i) RSG_FAIL("chain_group: item %d waits on flags no earlier item sets", i);
@@ -690,10 +729,15 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         }
         g.c[i] = it.c;
         g.first[i] = blocks;
+        if (it.wait_flags) waiters += ceil_div(it.batch, a.NI) * a.tiles_y;
         blocks += ceil_div(it.batch, a.NI) * a.tiles_y;
         if (lds > lds_max) lds_max = lds;
     }
     g.first[n] = blocks;
+    if (waiters > 0 && waiters > rsg_basic_chain_handoff_max_waiters())
+        RSG_FAIL("chain_group: %d workgroups wait on hand-off flags but the device guarantees progress for at most %d "
+                 "(compute units - 1): run the dependent chains as a second launch", waiters,
+                 rsg_basic_chain_handoff_max_waiters());
     void (*fn)(const ChainGroupArgs) = dtype == RSG_BF16 ? chain_group_kernel<BF16> : chain_group_kernel<F16>;
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess)
         RSG_FAIL("chain_group: cannot reserve %d B of LDS", lds_max);

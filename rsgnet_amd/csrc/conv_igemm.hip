@@ -406,3 +406,58 @@ extern "C" int rsg_pack_conv_weights_host(const float* w, const float* scale, co
     }
     return 0;
 }
+
+// ---- device-side packing (training: the fp32 master weights change every step) ---------------------------------
+// The same fragment order as rsg_pack_conv_weights_host, no BatchNorm folding (training normalises with batch
+// statistics in its own kernels).  One launch packs EVERY conv of the model: items[] (device) names the tensors,
+// item k owns blocks [first_block[k], first_block[k+1]); a thread writes one lane's 8 elements (16 bytes).
+// transpose = 1 packs the data-gradient form of the same weight: W'[i][o][ky][kx] = W[o][i][kh-1-ky][kw-1-kx]
+// (conv_transpose of a stride-1 conv = a conv with these weights; pose_hrnet.py's convs, backward).
+template <class DT>
+__global__ void __launch_bounds__(256) pack_weights_kernel(const rsg_pack_item* __restrict__ items, int n_items) {
+    // binary search: last item whose first_block <= blockIdx.x
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const rsg_pack_item it = items[lo];
+    const int wcin = it.cin, wcout = it.cout, ntaps = it.kh * it.kw;   // the weight tensor is [wcout][wcin][kh][kw]
+    const int cin = it.transpose ? wcout : wcin, cout = it.transpose ? wcin : wcout;   // the packed conv's own cin/cout
+    const int cin_pad = cin <= 16 ? 16 : (cin % 16 == 0 ? cin : (cin + 31) / 32 * 32);
+    const int cinb = cin_pad % 64 == 0 ? 64 : (cin_pad % 32 == 0 ? 32 : 16);
+    const int kpt = cinb / 16, nchunks = cin_pad / cinb, KS = nchunks * ntaps * kpt;
+    const int cout_pad = (cout + 31) / 32 * 32;
+    const long e = ((long)blockIdx.x - it.first_block) * 256 + threadIdx.x;      // (ct, ks, lane)
+    if (e >= (long)(cout_pad / 32) * KS * 64) return;
+    const int lane = (int)(e & 63), ks = (int)((e >> 6) % KS), ct = (int)((e >> 6) / KS);
+    const int c = ks % kpt, t = (ks / kpt) % ntaps, ch = ks / (kpt * ntaps);
+    const int i = lane & 31, h = lane >> 5;
+    const int co = ct * 32 + 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3);
+    typename DT::vec8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = ch * cinb + c * 16 + h * 8 + j;
+        float f = 0.f;
+        if (co < cout && ci < cin)
+            f = it.transpose ? it.w[((long)ci * wcin + co) * ntaps + (ntaps - 1 - t)] : it.w[((long)co * wcin + ci) * ntaps + t];
+        v[j] = DT::from_f32(f);
+    }
+    reinterpret_cast<uint4*>(it.dst)[e] = __builtin_bit_cast(uint4, v);
+}
+
+extern "C" int32_t rsg_pack_item_blocks(int32_t cin, int32_t cout, int32_t kh, int32_t kw) {
+    // cin/cout of the PACKED conv (swap them for a transposed item)
+    return ceil_div((int)(rsg_conv_packed_bytes(cin, cout, kh, kw) / 16), 256);
+}
+
+extern "C" int rsg_pack_conv_weights_device(const rsg_pack_item* items_device, int32_t n_items, int32_t total_blocks,
+                                            int32_t dtype, void* stream) {
+    if (!items_device || n_items < 1 || total_blocks < 1) RSG_FAIL("pack_device: bad arguments");
+    if (dtype == RSG_BF16)
+        RSG_LAUNCH(pack_weights_kernel<BF16>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_device, n_items);
+    else
+        RSG_LAUNCH(pack_weights_kernel<F16>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, items_device, n_items);
+    RSG_CHECK_LAUNCH("pack_device");
+    return 0;
+}

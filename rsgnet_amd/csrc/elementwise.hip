@@ -30,9 +30,17 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc16_kernel(const float* __rest
 extern "C" int rsg_nchw_f32_to_nhwc16(const float* in, void* out, int32_t batch, int32_t c, int32_t h,
                                       int32_t w, int32_t c_pad, int32_t dtype, void* stream) {
     if (!in || !out) RSG_FAIL("nchw_to_nhwc16: null pointer");
-    if (c_pad != 16 || c > c_pad || c < 1) RSG_FAIL("nchw_to_nhwc16: c=%d c_pad=%d (only c_pad=16)", c, c_pad);
+    if ((c_pad != 16 && c_pad != 32) || c > c_pad || c < 1) RSG_FAIL("nchw_to_nhwc16: c=%d c_pad=%d (c_pad 16 or 32)", c, c_pad);
     const long total = (long)batch * h * w;
     const int grid = (int)((total + 255) / 256);
+    if (c_pad == 32) {       // the heat-map gradient (17 / 14 joints) on its way into the backward convs
+        if (dtype == RSG_BF16)
+            RSG_LAUNCH((nchw_to_nhwc16_kernel<BF16, 32>), dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (char*)out, c, h * w, total);
+        else
+            RSG_LAUNCH((nchw_to_nhwc16_kernel<F16, 32>), dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (char*)out, c, h * w, total);
+        RSG_CHECK_LAUNCH("nchw_to_nhwc16");
+        return 0;
+    }
     if (dtype == RSG_BF16)
         RSG_LAUNCH((nchw_to_nhwc16_kernel<BF16, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            in, (char*)out, c, h * w, total);

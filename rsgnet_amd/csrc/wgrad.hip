@@ -1,0 +1,235 @@
+// Weight gradient of a convolution on the matrix cores (gfx950).
+//
+// Replaces autograd's conv weight gradient for the nn.Conv2d layers of pose_hrnet.py (3x3 s1/s2 p1, 1x1) in the
+// training step (lib/core/function.py:27-80):
+//     dW[o][i][ky][kx] = sum over (b, r, c) of  dy[b, r, c, o] * x[b, r*s + ky - p, c*s + kx - p, i]
+// i.e. per tap a GEMM  D[o][i] = A[o][pixel] * B[pixel][i]  whose contraction index is the PIXEL.  Both operands are
+// NHWC (channel-fast), so a lane's MFMA fragment (8 consecutive k for one row/column) is strided in memory; the tiles
+// are staged in LDS as [pixel][32 channels] (64 dense bytes per pixel) and read with ds_read_b64_tr_b16, the hardware
+// transpose read: 4 pixels x 16 channels per 16-lane group, every lane supplying the address of its own pixel row, so
+// the shifted (and for stride 2: strided) window of a tap is just a per-lane address.
+//
+// Decomposition: one workgroup (4 waves) owns ONE 32x32 (cout tile, cin tile) pair for ALL taps and a slice of the
+// pixels (chunks = row bands of single images, dealt round-robin to the slices); inside a chunk the waves take
+// alternate 16-pixel k-steps, each holding taps x 16 accumulator registers.  The four waves' tiles are added in LDS
+// in a fixed order, the slices' partial tiles go to a workspace and a second kernel sums them in slice order into
+// dW (fp32, nn.Conv2d layout): no atomics, bit-reproducible.
+#include "common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgradArgs {
+    const char* x;     // [B, Hin, Win, CinP] 16-bit
+    const char* dy;    // [B, Hout, Wout, CoutP] 16-bit
+    float* part;       // [pairs][nslices][taps][32][32] fp32
+    int B, Hin, Win, CinP, Hout, Wout, CoutP;
+    int kh, kw, stride, pad;
+    int n_ot, n_it, nslices;
+    int RB, nbands;    // output rows per chunk, chunks per image
+    int xrows, xcols;  // x tile: (RB-1)*stride + kh rows, Win + 2*pad columns
+    int P16;           // pixels of a chunk, padded to a multiple of 16
+};
+
+template <class DT>
+__device__ __forceinline__ f32x16 wg_mfma(s16x8 a, s16x8 b, f32x16 c) {
+    return DT::mfma(__builtin_bit_cast(typename DT::vec8, a), __builtin_bit_cast(typename DT::vec8, b), c);
+}
+
+__device__ __forceinline__ s16x4 tr_read(const char* lds, int off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) char*)(lds + off));
+}
+
+template <class DT, int NT>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pair = blockIdx.x / a.nslices, slice = blockIdx.x - pair * a.nslices;
+    const int ot = pair / a.n_it, it = pair - ot * a.n_it;
+    char* const sdy = smem;                                   // [P16][64 B]
+    char* const sx = smem + a.P16 * 64;                       // [xrows * xcols][64 B]
+    int* const soff = reinterpret_cast<int*>(sx + a.xrows * a.xcols * 64);   // [P16]: byte offset of a pixel's tap (0,0) in sx
+
+    // fragment geometry of this lane (see the header): 16-lane group g reads channels cb..cb+15, k rows kb..kb+7
+    const int grp = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+    const int cb = 16 * (grp & 1), kb = 8 * (grp >> 1);
+    const int lane_col = (cb + 4 * pp) * 2;                   // byte offset of this lane's 4 channels inside a pixel
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nchunks = a.B * a.nbands;
+    for (int chunk = slice; chunk < nchunks; chunk += a.nslices) {
+        const int b = chunk / a.nbands, band = chunk - b * a.nbands;
+        const int r0 = band * a.RB;                           // first output row of the chunk
+        const int rows = min(a.RB, a.Hout - r0);
+        const int P = rows * a.Wout;                          // valid pixels
+        __syncthreads();                                      // the previous chunk's reads are done
+        // ---- dy tile: the band is one contiguous pixel range of the image
+        {
+            const char* src = a.dy + ((size_t)(b * a.Hout + r0) * a.Wout) * a.CoutP * 2 + ot * 64;
+            for (int i = tid; i < a.P16 * 4; i += 256) {
+                const int p = i >> 2, c4 = i & 3;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (p < P && ot * 32 + c4 * 8 < a.CoutP) v = *reinterpret_cast<const uint4*>(src + (size_t)p * a.CoutP * 2 + c4 * 16);
+                *reinterpret_cast<uint4*>(sdy + i * 16) = v;
+            }
+        }
+        // ---- x tile with its zero border
+        {
+            const int iy0 = r0 * a.stride - a.pad;
+            const int npix = a.xrows * a.xcols;
+            for (int i = tid; i < npix * 4; i += 256) {
+                const int p = i >> 2, c4 = i & 3;
+                const int ry = p / a.xcols, cx = p - ry * a.xcols;
+                const int iy = iy0 + ry, ix = cx - a.pad;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && it * 32 + c4 * 8 < a.CinP)
+                    v = *reinterpret_cast<const uint4*>(a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.CinP * 2 + it * 64 + c4 * 16);
+                *reinterpret_cast<uint4*>(sx + i * 16) = v;
+            }
+        }
+        for (int p = tid; p < a.P16; p += 256) {
+            int o = 0;
+            if (p < P) {
+                const int r = p / a.Wout, c = p - r * a.Wout;
+                o = ((r * a.stride) * a.xcols + c * a.stride) * 64;
+            }
+            soff[p] = o;                                      // padded pixels: dy is zero there, any finite x will do
+        }
+        __syncthreads();
+        const int ksteps = (P + 15) >> 4;
+        for (int ks = wave; ks < ksteps; ks += 4) {
+            const int pix0 = ks * 16 + kb + q, pix1 = pix0 + 4;
+            const s16x4 a0 = tr_read(sdy, pix0 * 64 + lane_col), a1 = tr_read(sdy, pix1 * 64 + lane_col);
+            const s16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const int x0 = soff[pix0] + lane_col, x1 = soff[pix1] + lane_col;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                constexpr int KW = NT == 9 ? 3 : 1;
+                const int toff = ((t / KW) * a.xcols + (t % KW)) * 64;
+                const s16x4 b0 = tr_read(sx, x0 + toff), b1 = tr_read(sx, x1 + toff);
+                const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[t] = wg_mfma<DT>(af, bf, acc[t]);
+            }
+        }
+    }
+    // ---- add the four waves' tiles in a fixed order: (0 += 2, 1 += 3), then 0 += 1
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);               // [2][NT][16][64]
+    if (wave >= 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave - 2) * NT + t) * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += red[((wave * NT + t) * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = a.part + ((size_t)pair * a.nslices + slice) * NT * 1024;
+        const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;             // C/D map of the 32x32 MFMA: row = cout, col = cin
+                dst[t * 1024 + row * 32 + col] = acc[t][r] + red[(t * 16 + r) * 64 + lane];
+            }
+    }
+}
+
+// dW[o][i][t] = sum over slices (in slice order) of part[(ot, it)][slice][t][o % 32][i % 32]
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int cout, int cin,
+                                                           int ntaps, int n_it, int nslices) {
+    const long total = (long)cout * cin * ntaps;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int t = (int)(e % ntaps);
+        const int i = (int)((e / ntaps) % cin), o = (int)(e / ((long)ntaps * cin));
+        const float* p = part + ((size_t)((o >> 5) * n_it + (i >> 5)) * nslices * ntaps + t) * 1024 + (o & 31) * 32 + (i & 31);
+        float s = 0.f;
+        for (int k = 0; k < nslices; ++k) s += p[(size_t)k * ntaps * 1024];
+        dw[e] = s;
+    }
+}
+
+struct WgradPlan { WgradArgs a; int lds, grid, ntaps; };
+
+static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int out_w, int cout_pad, int kh, int kw, int stride,
+                      int pad, WgradPlan& p) {
+    memset(&p, 0, sizeof(p));
+    if (!((kh == 3 && kw == 3 && pad == 1) || (kh == 1 && kw == 1 && pad == 0)) || (stride != 1 && stride != 2)) return 1;
+    if (cin_pad % 8 || cout_pad % 8 || batch < 1) return 1;
+    if ((in_h + 2 * pad - kh) / stride + 1 != out_h || (in_w + 2 * pad - kw) / stride + 1 != out_w) return 1;
+    WgradArgs& a = p.a;
+    a.B = batch; a.Hin = in_h; a.Win = in_w; a.CinP = cin_pad; a.Hout = out_h; a.Wout = out_w; a.CoutP = cout_pad;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad;
+    a.n_ot = ceil_div(cout_pad, 32); a.n_it = ceil_div(cin_pad, 32);
+    a.xcols = in_w + 2 * pad;
+    p.ntaps = kh * kw;
+    const int red_bytes = 2 * p.ntaps * 16 * 64 * 4;
+    const int budget = 72 * 1024;                           // two workgroups per CU
+    int rb = 0;
+    for (int r = max(1, min(out_h, 512 / out_w)); r >= 1; --r) {
+        const int p16 = round_up(r * out_w, 16), xr = (r - 1) * stride + kh;
+        if (p16 * 64 + xr * a.xcols * 64 + p16 * 4 <= budget) { rb = r; break; }
+    }
+    if (!rb) return 1;
+    a.RB = rb; a.nbands = ceil_div(out_h, rb);
+    a.P16 = round_up(rb * out_w, 16); a.xrows = (rb - 1) * stride + kh;
+    p.lds = max(a.P16 * 64 + a.xrows * a.xcols * 64 + a.P16 * 4, red_bytes);
+    const int pairs = a.n_ot * a.n_it, chunks = batch * a.nbands;
+    a.nslices = max(1, min(chunks, ceil_div(1024, pairs)));
+    p.grid = pairs * a.nslices;
+    return 0;
+}
+
+extern "C" size_t rsg_conv_wgrad_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t cin_pad, int32_t out_h,
+                                                 int32_t out_w, int32_t cout_pad, int32_t kh, int32_t kw, int32_t stride, int32_t pad) {
+    WgradPlan p;
+    if (wgrad_plan(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p)) return 0;
+    return (size_t)p.grid * p.ntaps * 1024 * sizeof(float);
+}
+
+extern "C" int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, int32_t batch, int32_t in_h, int32_t in_w,
+                              int32_t cin, int32_t cin_pad, int32_t out_h, int32_t out_w, int32_t cout, int32_t cout_pad, int32_t kh,
+                              int32_t kw, int32_t stride, int32_t pad, int32_t dtype, void* stream) {
+    if (!x || !dy || !dw || !workspace) RSG_FAIL("conv_wgrad: null pointer");
+    if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)workspace) & 15) RSG_FAIL("conv_wgrad: operands must be 16-byte aligned");
+    if (cin < 1 || cin > cin_pad || cout < 1 || cout > cout_pad) RSG_FAIL("conv_wgrad: cin %d/%d cout %d/%d", cin, cin_pad, cout, cout_pad);
+    WgradPlan p;
+    if (wgrad_plan(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p))
+        RSG_FAIL("conv_wgrad: unsupported geometry %dx%d k%d s%d p%d (%dx%d -> %dx%d)", cin_pad, cout_pad, kh, stride, pad, in_h, in_w, out_h, out_w);
+    if ((long long)batch * in_h * in_w * cin_pad * 2 >= (1LL << 31) || (long long)batch * out_h * out_w * cout_pad * 2 >= (1LL << 31))
+        RSG_FAIL("conv_wgrad: map too large for 32-bit offsets");
+    p.a.x = (const char*)x; p.a.dy = (const char*)dy; p.a.part = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    void (*fn)(const WgradArgs) = nullptr;
+    if (dtype == RSG_BF16) fn = p.ntaps == 9 ? wgrad_kernel<BF16, 9> : wgrad_kernel<BF16, 1>;
+    else fn = p.ntaps == 9 ? wgrad_kernel<F16, 9> : wgrad_kernel<F16, 1>;
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds) != hipSuccess)
+        RSG_FAIL("conv_wgrad: cannot reserve %d B of LDS", p.lds);
+    RSG_LAUNCH(fn, dim3(p.grid), dim3(256), p.lds, s, p.a);
+    const long total = (long)cout * cin * p.ntaps;
+    RSG_LAUNCH(wgrad_reduce_kernel, dim3((int)min((total + 255) / 256, (long)2048)), dim3(256), 0, s, (const float*)workspace, dw, cout, cin,
+               p.ntaps, p.a.n_it, p.a.nslices);
+    RSG_CHECK_LAUNCH("conv_wgrad");
+    return 0;
+}

@@ -45,6 +45,12 @@ class ChainItem(C.Structure):
                 ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p)]
 
 
+class PackItem(C.Structure):
+    """struct rsg_pack_item (include/rsgnet_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("cin", C.c_int32), ("cout", C.c_int32), ("kh", C.c_int32),
+                ("kw", C.c_int32), ("transpose", C.c_int32), ("first_block", C.c_int32)]
+
+
 class CropDesc(C.Structure):
     """struct rsg_crop_desc (include/rsgnet_hip.h)."""
     _fields_ = [("image", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("stride", C.c_int32),
@@ -77,6 +83,8 @@ SYMBOLS = {
     "rsg_basic_chain_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rsg_basic_chain_group": (C.c_int, [C.POINTER(ChainItem), _i, _i, _vp]),
     "rsg_chain_handoff_timeouts": (C.c_int, [C.POINTER(C.c_uint32)]),
+    "rsg_chain_handoff_timeouts_async": (C.c_int, [_vp, _vp]),
+    "rsg_basic_chain_handoff_max_waiters": (C.c_int, []),
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_conv_groupable": (C.c_int, [C.POINTER(ConvDesc)]),
     "rsg_group_table_bytes": (C.c_size_t, []),
@@ -100,6 +108,19 @@ SYMBOLS = {
     "rsg_bce_loss": (C.c_int, [_vp, _vp, C.c_int64, C.c_float, C.c_float, _vp, _i, _vp, _vp, _vp]),
     "rsg_relation_target_vec": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.c_float, _vp]),
+    "rsg_pack_item_blocks": (C.c_int32, [_i, _i, _i, _i]),
+    "rsg_pack_conv_weights_device": (C.c_int, [_vp, _i, _i, _i, _vp]),
+    "rsg_bn_workspace_bytes": (C.c_size_t, [_i]),
+    "rsg_bn_stats": (C.c_int, [_vp, C.c_int64, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp]),
+    "rsg_bn_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_int64, _i, _i, _vp]),
+    "rsg_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _vp]),
+    "rsg_relu_backward": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
+    "rsg_add16": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
+    "rsg_upsample_nearest_backward": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "rsg_zero_insert2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_channel_sum_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "rsg_conv_wgrad_workspace_bytes": (C.c_size_t, [_i] * 11),
+    "rsg_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }

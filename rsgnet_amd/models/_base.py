@@ -17,7 +17,8 @@ class HipPoseModule(nn.Module):
     (``rsgnet_amd.plan``) that was built from those parameters: BatchNorm folded into fp16 weights,
     weights packed into MFMA fragment order, a static NHWC activation arena, and the launch list.
     The plan is rebuilt whenever the parameters may have changed (``load_state_dict``, ``train()``,
-    ``.to()/.cuda()``) or the batch size / device changes.
+    ``.to()/.cuda()``, any in-place update torch's version counters or ``FusedAdam`` record — ``_param_signature``;
+    ``invalidate_plan()`` is the explicit form for writes through raw pointers) or the batch size / device changes.
 
     There is deliberately NO CPU or eager fallback: off the GPU, or without the HIP library,
     ``forward`` raises.
@@ -49,6 +50,35 @@ class HipPoseModule(nn.Module):
     def _build_plan(self, batch: int, device: torch.device):  # pragma: no cover - overridden
         raise NotImplementedError
 
+    def _param_signature(self) -> int:
+        """Changes whenever a parameter or buffer was written in place (torch bumps `_version` on every in-place op:
+        `p.data.copy_`, torch optimizers' updates) or FusedAdam stepped (its kernel writes through raw pointers and
+        bumps `optim.PARAM_EPOCH` instead): the folded/packed weights of a cached plan are then stale."""
+        from .. import optim
+        sig = optim.PARAM_EPOCH
+        for t in self.parameters():
+            sig += t._version
+        for t in self.buffers():
+            sig += t._version
+        return sig
+
+    def run_plan(self, x: torch.Tensor):
+        """forward's way into the plan: everything (plan build, launches, output allocation) happens with the INPUT's
+        device current, whatever the caller's current device is (DataParallel replicas, a model on cuda:1)."""
+        from ..plan import HandoffTimeout
+        if x.device.type != "cuda":
+            self.plan_for(x)                  # raises: there is no CPU path
+        with torch.cuda.device(x.device):
+            plan = self.plan_for(x)
+            try:
+                return plan, plan.run(x)
+            except HandoffTimeout:
+                # an in-launch producer->consumer hand-off gave up: the flags were re-zeroed by the plan; from now on
+                # this model runs the dependent chains as separate launches (no hand-off), and the caller is told
+                self._no_handoff = True
+                self.invalidate_plan()
+                raise
+
     def plan_for(self, x: torch.Tensor):
         if x.device.type != "cuda":
             raise RuntimeError(
@@ -59,10 +89,15 @@ class HipPoseModule(nn.Module):
             raise NotImplementedError(
                 "training-mode forward (batch-statistics BatchNorm + backward kernels) is not built "
                 "yet; call model.eval() — see DESIGN.md 'next rows'.")
+        sig = self._param_signature()
+        if sig != getattr(self, "_plan_sig", None):
+            self._plans = {}                  # parameters were updated in place since the plans were built
+            self._plan_sig = sig
         key = (int(x.shape[0]), x.device.index, self.compute_dtype)
         plan = self._plans.get(key)
         if plan is None:
-            plan = self._build_plan(int(x.shape[0]), x.device)
+            with torch.cuda.device(x.device):
+                plan = self._build_plan(int(x.shape[0]), x.device)
             self._plans[key] = plan
         return plan
 

@@ -29,7 +29,7 @@ class PoseHighResolutionNet(HipPoseModule):
         return HRNetPlan(self, batch, device, self.compute_dtype)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.plan_for(x).run(x)
+        return self.run_plan(x)[1]
 
 
 def get_pose_net(cfg, is_train, **kwargs):

@@ -151,14 +151,14 @@ class RSGNet(HipPoseModule):
         return RSGNetPlan(self, batch, device, self.compute_dtype)
 
     def forward(self, x: torch.Tensor, relation_target=None):
-        plan = self.plan_for(x)
-        multi, kpt, limbs = plan.run(x)
-        if relation_target is not None:
-            rel = plan.relation_mse(relation_target)          # [B], pose_rsgnet.py:1014-1018
-        elif self.materialize_relation_scores:
-            rel = plan.relation_scores()
-        else:
-            rel = RelationScores(plan)
+        plan, (multi, kpt, limbs) = self.run_plan(x)
+        with torch.cuda.device(x.device):
+            if relation_target is not None:
+                rel = plan.relation_mse(relation_target)          # [B], pose_rsgnet.py:1014-1018
+            elif self.materialize_relation_scores:
+                rel = plan.relation_scores()
+            else:
+                rel = RelationScores(plan)
         return multi, kpt, limbs, rel
 
 

@@ -30,6 +30,12 @@ def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
+class HandoffTimeout(RuntimeError):
+    """A consumer chain of a grouped launch gave up waiting for its producer (csrc/chain.hip): the forwards since
+    the last clean poll may hold wrong pixels.  The plan has re-zeroed its flag words; models/_base.py rebuilds
+    without the hand-off."""
+
+
 class VT:
     """Virtual NHWC 16-bit activation [B,H,W,ld]; ``view(c0, c)`` addresses a channel slice of it."""
 
@@ -110,6 +116,15 @@ class Plan:
         self.n_lanes = max(1, min(4, int(os.environ.get("RSGNET_HIP_LANES", "4"))))
         self._lane = 0
         self._streams: List[torch.cuda.Stream] = []
+        # in-launch hand-off (chain_group items that wait on an earlier item): off after a failure (models/_base.py)
+        self.allow_handoff = os.environ.get("RSGNET_HIP_CHAIN_HANDOFF", "1") != "0" and \
+            not getattr(model, "_no_handoff", False)
+        self._ho_flags: List[torch.Tensor] = []       # every flag buffer of this plan (re-zeroed after a timeout)
+        self._ho_seen: Optional[int] = None           # error-word value the last time it was read
+        self._ho_pinned: Optional[torch.Tensor] = None
+        self._ho_pending: Optional[torch.cuda.Event] = None
+        self._runs = 0
+        self.handoff_poll_every = 32                   # forwards between two asynchronous reads of the error word
 
     class _LaneCtx:
         def __init__(self, plan, lane):
@@ -350,7 +365,10 @@ class Plan:
                 wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
                 layers.append((wp, bo))
         out = self.new(x.H, x.W, x.C, name=name)
-        self._record(dict(kind="chain", x=x, out=out, layers=layers, name=name), [x], [out])
+        # block-input scratch: a standalone chain owns its buffer (chains of different branches run on different
+        # lanes / graph branches, and the scheduler orders ops by the buffers they name: a shared one would be a race)
+        ws = self._chain_workspace(None, x, len(layers))
+        self._record(dict(kind="chain", x=x, out=out, layers=layers, name=name, ws=ws), [x], [out, ws])
         self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
         return out
 
@@ -375,11 +393,14 @@ class Plan:
             n0 = layers[0][0].numel()
             layers = [(allw[k * n0:(k + 1) * n0], b) for k, (_, b) in enumerate(layers)]
             out = self.new(x.H, x.W, x.C, name=name)
-            subs.append(dict(x=x, out=out, layers=layers, after=after))
+            # position k of every grouped launch shares one scratch buffer per size; it is named among the op's
+            # writes, so every scheduler (lanes, explicit graph) keeps the sharers in order
+            ws = self._chain_workspace(len(subs), x, len(layers))
+            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws))
             outs.append(out)
             self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
         self._record(dict(kind="chain_group", subs=subs, name=name),
-                     [d["x"] for d in subs if d["after"] is None], outs)
+                     [d["x"] for d in subs if d["after"] is None], outs + [d["ws"] for d in subs])
         return outs
 
     def chain_mode(self, C_, H, W, nblocks) -> int:
@@ -623,16 +644,21 @@ class Plan:
         # a lone fuse-sum is a group of one (the grouped entry point takes strided operands)
         self._lower_group(dict(subs=[r], name=r["name"]))
 
-    def _chain_workspace(self, slot: int, x: VT, nlayers: int):
-        """Block-input scratch of the chain in position ``slot`` of its launch.  Launches run one after the other,
-        so position k of every launch shares one buffer per distinct size (addresses are baked into the ops)."""
+    def _chain_workspace(self, slot: Optional[int], x: VT, nlayers: int) -> Optional[torch.Tensor]:
+        """Block-input scratch of a chain.  slot None: a buffer of the op's own.  slot k: the chain in position k of a
+        grouped launch; position k of every grouped launch shares one buffer per distinct size (the op names it among
+        its writes, so the sharers stay ordered)."""
         need = int(self.lib.rsg_basic_chain_workspace_bytes(x.C, x.H, x.W, nlayers, self.batch))
         if not need:
             return None
+        if slot is None:
+            t = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._keep.append(t)
+            return t
         pool = self.__dict__.setdefault("_chain_ws", {})
         if (slot, need) not in pool:
             pool[(slot, need)] = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return pool[(slot, need)].data_ptr()
+        return pool[(slot, need)]
 
     def _lower_chain(self, r):
         x, out, layers = r["x"], r["out"], r["layers"]
@@ -642,7 +668,7 @@ class Plan:
         wps = (C.c_void_p * n)(*[w.data_ptr() for w, _ in layers])
         bps = (C.c_void_p * n)(*[b.data_ptr() for _, b in layers])
         self._keep += [wps, bps]
-        ws = self._chain_workspace(0, x, n)
+        ws = r["ws"].data_ptr() if r["ws"] is not None else None
         args = (x.ptr(), out.ptr(), wps, bps, n, self.batch, x.H, x.W, x.C, self.dtype, ws)
         fn, nm = self.lib.rsg_basic_chain, r["name"]
         info = (C.c_int32 * 4)()
@@ -673,7 +699,7 @@ class Plan:
             it.w_packed = C.cast(wps, C.POINTER(C.c_void_p))
             it.bias = C.cast(bps, C.POINTER(C.c_void_p))
             it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, x.C
-            it.workspace = self._chain_workspace(len(log), x, n)
+            it.workspace = d["ws"].data_ptr() if d["ws"] is not None else None
             log.append((x.C, x.H, x.W, n))
         for k, d in enumerate(subs):
             if d.get("after") is not None:
@@ -682,6 +708,7 @@ class Plan:
                 self.lib.rsg_basic_chain_supported(prod.c, prod.h, prod.w, prod.nlayers, prod.batch, info)
                 flags = torch.zeros(3 * info[3], dtype=torch.int32, device=self.device)   # zeroed once, self-clearing
                 self._keep.append(flags)
+                self._ho_flags.append(flags)          # ... and again by _handoff_failed after a poll that gave up
                 prod.done_flags = flags.data_ptr()
                 items[k].wait_flags = flags.data_ptr()
         # RSGNET_HIP_CHAIN_PACK=1 (experiment, off: measured neutral): when the grid has more workgroups than CUs,
@@ -803,7 +830,70 @@ class Plan:
         """RSGNET_HIP_GRAPH = 'capture' (default): stream capture of the single-stream launch order (the
         grouped launches already overlap independent work inside each grid); 'dag': explicit HIP graph with
         data-dependency edges (librsgnet_hip's graph API); '0': eager launches, lanes = streams."""
+        self._replay_launch()
+        self._runs += 1
+        if self._ho_flags:
+            self._poll_handoff()
+
+    # ---- the hand-off's error word on the production path --------------------------------------------------
+    def _handoff_count(self) -> int:
+        v = C.c_uint32(0)
+        hip.check(self.lib.rsg_chain_handoff_timeouts(C.byref(v)), "chain_handoff_timeouts")   # synchronises
+        return int(v.value)
+
+    def _handoff_failed(self, count: int):
+        for f in self._ho_flags:       # a flag nobody saw may still be (or become) 1: start the next launch clean
+            f.zero_()
+        torch.cuda.synchronize(self.device)
+        was, self._ho_seen = self._ho_seen, count
+        raise HandoffTimeout(
+            f"{count - was} hand-off poll(s) of a grouped chain launch gave up (csrc/chain.hip): forwards since the last "
+            f"clean check (at most {self.handoff_poll_every} of this plan) may hold wrong pixels. Flags re-zeroed; the "
+            "model now rebuilds its plan without the in-launch hand-off.")
+
+    def check_handoff(self):
+        """Blocking read of the error word (plan warm-up, bench end, tests); raises HandoffTimeout on an increase."""
+        if not self._ho_flags:
+            return
+        self._ho_pending = None
+        count = self._handoff_count()
+        if self._ho_seen is None:
+            self._ho_seen = count
+        elif count != self._ho_seen:
+            self._handoff_failed(count)
+
+    def _poll_handoff(self):
+        """Every `handoff_poll_every` forwards: a 4-byte asynchronous copy of the error word into pinned memory behind
+        the launches; its value is looked at on a later call, once the copy's event has completed (no stall)."""
+        if self._ho_seen is None:
+            return                                    # the warm-up run has not set the baseline yet
+        if self._ho_pending is not None and self._ho_pending.query():
+            self._ho_pending = None
+            count = int(self._ho_pinned[0].item()) & 0xFFFFFFFF
+            if count != self._ho_seen:
+                self._handoff_failed(count)
+        if self._ho_pending is None and self._runs % self.handoff_poll_every == 0:
+            if self._ho_pinned is None:
+                self._ho_pinned = torch.zeros(1, dtype=torch.int32).pin_memory()
+            st = torch.cuda.current_stream(self.device)
+            hip.check(self.lib.rsg_chain_handoff_timeouts_async(self._ho_pinned.data_ptr(), st.cuda_stream),
+                      "chain_handoff_timeouts_async")
+            ev = torch.cuda.Event()
+            ev.record(st)
+            self._ho_pending = ev
+
+    def _replay_launch(self):
         mode = self.graph_mode
+        if self._ho_flags and self._ho_seen is None:
+            # warm-up of a plan with hand-offs: one eager pass, then a blocking look at the error word (the baseline
+            # for the polls, and the first place a hand-off that cannot work on this device shows up)
+            self._ho_seen = self._handoff_count()
+            lanes, self._lanes = self._lanes, [0] * len(self._lanes)
+            try:
+                self.launch_all()
+            finally:
+                self._lanes = lanes
+            self.check_handoff()
         if mode == "0":
             self.launch_all()
             return
@@ -971,9 +1061,18 @@ class _BackboneMixin:
             return n <= 8 and self.lib.rsg_basic_chain_supported(xs[b].C, xs[b].H, xs[b].W, n, self.batch, info) \
                 and info[0] == xs[b].H
 
-        handoff = self.use_group and len(steps) > 1 and all(steps.values()) and \
-            os.environ.get("RSGNET_HIP_CHAIN_HANDOFF", "1") != "0" and \
+        handoff = self.use_group and len(steps) > 1 and all(steps.values()) and self.allow_handoff and \
             all(whole(b) or 2 * steps[b] == len(mod.branches[b]) for b in steps)
+        if handoff:
+            # workgroups that would WAIT inside the launch (the second halves of the row-tiled branches): the launch
+            # is deadlock-free whatever the dispatch order only while they cannot fill the machine (csrc/chain.hip,
+            # rsg_basic_chain_handoff_max_waiters); otherwise the second halves get a launch of their own
+            waiters = 0
+            for b in steps:
+                if not whole(b):
+                    self.lib.rsg_basic_chain_supported(xs[b].C, xs[b].H, xs[b].W, 2 * steps[b], self.batch, info)
+                    waiters += info[3]
+            handoff = waiters <= self.lib.rsg_basic_chain_handoff_max_waiters()
         if handoff:
             order = sorted(steps, key=lambda b: (not whole(b), -xs[b].C))       # whole-image chains first, widest first
             items, where = [], {}

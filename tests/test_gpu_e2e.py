@@ -216,6 +216,10 @@ def test_hrnet_w32_bf16_path_runs_and_is_coarser():
 def test_forward_is_deterministic():
     """Same input, same bits, whatever other kernels left in the CUs' LDS and caches in between (a grouped chain
     kernel that spilled registers to scratch once failed exactly this; rsgnet_amd/build.py now rejects scratch)."""
+    import ctypes
+    from rsgnet_amd import hip
+    n0 = ctypes.c_uint32(0)
+    hip.check(hip.lib().rsg_chain_handoff_timeouts(ctypes.byref(n0)))
     cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
     model = model.cuda()
     xx = torch.cat([x, x.flip(3)] * 2, 0).cuda()
@@ -229,11 +233,9 @@ def test_forward_is_deterministic():
             if first is None:
                 first = y
             assert torch.equal(y, first), rep
-    import ctypes
-    from rsgnet_amd import hip
     n = ctypes.c_uint32(99)
     hip.check(hip.lib().rsg_chain_handoff_timeouts(ctypes.byref(n)))
-    assert n.value == 0           # no consumer chain ever gave up waiting for its producer
+    assert n.value == n0.value    # no consumer chain gave up waiting for its producer
 
 
 def test_eval_pipeline_picture_to_keypoints():
@@ -275,3 +277,30 @@ def test_eval_pipeline_picture_to_keypoints():
     kept = nms.rescore_and_nms(db, 17, 0.0, 0.9)
     want_keep = co.oks_nms(got, co.rescore(got, [1.0] * 4, 0.0), [d["area"] for d in db], 0.9)
     assert [id(k) for k in kept] == [id(db[i]) for i in want_keep]
+
+
+def test_handoff_timeout_reaches_the_caller_and_the_model_recovers():
+    """The in-launch hand-off of the row-tiled branch has a bounded poll; a poll that gives up must not pass silently:
+    the plan reads the sticky error word (here at its warm-up), re-zeroes its flags and raises, and the model then
+    runs the dependent chains as separate launches.  The failure is provoked with the library's debug switch
+    'producers never signal' (rsg_tune chain_debug 4)."""
+    from rsgnet_amd import hip
+    from rsgnet_amd.plan import HandoffTimeout
+    cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+    model = model.cuda()
+    xx = torch.cat([x] * 4, 0).cuda()
+    lib = hip.lib()
+    with torch.no_grad():
+        good = model(xx).clone()
+        assert model._plans and all(p._ho_flags for p in model._plans.values())     # the hand-off is in use
+        model.invalidate_plan()
+        hip.check(lib.rsg_tune(b"chain_debug", 4))
+        try:
+            with pytest.raises(HandoffTimeout):
+                model(xx)
+        finally:
+            hip.check(lib.rsg_tune(b"chain_debug", 0))
+        assert model._no_handoff and not model._plans
+        again = model(xx)                         # rebuilt without the hand-off: separate launches, same bits
+        assert not any(p._ho_flags for p in model._plans.values())
+        assert torch.equal(again, good)

@@ -100,3 +100,72 @@ def test_fused_adam_matches_goldens_and_oracle():
         ref = [to.adam_step(r[0], 0.5 * gg.cpu().double().numpy(), r[1], r[2], step, lr=3e-3) for r, gg in zip(ref, gs)]
         for q, r in zip(ps, ref):
             assert np.abs(q.detach().cpu().numpy() - r[0]).max() < 5e-6
+
+
+@pytest.mark.gpu
+def test_fused_adam_checkpoint_round_trip_against_torch_adam():
+    """save -> load -> step in both directions with torch.optim.Adam (the reference saves optimizer.state_dict(),
+    tools/train.py:223, and resumes with load_state_dict): moments and step counts survive, a parameter whose grad is
+    None is skipped exactly as torch skips it, and a torch.optim.Adam checkpoint loads into FusedAdam."""
+    from rsgnet_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = ((7, 3), (33,), (4, 4), (5, 5, 2), (1,))
+    FROZEN = 2                                         # like RSGNet's loc_features: in the index space, never stepped
+    init = [torch.randn(s) for s in shapes]
+
+    def mk(tensors):
+        out = [torch.nn.Parameter(t.detach().clone().cuda()) for t in tensors]
+        out[FROZEN].requires_grad_(False)
+        return out
+
+    grads = [[torch.randn(s) for s in shapes] for _ in range(6)]
+
+    def run(opt, ps, steps, skip=None):
+        for k in steps:
+            for i, (q, g) in enumerate(zip(ps, grads[k])):
+                if i == FROZEN:
+                    continue
+                if skip is not None and i == skip and k % 2 == 1:
+                    q.grad = None                      # an unused parameter on odd steps
+                elif q.grad is None:
+                    q.grad = g.to(q.device).clone()
+                else:
+                    q.grad.copy_(g)
+            opt.step()
+
+    ref_p = mk(init)
+    ref = torch.optim.Adam(ref_p, lr=2e-3)
+    run(ref, ref_p, range(6), skip=1)
+
+    # (a) FusedAdam alone, same schedule, grad None on the same steps
+    ps = mk(init)
+    opt = FusedAdam(ps, lr=2e-3)
+    run(opt, ps, range(3), skip=1)
+    sd = opt.state_dict()
+    assert set(sd["state"]) == {0, 1, 3, 4} and sd["param_groups"][0]["params"] == [0, 1, 2, 3, 4] and set(sd["state"][1]) == {"step", "exp_avg", "exp_avg_sq"}
+    assert float(sd["state"][1]["step"]) == 2.0 and float(sd["state"][0]["step"]) == 3.0
+    # (b) resume in a NEW FusedAdam from that checkpoint
+    ps2 = mk(ps)
+    opt2 = FusedAdam(ps2, lr=1.0)
+    opt2.load_state_dict(sd)
+    assert opt2.param_groups[0]["lr"] == 2e-3 and opt2.step_count == 3
+    run(opt2, ps2, range(3, 6), skip=1)
+    for q, r in zip(ps2, ref_p):
+        assert (q.detach() - r.detach()).abs().max().item() < 5e-6
+    # (c) the FusedAdam checkpoint loads into torch.optim.Adam and continues identically
+    ps3 = mk(ps)
+    t3 = torch.optim.Adam(ps3, lr=1.0)
+    t3.load_state_dict(sd)
+    run(t3, ps3, range(3, 6), skip=1)
+    for q, r in zip(ps3, ref_p):
+        assert (q.detach() - r.detach()).abs().max().item() < 5e-6
+    # (d) a torch.optim.Adam checkpoint loads into FusedAdam
+    half_p = mk(init)
+    half = torch.optim.Adam(half_p, lr=2e-3)
+    run(half, half_p, range(3), skip=1)
+    ps4 = mk(half_p)
+    opt4 = FusedAdam(ps4, lr=1.0)
+    opt4.load_state_dict(half.state_dict())
+    run(opt4, ps4, range(3, 6), skip=1)
+    for q, r in zip(ps4, ref_p):
+        assert (q.detach() - r.detach()).abs().max().item() < 5e-6
