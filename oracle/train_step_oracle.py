@@ -1,0 +1,84 @@
+"""ORACLE -- test infrastructure, NOT product code (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import it).
+
+CPU restatement of ONE training step of pose_hrnet as the reference runs it:
+  * `outputs = model(input)` with the model in train() mode       /root/reference/lib/core/function.py:27-52
+      = pose_hrnet.py:428-463 with every BatchNorm2d normalising by the batch statistics (biased variance) and
+        updating its running statistics with momentum 0.1 (unbiased variance)   pose_hrnet.py:19, SURVEY App. D
+  * `loss = criterion(outputs, target, target_weight)`            lib/core/loss.py:14-38 (JointsMSELoss)
+  * `loss.backward()`                                             function.py:62-64 -- torch autograd
+  * `optimizer.step()`                                            lib/utils/utils.py:70-74 (Adam): oracle/train_oracle.adam_step
+It walks the same functional graph as oracle/pose_oracle.py (its `calibrate` mode IS training-mode BatchNorm) with
+autograd enabled, in fp64 by default.  Pinned by tests/golden/train_step_hrnet_w32_256x192.npz, produced by
+oracle/make_train_step_goldens.py from the imported reference model and loss (forward, loss, gradients, running stats).
+"""
+from __future__ import annotations
+
+from typing import Dict, Mapping, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import pose_oracle as po
+
+BN_MOMENTUM = 0.1   # pose_hrnet.py:19
+
+
+def is_buffer(name: str) -> bool:
+    return name.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
+def joints_mse_loss(output: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor, use_target_weight: bool = True):
+    """lib/core/loss.py:20-38, in torch ops (differentiable): mean over joints of 0.5 * MSE(pred_j * w_j, gt_j * w_j)."""
+    B, J = output.shape[:2]
+    pred = output.reshape(B, J, -1)
+    gt = target.reshape(B, J, -1).to(output.dtype)
+    loss = output.new_zeros(())
+    for j in range(J):
+        p, g = pred[:, j], gt[:, j]
+        if use_target_weight:
+            w = target_weight.reshape(B, J, 1)[:, j].to(output.dtype)
+            p, g = p * w, g * w
+        loss = loss + 0.5 * F.mse_loss(p, g, reduction="mean")
+    return loss / J
+
+
+def gaussian_targets(batch: int, joints: int, hw: Tuple[int, int], seed: int, sigma: float = 2.0):
+    """Seeded training targets shaped like the reference's (lib/dataset/JointsDataset.py generate_target, 'gaussian'):
+    one unnormalised Gaussian per joint and a 0/1 visibility weight [B,J,1].  Data for tests, not a restatement."""
+    r = np.random.RandomState(seed)
+    H, W = hw
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    t = np.zeros((batch, joints, H, W), np.float32)
+    w = (r.uniform(size=(batch, joints, 1)) > 0.2).astype(np.float32)
+    for b in range(batch):
+        for j in range(joints):
+            cx, cy = r.uniform(2, W - 3), r.uniform(2, H - 3)
+            t[b, j] = np.exp(-((xs - np.round(cx)) ** 2 + (ys - np.round(cy)) ** 2) / (2 * sigma ** 2)) * w[b, j, 0]
+    return torch.from_numpy(t), torch.from_numpy(w)
+
+
+def hrnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor,
+                     use_target_weight: bool = True, dtype=torch.float64):
+    """One forward/backward of pose_hrnet in train() mode.
+    Returns (loss, heatmaps, {param name: gradient}, {buffer name: running statistic after the step})."""
+    work: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if not is_buffer(k):
+            t = t.to(dtype).requires_grad_(True)
+        work[k] = t
+    old = {k: v.detach().clone().double() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}
+    ctx = po.Ctx(work, dtype=dtype, calibrate=True)          # calibrate = batch statistics (training-mode BatchNorm)
+    ctx.sd = dict(work)                                       # the walk overwrites running stats; keep `work` intact
+    ys = po.backbone(ctx, x.to(dtype), cfg)
+    w, b = ctx.p("final_layer.weight"), ctx.p("final_layer.bias")
+    heat = F.conv2d(ys[0], w, b, padding=(w.shape[-1] - 1) // 2)
+    loss = joints_mse_loss(heat, target, target_weight, use_target_weight)
+    names = [k for k in work if not is_buffer(k)]
+    grads = torch.autograd.grad(loss, [work[k] for k in names], allow_unused=True)
+    gd = {k: (g.detach() if g is not None else None) for k, g in zip(names, grads)}
+    # calibrate mode stored (batch mean, unbiased batch variance): fold them in with the reference's momentum
+    stats = {k: ((1 - BN_MOMENTUM) * old[k] + BN_MOMENTUM * ctx.sd[k].detach().double()) for k in old}
+    return loss.detach(), heat.detach(), gd, stats

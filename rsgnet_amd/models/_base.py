@@ -30,10 +30,12 @@ class HipPoseModule(nn.Module):
     def __init__(self):
         super().__init__()
         self._plans = {}
+        self._train_plans = {}
 
     # -- plan lifecycle ---------------------------------------------------------------------
     def invalidate_plan(self) -> None:
         self._plans = {}
+        self._train_plans = {}
 
     def _apply(self, fn, *a, **kw):
         self.invalidate_plan()
@@ -44,8 +46,25 @@ class HipPoseModule(nn.Module):
         return super().load_state_dict(*a, **kw)
 
     def train(self, mode: bool = True):
-        self.invalidate_plan()
+        if mode != self.training:
+            self._plans = {}                  # eval plans fold the running statistics; training plans read everything live
         return super().train(mode)
+
+    #: models whose training-mode forward/backward is built (rsgnet_amd/train.py) set this
+    supports_training = False
+
+    def train_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """`model(x)` under `model.train()`: batch-statistics BatchNorm, one autograd node whose backward runs the HIP
+        backward kernels and writes the parameters' `.grad` (rsgnet_amd/train.py)."""
+        if x.device.type != "cuda":
+            raise RuntimeError(f"{type(self).__name__} runs only on an AMD GPU through librsgnet_hip.so; got a "
+                               f"{x.device.type} tensor. There is no CPU fallback.")
+        if not self.supports_training:
+            raise NotImplementedError(
+                f"training-mode forward of {type(self).__name__} is not built (pose_hrnet is: SURVEY 8(e) config 4); "
+                "call model.eval()")
+        from ..train import train_forward
+        return train_forward(self, x)
 
     def _build_plan(self, batch: int, device: torch.device):  # pragma: no cover - overridden
         raise NotImplementedError
@@ -87,8 +106,8 @@ class HipPoseModule(nn.Module):
                 "and is test infrastructure).")
         if self.training:
             raise NotImplementedError(
-                "training-mode forward (batch-statistics BatchNorm + backward kernels) is not built "
-                "yet; call model.eval() — see DESIGN.md 'next rows'.")
+                f"{type(self).__name__}: the inference plan serves model.eval() only; training-mode forward goes "
+                "through train_forward() (built for pose_hrnet).")
         sig = self._param_signature()
         if sig != getattr(self, "_plan_sig", None):
             self._plans = {}                  # parameters were updated in place since the plans were built

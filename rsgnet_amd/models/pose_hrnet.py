@@ -28,7 +28,11 @@ class PoseHighResolutionNet(HipPoseModule):
         from ..plan import HRNetPlan
         return HRNetPlan(self, batch, device, self.compute_dtype)
 
+    supports_training = True
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            return self.train_forward(x)
         return self.run_plan(x)[1]
 
 

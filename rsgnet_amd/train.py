@@ -1,0 +1,424 @@
+"""Training-mode execution of pose_hrnet on the HIP kernels: forward with batch-statistics BatchNorm, backward, all
+gradients written straight into the parameters' fp32 `.grad` tensors.
+
+What it replaces: `outputs = model(input)` ... `loss.backward()` of the reference's training loop
+(/root/reference/lib/core/function.py:27-80), i.e. torch autograd over pose_hrnet.py:428-463 in `model.train()` mode.
+The model's forward returns the fp32 NCHW heat maps as the output of ONE autograd node (`_TrainFn`); its backward takes
+the heat-map gradient that the loss hands back and runs the recorded backward launch list.
+
+Numerics: activations, their gradients and the packed weights are bf16 (same exponent range as fp32: no loss scaling),
+every contraction accumulates in fp32, BatchNorm statistics and all parameter gradients are fp32, master weights stay
+the module's fp32 parameters (re-packed on the device at every forward: one launch).  All reductions have a fixed
+order, so a step is bit-reproducible.
+
+Recording is two-phase: the forward walk creates op objects (inputs, outputs, forward launcher); the backward launch
+list is then generated from the ops in reverse, which is when gradient buffers are allocated and the "first writer
+writes, later writers add" decisions are taken in execution order.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+BF16 = hip.DTYPES["bf16"]
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class T:
+    """A dense NHWC bf16 map [B,H,W,C] of the training graph and, during backward recording, its gradient."""
+
+    __slots__ = ("H", "W", "C", "data", "grad", "grad_shared", "needs_grad", "name")
+
+    def __init__(self, plan: "TrainPlan", H: int, W: int, C_: int, name: str = "", needs_grad: bool = True):
+        self.H, self.W, self.C, self.name = H, W, C_, name
+        self.data = torch.zeros(plan.batch, H, W, C_, dtype=torch.bfloat16, device=plan.device)
+        self.grad: Optional[torch.Tensor] = None
+        self.grad_shared = False
+        self.needs_grad = needs_grad
+
+    @property
+    def pixels(self) -> int:
+        return self.data.shape[0] * self.H * self.W
+
+
+class TrainPlan:
+    """Forward and backward launch lists of pose_hrnet in training mode for one (batch, device)."""
+
+    def __init__(self, model: nn.Module, batch: int, device: torch.device):
+        self.lib = hip.lib()
+        self.model, self.batch, self.device = model, batch, device
+        self.fwd: List[Tuple[str, Callable[[int], None]]] = []
+        self.bwd: List[Tuple[str, Callable[[int], None]]] = []
+        self._ops: List[dict] = []
+        self._keep: List[object] = []
+        self._packs: List[dict] = []            # one entry per packed weight (forward and data-gradient forms)
+        self._bn_ws = torch.empty(self.lib.rsg_bn_workspace_bytes(256), dtype=torch.uint8, device=device)
+        self._wgrad_ws: Optional[torch.Tensor] = None
+        self._wgrad_need = 0
+        self._zero_bias = torch.zeros(256, dtype=torch.float32, device=device)
+        self._param_ptrs: Optional[Tuple[int, ...]] = None
+        self.flops_fwd = 0
+        W, H = model.cfg.MODEL.IMAGE_SIZE
+        self.H, self.W, self.J = H, W, model.cfg.MODEL.NUM_JOINTS
+        self.x_f32 = torch.zeros(batch, 3, H, W, dtype=torch.float32, device=device)
+        self.heat = torch.zeros(batch, self.J, H // 4, W // 4, dtype=torch.float32, device=device)
+        self.dheat = torch.zeros_like(self.heat)
+        self._record(model)
+        self._record_backward()
+        self._wgrad_ws = torch.empty(max(self._wgrad_need, 16), dtype=torch.uint8, device=device)
+        self._build_pack_table()
+        self._nbt = [m.num_batches_tracked for m in model.modules()
+                     if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+
+    # ------------------------------------------------------------------ helpers
+    def _chk(self, rc: int, what: str):
+        if rc:
+            hip.check(rc, what)
+
+    @staticmethod
+    def _grad_of(p: torch.nn.Parameter) -> torch.Tensor:
+        """The parameter's fp32 gradient tensor (allocated when the optimizer left it None)."""
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        return p.grad
+
+    def _packed(self, w: torch.nn.Parameter, transpose: bool) -> torch.Tensor:
+        O, I, kh, kw = w.shape
+        cin, cout = (O, I) if transpose else (I, O)
+        dst = torch.zeros(self.lib.rsg_conv_packed_bytes(cin, cout, kh, kw), dtype=torch.uint8, device=self.device)
+        self._packs.append(dict(w=w, dst=dst, transpose=transpose, blocks=self.lib.rsg_pack_item_blocks(cin, cout, kh, kw)))
+        return dst
+
+    def _build_pack_table(self):
+        """(Re)build the device table of the weight packer: it holds the parameters' CURRENT addresses (an optimizer
+        such as FusedAdam re-seats `.data` into its flat buffer)."""
+        items = (hip.PackItem * len(self._packs))()
+        blocks = 0
+        for it, p in zip(items, self._packs):
+            w = p["w"]
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise ValueError("training needs contiguous fp32 master weights")
+            O, I, kh, kw = w.shape
+            it.w, it.dst, it.cin, it.cout, it.kh, it.kw = w.data_ptr(), p["dst"].data_ptr(), I, O, kh, kw
+            it.transpose, it.first_block = int(p["transpose"]), blocks
+            blocks += p["blocks"]
+        self._pack_items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(self.device)
+        self._pack_blocks = blocks
+        self._param_ptrs = tuple(p["w"].data_ptr() for p in self._packs)
+
+    def _conv_desc(self, x: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, out16: Optional[torch.Tensor],
+                   out_f32: Optional[torch.Tensor], H: int, W: int, cin_pad: int, cout: int, k: int, stride: int) -> "hip.ConvDesc":
+        pad = (k - 1) // 2
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        d = hip.ConvDesc()
+        d.inp, d.w_packed, d.bias = x.data_ptr(), wp.data_ptr(), bias.data_ptr()
+        d.out16 = out16.data_ptr() if out16 is not None else None
+        d.out_nchw_f32 = out_f32.data_ptr() if out_f32 is not None else None
+        d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = self.batch, H, W, cin_pad, cin_pad
+        d.out_h, d.out_w, d.out_c, d.out_ld = Ho, Wo, cout, _round_up(cout, 32)
+        d.kh, d.kw, d.stride, d.pad_y, d.pad_x = k, k, stride, pad, pad
+        d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, Ho, Wo
+        d.relu, d.dtype = 0, BF16
+        self._keep.append(d)
+        return d
+
+    # ------------------------------------------------------------------ forward recording
+    def conv(self, x: T, m: nn.Conv2d, name: str) -> T:
+        """y = conv(x) (no bias, no activation; BatchNorm follows as its own op)."""
+        O, I, k, _ = m.weight.shape
+        stride = m.stride[0]
+        cin_pad = self.lib.rsg_conv_padded_cin(I)
+        if x.C != cin_pad or m.bias is not None or O % 32:
+            raise NotImplementedError(f"{name}: conv {I}->{O} on a {x.C}-channel map")
+        pad = (k - 1) // 2
+        y = T(self, (x.H + 2 * pad - k) // stride + 1, (x.W + 2 * pad - k) // stride + 1, O, name)
+        wp = self._packed(m.weight, False)
+        d = self._conv_desc(x.data, wp, self._zero_bias, y.data, None, x.H, x.W, cin_pad, O, k, stride)
+        fn, ref = self.lib.rsg_conv_igemm, C.byref(d)
+        self.fwd.append((name, lambda s, fn=fn, ref=ref, nm=name: self._chk(fn(ref, s), nm)))
+        self._ops.append(dict(kind="conv", x=x, y=y, m=m, name=name, cin_pad=cin_pad))
+        self.flops_fwd += 2 * self.batch * y.H * y.W * O * I * k * k
+        return y
+
+    def bn(self, y: T, m: nn.BatchNorm2d, relu: bool, res: Optional[T], name: str) -> T:
+        """z = [ReLU](BatchNorm_train(y) [+ res]); running statistics updated in place (momentum m.momentum)."""
+        z = T(self, y.H, y.W, y.C, name)
+        mean = torch.zeros(y.C, dtype=torch.float32, device=self.device)
+        invstd = torch.zeros(y.C, dtype=torch.float32, device=self.device)
+        lib, ws, px, Cc = self.lib, self._bn_ws, y.pixels, y.C
+        mom, eps = float(m.momentum), float(m.eps)
+
+        def launch(s):
+            self._chk(lib.rsg_bn_stats(y.data.data_ptr(), px, Cc, BF16, ws.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                       m.running_mean.data_ptr(), m.running_var.data_ptr(), mom, eps, s), name)
+            self._chk(lib.rsg_bn_apply(y.data.data_ptr(), mean.data_ptr(), invstd.data_ptr(), m.weight.data_ptr(),
+                                       m.bias.data_ptr(), res.data.data_ptr() if res is not None else None, int(relu),
+                                       z.data.data_ptr(), px, Cc, BF16, s), name)
+
+        self.fwd.append((name, launch))
+        self._ops.append(dict(kind="bn", y=y, z=z, m=m, relu=relu, res=res, mean=mean, invstd=invstd, name=name))
+        return z
+
+    def unit(self, x: T, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, name: str, res: Optional[T] = None) -> T:
+        return self.bn(self.conv(x, conv, name), bn, relu, res, name + ".bn")
+
+    def fuse_sum(self, same: Sequence[T], low: Sequence[Tuple[T, int]], name: str) -> T:
+        """out = ReLU(sum same + sum nearest_up(low)) (pose_hrnet.py:259-266)."""
+        ref = same[0]
+        out = T(self, ref.H, ref.W, ref.C, name)
+        sp = (C.c_void_p * len(same))(*[t.data.data_ptr() for t in same])
+        lp = (C.c_void_p * max(len(low), 1))(*[t.data.data_ptr() for t, _ in low])
+        ls = (C.c_int32 * max(len(low), 1))(*[s for _, s in low])
+        self._keep += [sp, lp, ls]
+        lib, B = self.lib, self.batch
+        self.fwd.append((name, lambda s: self._chk(lib.rsg_hr_fuse_sum(sp, len(same), lp, ls, len(low), out.data.data_ptr(), B,
+                                                                     out.H, out.W, out.C, BF16, s), name)))
+        self._ops.append(dict(kind="fuse", same=list(same), low=list(low), out=out, name=name))
+        return out
+
+    def _record(self, m: nn.Module):
+        lib, B, H, W = self.lib, self.batch, self.H, self.W
+        x16 = T(self, H, W, 16, "x_nhwc16", needs_grad=False)
+        self.fwd.append(("input", lambda s: self._chk(lib.rsg_nchw_f32_to_nhwc16(self.x_f32.data_ptr(), x16.data.data_ptr(), B, 3,
+                                                                              H, W, 16, BF16, s), "input")))
+        x = self.unit(x16, m.conv1, m.bn1, True, "conv1")
+        x = self.unit(x, m.conv2, m.bn2, True, "conv2")
+        for k, blk in enumerate(m.layer1):
+            x = self._block(x, blk, f"layer1.{k}")
+        ys = [x]
+        for s in (2, 3, 4):
+            trans = getattr(m, f"transition{s - 1}")
+            xs = []
+            for i, tr in enumerate(trans):
+                if i < len(ys):
+                    xs.append(ys[i] if tr is None else self.unit(ys[i], tr[0], tr[1], True, f"transition{s - 1}.{i}"))
+                else:
+                    t = ys[-1]
+                    for j, step in enumerate(tr):
+                        t = self.unit(t, step[0], step[1], True, f"transition{s - 1}.{i}.{j}")
+                    xs.append(t)
+            for k, mod in enumerate(getattr(m, f"stage{s}")):
+                xs = self._hr_module(xs, mod, f"stage{s}.{k}")
+            ys = xs
+        # classifier: 1x1 conv + bias -> fp32 NCHW heat maps (pose_hrnet.py:326-332,461)
+        fl = m.final_layer
+        if fl.kernel_size != (1, 1):
+            raise NotImplementedError("FINAL_CONV_KERNEL=3")
+        x0 = ys[0]
+        J = self.J
+        wp = self._packed(fl.weight, False)
+        bias32 = torch.zeros(_round_up(J, 32), dtype=torch.float32, device=self.device)
+        d = self._conv_desc(x0.data, wp, bias32, None, self.heat, x0.H, x0.W, x0.C, J, 1, 1)
+        ref = C.byref(d)
+
+        def launch(s):
+            bias32[:J].copy_(fl.bias.detach())
+            self._chk(lib.rsg_conv_igemm(ref, s), "final_layer")
+
+        self.fwd.append(("final_layer", launch))
+        self._ops.append(dict(kind="final", x=x0, m=fl, name="final_layer"))
+        self.flops_fwd += 2 * B * x0.H * x0.W * J * x0.C
+
+    def _block(self, x: T, blk, name: str) -> T:
+        """BasicBlock / Bottleneck in training mode (pose_hrnet.py:30-101)."""
+        res = x
+        if blk.downsample is not None:
+            res = self.unit(x, blk.downsample[0], blk.downsample[1], False, name + ".downsample")
+        y = self.unit(x, blk.conv1, blk.bn1, True, name + ".conv1")
+        if hasattr(blk, "conv3"):
+            y = self.unit(y, blk.conv2, blk.bn2, True, name + ".conv2")
+            return self.unit(y, blk.conv3, blk.bn3, True, name + ".conv3", res=res)
+        return self.unit(y, blk.conv2, blk.bn2, True, name + ".conv2", res=res)
+
+    def _hr_module(self, xs: List[T], mod, name: str) -> List[T]:
+        """HighResolutionModule.forward (pose_hrnet.py:250-268), training mode."""
+        xs = list(xs)
+        for b, branch in enumerate(mod.branches):
+            for k, blk in enumerate(branch):
+                xs[b] = self._block(xs[b], blk, f"{name}.branches.{b}.{k}")
+        if mod.fuse_layers is None:
+            return xs
+        outs = []
+        for i, row in enumerate(mod.fuse_layers):
+            same, low = [], []
+            for j, fl in enumerate(row):
+                if j == i:
+                    same.append(xs[j])
+                elif j > i:
+                    low.append((self.unit(xs[j], fl[0], fl[1], False, f"{name}.fuse.{i}.{j}"), j - i))
+                else:
+                    t = xs[j]
+                    for k, step in enumerate(fl):
+                        t = self.unit(t, step[0], step[1], k != len(fl) - 1, f"{name}.fuse.{i}.{j}.{k}")
+                    same.append(t)
+            outs.append(self.fuse_sum(same, low, f"{name}.fuse.{i}"))
+        return outs
+
+    # ------------------------------------------------------------------ backward recording
+    def _contribute(self, t: T, src: torch.Tensor, shared: bool, name: str):
+        """`src` (a gradient of t) joins t.grad: the first one becomes it, later ones are added.  A buffer that several
+        maps alias (`shared`) is never written in place."""
+        if not t.needs_grad:
+            return
+        if t.grad is None:
+            t.grad, t.grad_shared = src, shared
+            return
+        lib, n = self.lib, src.numel()
+        a = t.grad
+        dst = torch.empty_like(a) if t.grad_shared else a
+        self.bwd.append((name + ".add", lambda s: self._chk(lib.rsg_add16(a.data_ptr(), src.data_ptr(), dst.data_ptr(), n, BF16, s), name)))
+        t.grad, t.grad_shared = dst, False
+
+    def _new_like(self, t: T) -> torch.Tensor:
+        return torch.zeros_like(t.data)
+
+    def _record_backward(self):
+        lib, B = self.lib, self.batch
+        for op in reversed(self._ops):
+            kind, name = op["kind"], op["name"]
+            if kind == "final":
+                x, fl = op["x"], op["m"]
+                J = self.J
+                d16 = torch.zeros(B, x.H, x.W, 32, dtype=torch.bfloat16, device=self.device)
+                self.bwd.append((name + ".dheat", lambda s, d16=d16, x=x: self._chk(
+                    lib.rsg_nchw_f32_to_nhwc16(self.dheat.data_ptr(), d16.data_ptr(), B, J, x.H, x.W, 32, BF16, s), "dheat")))
+                self.bwd.append((name + ".dbias", lambda s, fl=fl, x=x: self._chk(
+                    lib.rsg_channel_sum_nchw_f32(self.dheat.data_ptr(), self._grad_of(fl.bias).data_ptr(), B, J, x.H * x.W, s), "dbias")))
+                self._wgrad(x.data, d16, fl.weight, x.H, x.W, x.C, x.C, x.H, x.W, J, 32, 1, 1, name)
+                self._dgrad(x, d16, fl.weight, 32, 1, 1, x.H, x.W, name)
+            elif kind == "fuse":
+                out = op["out"]
+                if out.grad is None:
+                    continue                              # an output nobody consumed (does not occur in pose_hrnet)
+                g = torch.zeros_like(out.data)
+                dout, n = out.grad, out.data.numel()
+                self.bwd.append((name + ".relu", lambda s, dout=dout, out=out, g=g, n=n: self._chk(
+                    lib.rsg_relu_backward(dout.data_ptr(), out.data.data_ptr(), g.data_ptr(), n, BF16, s), "relu_backward")))
+                for t in op["same"]:
+                    self._contribute(t, g, True, name)
+                for t, sh in op["low"]:
+                    lo = torch.zeros_like(t.data)
+                    self.bwd.append((name + ".up", lambda s, g=g, lo=lo, t=t, sh=sh: self._chk(
+                        lib.rsg_upsample_nearest_backward(g.data_ptr(), lo.data_ptr(), B, t.H, t.W, t.C, sh, BF16, s), "upsample_bwd")))
+                    self._contribute(t, lo, False, name)
+            elif kind == "bn":
+                y, z, m, res = op["y"], op["z"], op["m"], op["res"]
+                if z.grad is None:
+                    raise RuntimeError(f"{name}: output has no gradient (dead branch)")
+                dz = z.grad
+                y.grad = torch.zeros_like(y.data)
+                dres = torch.zeros_like(z.data) if res is not None and res.needs_grad else None
+                mean, invstd, relu, ws, px, Cc = op["mean"], op["invstd"], op["relu"], self._bn_ws, y.pixels, y.C
+
+                def launch(s, dz=dz, y=y, z=z, m=m, dres=dres, mean=mean, invstd=invstd, relu=relu, px=px, Cc=Cc):
+                    self._chk(lib.rsg_bn_backward(dz.data_ptr(), z.data.data_ptr() if relu else None, y.data.data_ptr(),
+                                                  mean.data_ptr(), invstd.data_ptr(), m.weight.data_ptr(), y.grad.data_ptr(),
+                                                  dres.data_ptr() if dres is not None else None,
+                                                  self._grad_of(m.weight).data_ptr(), self._grad_of(m.bias).data_ptr(),
+                                                  ws.data_ptr(), px, Cc, BF16, s), "bn_backward")
+
+                self.bwd.append((name, launch))
+                if dres is not None:
+                    self._contribute(res, dres, False, name)
+            elif kind == "conv":
+                x, y, m = op["x"], op["y"], op["m"]
+                O, I, k, _ = m.weight.shape
+                stride = m.stride[0]
+                self._wgrad(x.data, y.grad, m.weight, x.H, x.W, I, op["cin_pad"], y.H, y.W, O, O, k, stride, name)
+                if x.needs_grad:
+                    self._dgrad(x, y.grad, m.weight, O, k, stride, y.H, y.W, name)
+
+    def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, w: torch.nn.Parameter, H, W, cin, cin_pad, Ho, Wo, cout, cout_pad, k, stride, name):
+        lib, B, pad = self.lib, self.batch, (k - 1) // 2
+        need = int(lib.rsg_conv_wgrad_workspace_bytes(B, H, W, cin_pad, Ho, Wo, cout_pad, k, k, stride, pad))
+        if not need:
+            raise NotImplementedError(f"{name}: weight gradient of a {k}x{k} stride-{stride} conv")
+        self._wgrad_need = max(self._wgrad_need, need)
+
+        def launch(s):
+            self._chk(lib.rsg_conv_wgrad(x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_ws.data_ptr(), B, H, W,
+                                         cin, cin_pad, Ho, Wo, cout, cout_pad, k, k, stride, pad, BF16, s), name + ".wgrad")
+
+        self.bwd.append((name + ".wgrad", launch))
+
+    def _dgrad(self, x: T, dy: torch.Tensor, w: torch.nn.Parameter, dy_c: int, k: int, stride: int, Ho: int, Wo: int, name: str):
+        """dx = conv_transpose(dy, w): a stride-1 conv of dy (stride 2: of dy spread onto the input grid with zeros
+        between) with the transposed, flipped weights (rsg_pack_conv_weights_device, transpose = 1)."""
+        lib, B = self.lib, self.batch
+        wp = self._packed(w, True)
+        src, sh, sw = dy, Ho, Wo
+        if stride == 2:
+            if (2 * Ho, 2 * Wo) != (x.H, x.W):
+                raise NotImplementedError(f"{name}: stride-2 data gradient on an odd map")
+            src = torch.zeros(B, 2 * Ho, 2 * Wo, dy_c, dtype=torch.bfloat16, device=self.device)
+            self.bwd.append((name + ".spread", lambda s: self._chk(lib.rsg_zero_insert2x(dy.data_ptr(), src.data_ptr(), B, Ho, Wo, dy_c, s), name)))
+            sh, sw = 2 * Ho, 2 * Wo
+        dx = torch.zeros_like(x.data)
+        cin_real = w.shape[1]
+        d = self._conv_desc(src, wp, self._zero_bias, dx, None, sh, sw, dy_c, cin_real, k, 1)
+        if _round_up(cin_real, 32) != x.C:
+            raise NotImplementedError(f"{name}: data gradient into a {x.C}-channel map")
+        ref = C.byref(d)
+        self.bwd.append((name + ".dgrad", lambda s: self._chk(lib.rsg_conv_igemm(ref, s), name + ".dgrad")))
+        self._contribute(x, dx, False, name)
+
+    # ------------------------------------------------------------------ execution
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if tuple(x.shape) != tuple(self.x_f32.shape):
+            raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_f32.shape)}")
+        if tuple(p["w"].data_ptr() for p in self._packs) != self._param_ptrs:
+            self._build_pack_table()              # the optimizer re-seated the parameters
+        self.x_f32.copy_(x)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self._chk(self.lib.rsg_pack_conv_weights_device(self._pack_items.data_ptr(), len(self._packs), self._pack_blocks, BF16, s),
+                  "pack_weights")
+        for _, op in self.fwd:
+            op(s)
+        torch._foreach_add_(self._nbt, 1)            # num_batches_tracked of every BatchNorm, one launch
+        return self.heat.clone()
+
+    def backward(self, dheat: torch.Tensor) -> None:
+        self.dheat.copy_(dheat)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        for _, op in self.bwd:
+            op(s)
+
+
+class _TrainFn(torch.autograd.Function):
+    """The whole training-mode forward as one autograd node: backward = the HIP backward launch list, parameter
+    gradients are written into `p.grad` by the kernels (overwritten, as after `optimizer.zero_grad()`)."""
+
+    @staticmethod
+    def forward(ctx, hook: torch.Tensor, plan: TrainPlan, x: torch.Tensor):
+        ctx.plan = plan
+        with torch.cuda.device(x.device):
+            return plan.forward(x)
+
+    @staticmethod
+    def backward(ctx, dheat: torch.Tensor):
+        plan: TrainPlan = ctx.plan
+        with torch.cuda.device(dheat.device):
+            plan.backward(dheat.contiguous().float())
+        return None, None, None
+
+
+def train_forward(model: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """`model(x)` in training mode (models/_base.py calls this)."""
+    key = (int(x.shape[0]), x.device.index)
+    plan = model._train_plans.get(key)
+    if plan is None:
+        with torch.cuda.device(x.device):
+            plan = TrainPlan(model, int(x.shape[0]), x.device)
+        model._train_plans[key] = plan
+    hook = getattr(model, "_train_hook", None)
+    if hook is None or hook.device != x.device:
+        hook = model._train_hook = torch.zeros(1, device=x.device, requires_grad=True)
+    return _TrainFn.apply(hook, plan, x)
