@@ -183,6 +183,95 @@ def family_table(plan, per_op):
     return fams
 
 
+def train_bench(a, rank, world, local, dev, dist):
+    """BASELINE configs[3]: HRNet-W32 256x192 training step (forward + backward + Adam), 32 crops per GPU (256 over 8),
+    gradients all-reduced over RCCL between backward and step.  A step = the reference's loop body
+    (lib/core/function.py:46-64) through rsgnet_amd.parallel.DataParallelStep.  Prints its own JSON line."""
+    from oracle import train_step_oracle as tso            # targets (data) and the cpu_baseline leg only
+    from rsgnet_amd import make_cfg, models
+    from rsgnet_amd.loss import JointsMSELoss
+    from rsgnet_amd.optim import FusedAdam
+    from rsgnet_amd.parallel import DataParallelStep
+    from rsgnet_amd.weights import synth_input, synth_state_dict
+    tag = "hrnet_w32_256x192"
+    batch = a.batch or 32
+    cfg = make_cfg("pose_hrnet", 32, (192, 256), 17)
+    model = models.pose_hrnet.get_pose_net(cfg, is_train=False)
+    bn = dict(np.load(os.path.join(ROOT, "tests", "golden", f"bnstats_{tag}.npz")))
+    sd = synth_state_dict(model.state_dict(), 0, bn)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    step_fn = DataParallelStep(model, JointsMSELoss(True), opt)
+    x = synth_input(batch, (192, 256), seed=100 + rank).to(dev)
+    target, tw = tso.gaussian_targets(batch, 17, (64, 48), 200 + rank)
+    target, tw = target.to(dev), tw.to(dev)
+    losses = []
+
+    def step():
+        loss, _ = step_fn(x, target, tw)
+        losses.append(loss)
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    wall, dev_ms = timed_steps(step, a.steps, dist, dev)
+    vals = [float(l) for l in losses]
+    assert all(np.isfinite(vals)), "non-finite loss"
+    if rank != 0:
+        return
+    plan = next(iter(model._train_plans.values()))
+    # per-family device time of one step (event pairs around the forward list, the backward list's kernel kinds)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    fams = {}
+    for name_ops, ops in (("forward", plan.fwd), ("backward", plan.bwd)):
+        evs = []
+        for nm, op in ops:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            op(st)
+            e1.record()
+            evs.append((nm, e0, e1))
+        torch.cuda.synchronize()
+        for nm, e0, e1 in evs:
+            if name_ops == "forward":
+                kind = "input" if nm == "input" else "batchnorm" if nm.endswith(".bn") else \
+                    "fuse sum" if ".fuse." in nm and nm.count(".") == 3 else "conv"
+            else:
+                kind = "wgrad" if nm.endswith(".wgrad") else "dgrad" if nm.endswith((".dgrad", ".spread")) else \
+                    "batchnorm" if nm.endswith(".bn") else "gradient plumbing"
+            d = fams.setdefault(f"{name_ops}: {kind}", {"launches": 0, "us": 0.0})
+            d["launches"] += 1
+            d["us"] += e0.elapsed_time(e1) * 1e3
+    for d in fams.values():
+        d["us"] = round(d["us"], 1)
+    ms = wall / a.steps * 1e3
+    imgs = world * batch * a.steps / wall
+    gflop = 3 * GFLOP_PER_IMG[tag]                 # forward + data gradient + weight gradient
+    whole = gflop * batch / (dev_ms / a.steps)
+    dom_name, dom = max(fams.items(), key=lambda kv: kv[1]["us"])
+    line = {"metric": "images/sec HRNet-W32 256x192 training step (fwd+bwd+Adam)", "value": round(imgs, 1), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "hrnet_w32_256x192_train", "per_gpu_batch": batch, "global_batch": batch * world,
+                       "image": "256x192", "parallelism": f"dp{world} (bucketed RCCL all-reduce of the flat fp32 gradient buffer)",
+                       "optimizer": "Adam lr 1e-3 (FusedAdam)", "loss_first_last": [round(vals[0], 6), round(vals[-1], 6)]},
+            "roofline": {"bound": "mfma", "achieved": round(whole, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(whole / PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "whole training step (3 x 15.29 GFLOP per image)", "device_ms_per_step": round(dev_ms / a.steps, 3),
+                         "largest_family": dom_name, "families": fams}}
+    if not a.no_cpu_baseline and world == 1:
+        cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
+        torch.set_num_threads(cores)
+        xs, ts, ws = x[:2].cpu(), target[:2].cpu(), tw[:2].cpu()
+        t0 = time.time()
+        tso.hrnet_train_step(sd, cfg, xs, ts, ws, dtype=torch.float32)
+        dt = time.time() - t0
+        line["cpu_baseline"] = {"value": round(2 / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+                                "sample": f"1 forward+backward of batch 2 (no optimizer), torch {torch.__version__} CPU fp32"}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +289,9 @@ def main():
                     help="a step starts from the fp32 batch in pinned HOST memory (PCIe-inclusive rate; never the "
                          "headline value, which has inputs resident in HBM)")
     ap.add_argument("--per-op", default="", help="write a per-op timing table (JSON) to this path")
+    ap.add_argument("--train", action="store_true",
+                    help="BASELINE configs[3] instead of the headline: one training step (forward + backward + Adam, "
+                         "gradient all-reduce when N > 1), 32 crops per GPU")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,6 +310,11 @@ def main():
         dist = dist_
         dist.init_process_group("nccl", device_id=dev)
 
+    if a.train:
+        train_bench(a, rank, world, local, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     from rsgnet_amd.weights import synth_input
     cfg, model, sd, wh, batch = make_model(a.workload)
     if a.batch:

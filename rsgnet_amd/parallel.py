@@ -55,3 +55,45 @@ class FlatGradReducer:
             for b in self.buckets:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
         cur.wait_stream(self._stream)
+
+
+class DataParallelStep:
+    """One data-parallel training step per rank: the reference's loop body (lib/core/function.py:46-64: forward,
+    criterion, zero_grad, backward, step) with the gradient exchange between backward and step.
+
+    With `rsgnet_amd.optim.FusedAdam` the gradients already live in one flat buffer: it is all-reduced in place in
+    buckets and the 1/world average rides in the Adam kernel (`grad_scale`).  Any other optimizer gets the generic
+    form: gradients are flattened, summed over the ranks, averaged and copied back."""
+
+    def __init__(self, model, criterion, optimizer, group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 32 << 20):
+        self.model, self.criterion, self.optimizer, self.group = model, criterion, optimizer, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.reducer: Optional[FlatGradReducer] = None
+        flat = getattr(optimizer, "flat_grad", None)
+        if flat is not None and self.world > 1:
+            self.reducer = FlatGradReducer(flat, bucket_bytes, group)
+            optimizer.grad_scale = self.reducer.grad_scale
+
+    def exchange(self):
+        if self.world == 1:
+            return
+        if self.reducer is not None:
+            self.reducer.reduce()
+            return
+        grads = [p.grad for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def __call__(self, x, target, target_weight):
+        out = self.model(x)
+        loss = self.criterion(out, target, target_weight)
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.exchange()
+        self.optimizer.step()
+        return loss, out

@@ -169,3 +169,49 @@ def test_fused_adam_checkpoint_round_trip_against_torch_adam():
     run(opt4, ps4, range(3, 6), skip=1)
     for q, r in zip(ps4, ref_p):
         assert (q.detach() - r.detach()).abs().max().item() < 5e-6
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rsgnet_amd.parallel import DataParallelStep
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    crit = lambda o, t, w: 0.5 * ((o - t) * w).pow(2).mean()
+    step = DataParallelStep(net, crit, opt)
+    g = torch.Generator().manual_seed(7)
+    x, t = torch.randn(4, 3, 8, 6, generator=g), torch.randn(4, 2, 8, 6, generator=g)
+    w = torch.ones(4, 2, 1, 1)
+    sl = slice(2 * rank, 2 * rank + 2)
+    for _ in range(3):
+        step(x[sl], t[sl], w[sl])
+    q.put((rank, [p.detach().clone() for p in net.parameters()]))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_equals_one_process_gloo():
+    """DataParallelStep (forward, criterion, zero_grad, backward, all-reduce/world, step) on two gloo ranks with half the
+    batch each ends where one process with the whole batch ends (generic path: a torch optimizer, grads averaged)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(30)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(4, 2, 1))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(7)
+    x, t = torch.randn(4, 3, 8, 6, generator=g), torch.randn(4, 2, 8, 6, generator=g)
+    for _ in range(3):
+        loss = 0.5 * (net(x) - t).pow(2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for r in (0, 1):
+        for a, b in zip(res[r], net.parameters()):
+            assert (a - b).abs().max().item() < 1e-6
