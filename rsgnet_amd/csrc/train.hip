@@ -72,14 +72,25 @@ __global__ void __launch_bounds__(256) bn_partial_kernel(const char* __restrict_
 // estimate, the normalisation the biased one: SURVEY App. D).  MODE 1: dgamma = sum g*yhat, dbeta = sum g, and the two
 // sums (kept in out0/out1 as fp32) for the apply pass.
 template <int MODE>
-__global__ void __launch_bounds__(256) bn_final_kernel(const float* __restrict__ part, int nblocks, int C, long pixels,
-                                                       float* __restrict__ out0, float* __restrict__ out1,
-                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                       float momentum, float eps) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(64) bn_final_kernel(const float* __restrict__ part, int nblocks, int C, long pixels,
+                                                      float* __restrict__ out0, float* __restrict__ out1,
+                                                      float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                      float momentum, float eps) {
+    // one wave per channel: lane t sums the partials t, t+64, ... (fp64), then a fixed butterfly over the lanes --
+    // the first version walked the partials with one thread per channel, a chain of up to 512 dependent L2 reads
+    // (~100 us per BatchNorm, more than the passes over the map)
+    __shared__ double ra[64], rb[64];
+    const int c = blockIdx.x, t = threadIdx.x;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nblocks; ++k) { a += (double)part[((long)k * 2 + 0) * C + c]; b += (double)part[((long)k * 2 + 1) * C + c]; }
+    for (int k = t; k < nblocks; k += 64) { a += (double)part[((long)k * 2 + 0) * C + c]; b += (double)part[((long)k * 2 + 1) * C + c]; }
+    ra[t] = a; rb[t] = b;
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+        if (t < w) { ra[t] += ra[t + w]; rb[t] += rb[t + w]; }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    a = ra[0]; b = rb[0];
     if (MODE == 0) {
         const double m = a / (double)pixels;
         double var = b / (double)pixels - m * m;
@@ -181,7 +192,7 @@ extern "C" int rsg_bn_stats(const void* y, int64_t pixels, int32_t c, int32_t dt
         RSG_LAUNCH((bn_partial_kernel<BF16, 0>), dim3(nb), dim3(256), 0, s, (const char*)y, nullptr, nullptr, nullptr, nullptr, (long)pixels, c, workspace);
     else
         RSG_LAUNCH((bn_partial_kernel<F16, 0>), dim3(nb), dim3(256), 0, s, (const char*)y, nullptr, nullptr, nullptr, nullptr, (long)pixels, c, workspace);
-    RSG_LAUNCH(bn_final_kernel<0>, dim3(ceil_div(c, 256)), dim3(256), 0, s, (const float*)workspace, nb, c, (long)pixels, mean, invstd,
+    RSG_LAUNCH(bn_final_kernel<0>, dim3(c), dim3(64), 0, s, (const float*)workspace, nb, c, (long)pixels, mean, invstd,
                running_mean, running_var, momentum, eps);
     RSG_CHECK_LAUNCH("bn_stats");
     return 0;
@@ -214,13 +225,13 @@ extern "C" int rsg_bn_backward(const void* dz, const void* z, const void* y, con
     const int na = (int)min((pixels + ppb - 1) / ppb, (long)2048);
     if (dtype == RSG_BF16) {
         RSG_LAUNCH((bn_partial_kernel<BF16, 1>), dim3(nb), dim3(256), 0, s, (const char*)y, (const char*)dz, (const char*)z, mean, invstd, (long)pixels, c, workspace);
-        RSG_LAUNCH(bn_final_kernel<1>, dim3(ceil_div(c, 256)), dim3(256), 0, s, (const float*)workspace, nb, c, (long)pixels, dbeta, dgamma,
+        RSG_LAUNCH(bn_final_kernel<1>, dim3(c), dim3(64), 0, s, (const float*)workspace, nb, c, (long)pixels, dbeta, dgamma,
                    nullptr, nullptr, 0.f, 0.f);
         RSG_LAUNCH(bn_backward_apply_kernel<BF16>, dim3(na), dim3(256), 0, s, (const char*)y, (const char*)dz, (const char*)z, mean, invstd,
                    gamma, (const float*)dbeta, (const float*)dgamma, (char*)dy, (char*)dres, (long)pixels, c);
     } else {
         RSG_LAUNCH((bn_partial_kernel<F16, 1>), dim3(nb), dim3(256), 0, s, (const char*)y, (const char*)dz, (const char*)z, mean, invstd, (long)pixels, c, workspace);
-        RSG_LAUNCH(bn_final_kernel<1>, dim3(ceil_div(c, 256)), dim3(256), 0, s, (const float*)workspace, nb, c, (long)pixels, dbeta, dgamma,
+        RSG_LAUNCH(bn_final_kernel<1>, dim3(c), dim3(64), 0, s, (const float*)workspace, nb, c, (long)pixels, dbeta, dgamma,
                    nullptr, nullptr, 0.f, 0.f);
         RSG_LAUNCH(bn_backward_apply_kernel<F16>, dim3(na), dim3(256), 0, s, (const char*)y, (const char*)dz, (const char*)z, mean, invstd,
                    gamma, (const float*)dbeta, (const float*)dgamma, (char*)dy, (char*)dres, (long)pixels, c);

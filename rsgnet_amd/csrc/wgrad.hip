@@ -195,8 +195,11 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
     a.RB = rb; a.nbands = ceil_div(out_h, rb);
     a.P16 = round_up(rb * out_w, 16); a.xrows = (rb - 1) * stride + kh;
     p.lds = max(a.P16 * 64 + a.xrows * a.xcols * 64 + a.P16 * 4, red_bytes);
+    // pixel slices per tile pair: enough workgroups to fill the chip (2 per CU), but every slice pays a fixed price
+    // (the cross-wave add through LDS and a taps x 4 KB partial tile written and read back), so a slice should own
+    // several chunks when the pairs alone already give the parallelism (256-channel maps: 64 pairs of 8x6 chunks)
     const int pairs = a.n_ot * a.n_it, chunks = batch * a.nbands;
-    a.nslices = max(1, min(chunks, ceil_div(1024, pairs)));
+    a.nslices = max(1, min(chunks, ceil_div(512, pairs)));
     p.grid = pairs * a.nslices;
     return 0;
 }

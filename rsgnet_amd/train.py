@@ -65,6 +65,13 @@ class TrainPlan:
         self._wgrad_need = 0
         self._zero_bias = torch.zeros(256, dtype=torch.float32, device=device)
         self._param_ptrs: Optional[Tuple[int, ...]] = None
+        self._gbuf: Dict[int, torch.Tensor] = {}
+        self._params = [p for p in model.parameters() if p.requires_grad]
+        self._sig: Optional[Tuple[int, ...]] = None
+        self._graphs: Optional[Tuple[torch.cuda.CUDAGraph, torch.cuda.CUDAGraph]] = None
+        self._warm = 0
+        import os
+        self.use_graph = os.environ.get("RSGNET_HIP_TRAIN_GRAPH", "1") != "0"
         self.flops_fwd = 0
         W, H = model.cfg.MODEL.IMAGE_SIZE
         self.H, self.W, self.J = H, W, model.cfg.MODEL.NUM_JOINTS
@@ -75,20 +82,42 @@ class TrainPlan:
         self._record_backward()
         self._wgrad_ws = torch.empty(max(self._wgrad_need, 16), dtype=torch.uint8, device=device)
         self._build_pack_table()
-        self._nbt = [m.num_batches_tracked for m in model.modules()
-                     if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        self._bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+        self._nbt = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
 
     # ------------------------------------------------------------------ helpers
     def _chk(self, rc: int, what: str):
         if rc:
             hip.check(rc, what)
 
-    @staticmethod
-    def _grad_of(p: torch.nn.Parameter) -> torch.Tensor:
-        """The parameter's fp32 gradient tensor (allocated when the optimizer left it None)."""
-        if p.grad is None:
-            p.grad = torch.zeros_like(p, dtype=torch.float32)
-        return p.grad
+    def _grad_of(self, p: torch.nn.Parameter) -> torch.Tensor:
+        """The fp32 buffer the kernels write this parameter's gradient into.  It is the parameter's own `.grad` when
+        that exists (FusedAdam: a view of its flat buffer, so the gradient lands where the optimizer and the all-reduce
+        read it), else a buffer of the plan's that `_publish_grads` hands to `p.grad` after every backward (torch
+        optimizers' `zero_grad(set_to_none=True)`).  Addresses are stable from step to step: the captured graphs hold them."""
+        g = self._gbuf.get(id(p))
+        if g is None or (p.grad is not None and p.grad.data_ptr() != g.data_ptr()):
+            g = p.grad if p.grad is not None else torch.zeros_like(p, dtype=torch.float32)
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise ValueError("training needs contiguous fp32 gradients")
+            self._gbuf[id(p)] = g
+        return g
+
+    def _publish_grads(self):
+        for p in self._params:
+            g = self._gbuf.get(id(p))
+            if g is not None and p.grad is None:
+                p.grad = g
+
+    def _signature(self) -> Tuple[int, ...]:
+        """Every address a captured graph froze: parameters (BatchNorm affine terms are kernel arguments, conv weights
+        sit in the pack table) and gradient buffers.  An optimizer that re-seats them (FusedAdam's flat buffers)
+        changes it, and the graphs are captured again."""
+        sig = []
+        for p in self._params:
+            sig.append(p.data_ptr())
+            sig.append(self._grad_of(p).data_ptr())
+        return tuple(sig)
 
     def _packed(self, w: torch.nn.Parameter, transpose: bool) -> torch.Tensor:
         O, I, kh, kw = w.shape
@@ -371,25 +400,63 @@ class TrainPlan:
         self._contribute(x, dx, False, name)
 
     # ------------------------------------------------------------------ execution
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if tuple(x.shape) != tuple(self.x_f32.shape):
-            raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_f32.shape)}")
-        if tuple(p["w"].data_ptr() for p in self._packs) != self._param_ptrs:
-            self._build_pack_table()              # the optimizer re-seated the parameters
-        self.x_f32.copy_(x)
+    def _run_forward(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
         self._chk(self.lib.rsg_pack_conv_weights_device(self._pack_items.data_ptr(), len(self._packs), self._pack_blocks, BF16, s),
                   "pack_weights")
         for _, op in self.fwd:
             op(s)
         torch._foreach_add_(self._nbt, 1)            # num_batches_tracked of every BatchNorm, one launch
+
+    def _run_backward(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        for _, op in self.bwd:
+            op(s)
+
+    def _prepare(self):
+        """Before a forward: follow re-seated parameters / gradients, and (re)capture the two HIP graphs once the
+        addresses have been stable for a step (the ~3 000 launches of a step are host-bound when enqueued one by one)."""
+        if tuple(p["w"].data_ptr() for p in self._packs) != self._param_ptrs:
+            self._build_pack_table()
+        sig = self._signature()
+        if sig != self._sig:
+            self._sig, self._graphs, self._warm = sig, None, 0
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if tuple(x.shape) != tuple(self.x_f32.shape):
+            raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_f32.shape)}")
+        self._prepare()
+        self.x_f32.copy_(x)
+        if self.use_graph and self._graphs is None and self._warm >= 1:
+            torch.cuda.synchronize(self.device)
+            gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            nbt = [t.clone() for t in self._nbt]
+            stats = [(m.running_mean.clone(), m.running_var.clone()) for m in self._bns]
+            with torch.cuda.graph(gf):
+                self._run_forward()
+            with torch.cuda.graph(gb):
+                self._run_backward()
+            # capture does not execute, but be explicit that nothing observable moved
+            for t, c in zip(self._nbt, nbt):
+                t.copy_(c)
+            for m, (rm, rv) in zip(self._bns, stats):
+                m.running_mean.copy_(rm)
+                m.running_var.copy_(rv)
+            self._graphs = (gf, gb)
+        if self._graphs is not None:
+            self._graphs[0].replay()
+        else:
+            self._run_forward()
         return self.heat.clone()
 
     def backward(self, dheat: torch.Tensor) -> None:
         self.dheat.copy_(dheat)
-        s = torch.cuda.current_stream(self.device).cuda_stream
-        for _, op in self.bwd:
-            op(s)
+        if self._graphs is not None:
+            self._graphs[1].replay()
+        else:
+            self._run_backward()
+            self._warm += 1
+        self._publish_grads()
 
 
 class _TrainFn(torch.autograd.Function):

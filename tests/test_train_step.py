@@ -108,7 +108,7 @@ def test_hrnet_training_step_matches_oracle_and_fixture():
     msd = model.state_dict()
     for k, v in stats_o.items():
         ref = v.double()
-        assert (msd[k].cpu().double() - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 1.0), k
+        assert (msd[k].cpu().double() - ref).abs().max().item() < 1e-2 * max(ref.abs().max().item(), 1.0), k   # 0.1 x the batch statistic of bf16 maps
     assert int(msd["bn1.num_batches_tracked"]) == 1
 
 

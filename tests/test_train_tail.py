@@ -186,7 +186,7 @@ def _dp_worker(rank, world, port, q):
     sl = slice(2 * rank, 2 * rank + 2)
     for _ in range(3):
         step(x[sl], t[sl], w[sl])
-    q.put((rank, [p.detach().clone() for p in net.parameters()]))
+    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()]))   # arrays, not tensors: no fd hand-over after exit
     dist.destroy_process_group()
 
 
@@ -214,4 +214,4 @@ def test_data_parallel_step_two_ranks_equals_one_process_gloo():
         opt.step()
     for r in (0, 1):
         for a, b in zip(res[r], net.parameters()):
-            assert (a - b).abs().max().item() < 1e-6
+            assert np.abs(a - b.detach().numpy()).max() < 1e-6
