@@ -216,7 +216,7 @@ def train_bench(a, rank, world, local, dev, dist):
         step()
     torch.cuda.synchronize()
     wall, dev_ms = timed_steps(step, a.steps, dist, dev)
-    vals = [float(l) for l in losses]
+    vals = [float(l.detach()) for l in losses]
     assert all(np.isfinite(vals)), "non-finite loss"
     if rank != 0:
         return
@@ -269,6 +269,29 @@ def train_bench(a, rank, world, local, dev, dist):
         dt = time.time() - t0
         line["cpu_baseline"] = {"value": round(2 / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
                                 "sample": f"1 forward+backward of batch 2 (no optimizer), torch {torch.__version__} CPU fp32"}
+        # the same operator graph through PyTorch-ROCm's own GPU kernels (MIOpen / rocBLAS): what the reference's
+        # `model.cuda()` training loop would run on this GPU (forward + loss + autograd backward, no optimizer)
+        try:
+            sdg = {k: v.to(dev) for k, v in sd.items()}
+            res = {}
+            for label, ctxm in (("fp32", None), ("autocast_bf16", torch.autocast("cuda", dtype=torch.bfloat16))):
+                def one():
+                    if ctxm is None:
+                        tso.hrnet_train_step(sdg, cfg, x, target, tw, dtype=torch.float32)
+                    else:
+                        with ctxm:
+                            tso.hrnet_train_step(sdg, cfg, x, target, tw, dtype=torch.float32)
+                one(); one()
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(3):
+                    one()
+                torch.cuda.synchronize()
+                res[label] = round(3 * batch / (time.time() - t0), 1)
+            line["torch_rocm_same_gpu"] = {"images_per_s": res, "what": "oracle's functional graph on torch.cuda ops (MIOpen convs, "
+                                           "eager), forward + loss + backward of the same batch, no optimizer"}
+        except Exception as e:      # never let the comparison leg break the bench line
+            line["torch_rocm_same_gpu"] = {"error": repr(e)[:200]}
     print(json.dumps(line), flush=True)
 
 

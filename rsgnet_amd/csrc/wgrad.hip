@@ -156,18 +156,36 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dW[o][i][t] = sum over slices (in slice order) of part[(ot, it)][slice][t][o % 32][i % 32]
+// dW[o][i][t] = sum over slices of part[(ot, it)][slice][t][o % 32][i % 32], in a fixed order: a workgroup owns a
+// quarter (256 elements) of one (pair, tap) tile; lane l of slice group sg (4 groups) adds the float4 l of slices
+// sg, sg+4, ... and the four group sums are added in group order through LDS.  Every read is a coalesced 1 KB row.
+// (The first version gave each thread one output element and walked the slices with a 36 KB stride: uncoalesced, a
+// quarter of the training step.)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int cout, int cin,
                                                            int ntaps, int n_it, int nslices) {
-    const long total = (long)cout * cin * ntaps;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int t = (int)(e % ntaps);
-        const int i = (int)((e / ntaps) % cin), o = (int)(e / ((long)ntaps * cin));
-        const float* p = part + ((size_t)((o >> 5) * n_it + (i >> 5)) * nslices * ntaps + t) * 1024 + (o & 31) * 32 + (i & 31);
-        float s = 0.f;
-        for (int k = 0; k < nslices; ++k) s += p[(size_t)k * ntaps * 1024];
-        dw[e] = s;
+    __shared__ float4 red[3][64];
+    const int tile = blockIdx.x >> 2, quarter = blockIdx.x & 3;          // tile = pair * ntaps + t
+    const int pair = tile / ntaps, t = tile - pair * ntaps;
+    const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const float4* p = reinterpret_cast<const float4*>(part + ((size_t)pair * nslices * ntaps + t) * 1024) + quarter * 64 + l;
+    const size_t stride = (size_t)ntaps * 256;                            // float4s between two slices
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = sg; k < nslices; k += 4) {
+        const float4 v = p[(size_t)k * stride];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+    if (sg) red[sg - 1][l] = s;
+    __syncthreads();
+    if (sg) return;
+    for (int g = 0; g < 3; ++g) { const float4 v = red[g][l]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    const int ot = pair / n_it, it = pair - ot * n_it;
+    const int e0 = quarter * 256 + l * 4;                                 // element of the 32x32 tile: row = cout, col = cin
+    const int o = ot * 32 + (e0 >> 5), i0 = it * 32 + (e0 & 31);
+    if (o >= cout) return;
+    const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (i0 + j < cin) dw[((size_t)o * cin + i0 + j) * ntaps + t] = v[j];
 }
 
 struct WgradPlan { WgradArgs a; int lds, grid, ntaps; };
@@ -230,8 +248,7 @@ extern "C" int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds) != hipSuccess)
         RSG_FAIL("conv_wgrad: cannot reserve %d B of LDS", p.lds);
     RSG_LAUNCH(fn, dim3(p.grid), dim3(256), p.lds, s, p.a);
-    const long total = (long)cout * cin * p.ntaps;
-    RSG_LAUNCH(wgrad_reduce_kernel, dim3((int)min((total + 255) / 256, (long)2048)), dim3(256), 0, s, (const float*)workspace, dw, cout, cin,
+    RSG_LAUNCH(wgrad_reduce_kernel, dim3(p.a.n_ot * p.a.n_it * p.ntaps * 4), dim3(256), 0, s, (const float*)workspace, dw, cout, cin,
                p.ntaps, p.a.n_it, p.a.nslices);
     RSG_CHECK_LAUNCH("conv_wgrad");
     return 0;
