@@ -144,7 +144,7 @@ def family_table(plan, per_op):
         if "chain" in e:
             chain[e["name"]] = 2.0 * plan.batch * e["hw"][0] * e["hw"][1] * e["cin"] * e["cout"] * 9 * e["layers"]
         elif "group" in e and e["group"] and isinstance(e["group"][0], (list, tuple)):
-            chain[e["name"]] = sum(2.0 * plan.batch * h * w * c * c * 9 * n for c, h, w, n in e["group"])
+            chain[e["name"]] = sum(2.0 * plan.batch * h * w * c * c * 9 * n for c, h, w, n in e["group"]) + e.get("tail_flops", 0.0)
         elif "group" in e:
             flops[e["name"]] = sum(flops.get(n, 0.0) for n in e["group"])
     fams = {}

@@ -149,6 +149,19 @@ int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, 
  * what it saw.  done_flags: int32[3 * workgroups of the item], zeroed by the caller before the first launch (a
  * launch leaves every word that was seen at zero again) and again whenever rsg_chain_handoff_timeouts reports a
  * poll that gave up. */
+/* A conv of the module's fuse layers (pose_hrnet.py:190-268) that reads a whole-image chain's output: a 1x1 conv
+ * (k = 1, stride 1; towards a higher-resolution branch, before its nearest up-sampling) or a 3x3 stride-2 pad-1 conv
+ * (k = 3, stride 2; the first step towards a lower-resolution branch), BatchNorm folded by
+ * rsg_pack_conv_weights_host, optional ReLU.  The chain's workgroup computes it from its LDS image when the chain
+ * ends; out: dense NHWC 16-bit [batch, h/stride, w/stride, cout], cout a multiple of 32.  Results are bit-identical
+ * to rsg_conv_igemm on the chain's output. */
+typedef struct rsg_chain_tail {
+    const void* w_packed;
+    const float* bias;
+    void* out;
+    int32_t cout, k, stride, relu;
+} rsg_chain_tail;
+
 typedef struct rsg_chain_item {
     const void* in;
     void* out;
@@ -159,6 +172,9 @@ typedef struct rsg_chain_item {
     void* workspace;               /* rsg_basic_chain_workspace_bytes(c,h,w,nlayers,batch) bytes, own per item */
     void* done_flags;              /* NULL, or 3 x int32 per workgroup (see above) */
     const void* wait_flags;        /* NULL, or the done_flags of an earlier item */
+    int32_t ntails;                /* 0..3 fuse convs computed from the final LDS image (whole-image maps only) */
+    int32_t reserved;
+    rsg_chain_tail tails[3];
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
 /* Sticky error word of the hand-off: the number of polls that gave up since the library was loaded on the current

@@ -47,6 +47,21 @@ __device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][8 waves][
 // there), so a producer always finds a CU; the bound only turns a bug into an error instead of a hung GPU.
 __device__ unsigned g_chain_handoff_timeouts = 0;
 
+// A convolution of the module's fuse layers (pose_hrnet.py:190-268) that reads this chain's OUTPUT: the 1x1 convs
+// towards the higher-resolution branches and the first strided 3x3 conv towards every lower one.  The chain's final
+// image is still in LDS when it ends, so the workgroup computes them right there (BatchNorm folded, optional ReLU,
+// 16-bit NHWC out) instead of a later launch staging the same map again from memory.  Whole-image chains only.
+#define RSG_CHAIN_MAX_TAILS 3
+struct ChainTail {
+    const uint4* wpk;      // packed like every conv (cin = the chain's C)
+    const float* bias;
+    char* out;             // [B, Ho, Wo, cout] 16-bit
+    int cout;              // multiple of 32
+    int k, stride;         // 1x1 stride 1, or 3x3 stride 2 (pad 1)
+    int relu;
+    int Ho, Wo;
+};
+
 struct ChainArgs {
     const char* in;
     char* out;
@@ -67,9 +82,74 @@ struct ChainArgs {
     // Both null for an ordinary chain.
     int* done;
     const int* wait;
+    int ntails;
+    ChainTail tail[RSG_CHAIN_MAX_TAILS];
     int dual;     // 1: two LDS images (ping-pong): a layer reads one and writes the other, the block input stays in LDS
     int debug;    // experiments (rsg_tune("chain_debug")): bit 2 = no block-input fetch (WRONG results), bit 4 = producers never signal
 };
+
+// One tail conv over the LDS image `img` (slot layout of chain_body: slot_rows rows of RP bytes per image, pixel
+// stride PS, one zero row/pixel around every image = the conv's zero padding).  Output tiles (32 couts x 32 pixels)
+// are dealt to the waves cout-tile-major (neighbouring waves share the weight fragments in L1); per tile the k-steps
+// run in packed order with the A operand NPF steps and the B operand one step ahead, accumulators start at the bias:
+// the same sums in the same order as conv_igemm.hip, so the results are bit-identical to the separate launch.
+template <class DT, int C, int NWAVES, int NTAPS>
+__device__ __forceinline__ void chain_tail_conv(const ChainTail& t, const char* img, int NI, int b0, int B, int slot_rows, int RP) {
+    constexpr int CINB = (C % 64 == 0) ? 64 : 32;
+    constexpr int NCH = C / CINB, KPT = CINB / 16, KS = NCH * NTAPS * KPT;
+    constexpr int PS = 2 * C + 16;
+    constexpr int NPF = (KS % 4 == 0) ? 4 : 2;
+    static_assert(KS % NPF == 0, "tail prefetch ring");
+    const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per_img = t.Ho * t.Wo, npix = NI * per_img;
+    const int ngroups = (npix + 31) >> 5, nct = t.cout >> 5;
+    auto boff = [&](int ks) {
+        const int ch = ks / (NTAPS * KPT), tp = (ks / KPT) % NTAPS, c = ks % KPT;
+        return (NTAPS == 9 ? (tp / 3 - 1) * RP + (tp % 3 - 1) * PS : 0) + ch * CINB * 2 + c * 32;
+    };
+    for (int tile = wave; tile < nct * ngroups; tile += NWAVES) {
+        const int ct = tile / ngroups, g = tile - ct * ngroups;
+        const int q = g * 32 + n;
+        const bool live = q < npix;
+        const int qq = live ? q : 0;
+        const int i = qq / per_img, rem = qq - i * per_img;
+        const int oy = rem / t.Wo, ox = rem - oy * t.Wo;
+        const char* px = img + (i * slot_rows + oy * t.stride + 1) * RP + (ox * t.stride + 1) * PS + hh * 16;
+        const uint4* ap = t.wpk + (size_t)ct * KS * 64 + lane;
+        f32x16 acc;
+        {
+            const float* bp = t.bias + ct * 32 + hh * 16;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 bv = *reinterpret_cast<const float4*>(bp + r4 * 4);
+                acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
+            }
+        }
+        uint4 aq[NPF], bq[2];
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
+        bq[0] = *reinterpret_cast<const uint4*>(px + boff(0));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+            if (ks + 1 < KS) bq[(ks + 1) & 1] = *reinterpret_cast<const uint4*>(px + boff(ks + 1));
+            if (ks + NPF < KS) aq[ks % NPF] = ap[(ks + NPF) * 64];
+            acc = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1]), acc);
+        }
+        if (live && b0 + i < B) {
+            char* o = t.out + ((size_t)((b0 + i) * per_img + rem) * t.cout + ct * 32 + hh * 16) * 2;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc[k * 8 + e];
+                const typename DT::vec8 pk = t.relu ? DT::relu_pack(v) : __builtin_convertvector(v, typename DT::vec8);
+                *reinterpret_cast<uint4*>(o + k * 16) = __builtin_bit_cast(uint4, pk);
+            }
+        }
+    }
+}
 
 template <class DT, int C, int WM, int WN, int NT, bool DUAL = false>
 __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_id, char* smem, const unsigned pf = 0) {
@@ -415,6 +495,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             if (c >= rowc) { c -= rowc; ++r; }
         }
     }
+    // ---- the module's fuse convs that read this chain's output, straight from the LDS image (whole images only)
+    if (p.ntails) {
+        const char* const img = smem + (dual ? (p.nlayers & 1) * lds_bytes : 0);
+        for (int ti = 0; ti < p.ntails; ++ti) {
+            if (p.tail[ti].k == 3) chain_tail_conv<DT, C, WM * WN, 9>(p.tail[ti], img, p.NI, b0, p.B, slot_rows, RP);
+            else chain_tail_conv<DT, C, WM * WN, 1>(p.tail[ti], img, p.NI, b0, p.B, slot_rows, RP);
+        }
+    }
     if (p.done) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores have left the CU
         __syncthreads();
@@ -701,6 +789,20 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         a.ws = (uint4*)it.workspace;
         a.done = (int*)it.done_flags;
         a.wait = (const int*)it.wait_flags;
+        if (it.ntails < 0 || it.ntails > RSG_CHAIN_MAX_TAILS) RSG_FAIL("chain_group: item %d: ntails=%d", i, it.ntails);
+        if (it.ntails && a.tiles_y != 1) RSG_FAIL("chain_group: item %d: tail convs need a whole-image chain", i);
+        a.ntails = it.ntails;
+        for (int k = 0; k < it.ntails; ++k) {
+            const rsg_chain_tail& t = it.tails[k];
+            if (!t.w_packed || !t.bias || !t.out || t.cout < 32 || t.cout % 32 ||
+                !((t.k == 1 && t.stride == 1) || (t.k == 3 && t.stride == 2 && it.h % 2 == 0 && it.w % 2 == 0)))
+                RSG_FAIL("chain_group: item %d tail %d: 1x1 stride 1 or 3x3 stride 2 (even map), cout %% 32 == 0", i, k);
+            if (((uintptr_t)t.out | (uintptr_t)t.w_packed | (uintptr_t)t.bias) & 15) RSG_FAIL("chain_group: item %d tail %d: alignment", i, k);
+            ChainTail& d = a.tail[k];
+            d.wpk = (const uint4*)t.w_packed; d.bias = t.bias; d.out = (char*)t.out;
+            d.cout = t.cout; d.k = t.k; d.stride = t.stride; d.relu = t.relu ? 1 : 0;
+            d.Ho = it.h / t.stride; d.Wo = it.w / t.stride;
+        }
         a.debug = g_chain_debug;
         if (it.wait_flags) {
             // the producer comes EARLIER in the grid (in-order dispatch then makes the wait short; correctness does

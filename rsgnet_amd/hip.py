@@ -37,12 +37,19 @@ class FuseItem(C.Structure):
                 ("low_ld", C.c_int32 * 3), ("reserved", C.c_int32)]
 
 
+class ChainTail(C.Structure):
+    """struct rsg_chain_tail (include/rsgnet_hip.h)."""
+    _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("cout", C.c_int32), ("k", C.c_int32),
+                ("stride", C.c_int32), ("relu", C.c_int32)]
+
+
 class ChainItem(C.Structure):
     """struct rsg_chain_item (include/rsgnet_hip.h)."""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
                 ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
                 ("w", C.c_int32), ("c", C.c_int32), ("images_per_workgroup", C.c_int32), ("workspace", C.c_void_p),
-                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p)]
+                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("ntails", C.c_int32), ("reserved", C.c_int32),
+                ("tails", ChainTail * 3)]
 
 
 class PackItem(C.Structure):

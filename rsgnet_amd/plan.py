@@ -377,7 +377,10 @@ class Plan:
         INDEX of an earlier item: that chain then reads the earlier one's output and the two hand over inside the
         launch (done/wait flags, include/rsgnet_hip.h)."""
         subs, outs = [], []
-        for x, blocks in items:
+        self._tail_outs = []                # per item: the VTs its tail convs write (read by the caller)
+        for item in items:
+            x, blocks = item[0], item[1]
+            tails_in = item[2] if len(item) > 2 else []
             after = None
             if isinstance(x, int):
                 after, x = x, outs[x]
@@ -396,11 +399,23 @@ class Plan:
             # position k of every grouped launch shares one scratch buffer per size; it is named among the op's
             # writes, so every scheduler (lanes, explicit graph) keeps the sharers in order
             ws = self._chain_workspace(len(subs), x, len(layers))
-            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws))
+            # fuse convs computed from the chain's final LDS image (rsg_chain_tail): (conv, bn, relu) each
+            tails, touts = [], []
+            for conv, bnm, relu in tails_in:
+                sc, sh = self.bn_fold(bnm)
+                wp, bo, _i, O = self.pack_conv(conv.weight, sc, sh, conv.bias)
+                k, st = conv.kernel_size[0], conv.stride[0]
+                tv = self.new(x.H // st, x.W // st, O, name=f"{name}.tail")
+                tails.append(dict(wp=wp, bias=bo, out=tv, cout=O, k=k, stride=st, relu=relu))
+                touts.append(tv)
+                self.flops += 2 * self.batch * tv.H * tv.W * O * x.C * k * k
+            self._tail_outs.append(touts)
+            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, tails=tails))
             outs.append(out)
             self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
         self._record(dict(kind="chain_group", subs=subs, name=name),
-                     [d["x"] for d in subs if d["after"] is None], outs + [d["ws"] for d in subs])
+                     [d["x"] for d in subs if d["after"] is None],
+                     outs + [d["ws"] for d in subs] + [t["out"] for d in subs for t in d["tails"]])
         return outs
 
     def chain_mode(self, C_, H, W, nblocks) -> int:
@@ -700,6 +715,13 @@ class Plan:
             it.bias = C.cast(bps, C.POINTER(C.c_void_p))
             it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, x.C
             it.workspace = d["ws"].data_ptr() if d["ws"] is not None else None
+            it.ntails = len(d["tails"])
+            for k, t in enumerate(d["tails"]):
+                tv = t["out"]
+                if tv.ld != tv.C or tv.coff:
+                    raise ValueError("tail outputs must be dense tensors")
+                it.tails[k].w_packed, it.tails[k].bias, it.tails[k].out = t["wp"].data_ptr(), t["bias"].data_ptr(), tv.ptr()
+                it.tails[k].cout, it.tails[k].k, it.tails[k].stride, it.tails[k].relu = t["cout"], t["k"], t["stride"], int(t["relu"])
             log.append((x.C, x.H, x.W, n))
         for k, d in enumerate(subs):
             if d.get("after") is not None:
@@ -729,7 +751,9 @@ class Plan:
                     total -= blocks[k][0] // 2
         self._keep.append(items)
         fn, nm, n_items, dt = self.lib.rsg_basic_chain_group, r["name"], len(subs), self.dtype
-        self.conv_log.append(dict(name=nm, group=log))
+        tail_flops = float(sum(2 * self.batch * t["out"].H * t["out"].W * t["cout"] * d["x"].C * t["k"] ** 2
+                               for d in subs for t in d["tails"]))
+        self.conv_log.append(dict(name=nm, group=log, tail_flops=tail_flops, tails=sum(len(d["tails"]) for d in subs)))
 
         def launch(stream):
             rc = fn(items, n_items, dt, stream)
@@ -1073,14 +1097,35 @@ class _BackboneMixin:
                     self.lib.rsg_basic_chain_supported(xs[b].C, xs[b].H, xs[b].W, 2 * steps[b], self.batch, info)
                     waiters += info[3]
             handoff = waiters <= self.lib.rsg_basic_chain_handoff_max_waiters()
+        pre: Dict[Tuple[int, int], VT] = {}                  # (i, j) -> first conv of fuse path j -> i, done by a chain tail
         if handoff:
             order = sorted(steps, key=lambda b: (not whole(b), -xs[b].C))       # whole-image chains first, widest first
+            # fuse convs that read a whole-image branch ride on that branch's chain (tails of the launch)
+            tails_of: Dict[int, list] = {b: [] for b in order}
+            tail_ij: Dict[int, list] = {b: [] for b in order}
+            # RSGNET_HIP_CHAIN_TAILS=1 (off by default): measured SLOWER in a same-visit A/B (1.780 -> 1.816 ms): the
+            # fuse launches drop from 364 to 278 us but the chain launches grow from 884 to 1000 us -- the small convs
+            # are latency-bound either way, and in the chain kernel (one workgroup per CU) nothing hides that latency,
+            # while the fuse launches run them at 2-3 workgroups per CU (profiles/README.md, r02e)
+            if mod.fuse_layers is not None and os.environ.get("RSGNET_HIP_CHAIN_TAILS", "0") != "0":
+                for i, row in enumerate(mod.fuse_layers):
+                    for j, fl in enumerate(row):
+                        if j == i or j not in steps or not whole(j) or len(tails_of[j]) >= 3:
+                            continue
+                        conv, bnm = (fl[0], fl[1]) if j > i else (fl[0][0], fl[0][1])
+                        relu = False if j > i else len(fl) > 1
+                        ok = conv.out_channels % 32 == 0 and conv.bias is None and conv.in_channels == xs[j].C and \
+                            ((conv.kernel_size == (1, 1) and conv.stride == (1, 1)) or
+                             (conv.kernel_size == (3, 3) and conv.stride == (2, 2) and xs[j].H % 2 == 0 and xs[j].W % 2 == 0))
+                        if ok:
+                            tails_of[j].append((conv, bnm, relu))
+                            tail_ij[j].append((i, j))
             items, where = [], {}
             for b in order:
                 blocks = list(mod.branches[b])
                 if whole(b):
                     where[b] = len(items)
-                    items.append((xs[b], blocks))
+                    items.append((xs[b], blocks, tails_of[b]))
             for b in order:                      # first halves, then second halves: a producer precedes its consumer
                 if not whole(b):
                     where[b] = len(items)
@@ -1090,6 +1135,10 @@ class _BackboneMixin:
                     first, where[b] = where[b], len(items)
                     items.append((first, list(mod.branches[b])[steps[b]:]))
             outs = self.chain_group(items, f"{name}.chains")
+            for b in order:
+                if whole(b):
+                    for ij, tv in zip(tail_ij[b], self._tail_outs[where[b]]):
+                        pre[ij] = tv
             for b in order:
                 xs[b] = outs[where[b]]
             steps = {}
@@ -1122,12 +1171,14 @@ class _BackboneMixin:
         rows = mod.fuse_layers
         n_out = len(rows)
         cur = {}                                         # (i, j) -> tensor produced so far on that path
-        depth = {}                                       # (i, j) -> number of convs on that path
+        depth = {}                                       # (i, j) -> number of convs on that path LEFT for these launches
+        done = {}                                        # (i, j) -> convs of the path a chain tail has already run
         for i, row in enumerate(rows):
             for j, fl in enumerate(row):
                 if j != i:
-                    depth[(i, j)] = 1 if j > i else len(fl)
-                    cur[(i, j)] = xs[j]
+                    done[(i, j)] = 1 if (i, j) in pre else 0
+                    depth[(i, j)] = (1 if j > i else len(fl)) - done[(i, j)]
+                    cur[(i, j)] = pre.get((i, j), xs[j])
         max_depth = max(depth.values()) if depth else 0
         outs: List[Optional[VT]] = [None] * n_out
         ready = {i: max([d for (ii, _), d in depth.items() if ii == i], default=0) for i in range(n_out)}
@@ -1135,7 +1186,7 @@ class _BackboneMixin:
         fold_into = None
         last = n_out - 1
         if os.environ.get("RSGNET_HIP_FOLD_SUM", "1") != "0" and not self.use_fanout and last >= 1 and last == len(xs) - 1 \
-                and last <= 3 and depth.get((last, 0), 0) == last:
+                and last <= 3 and depth.get((last, 0), 0) == last and depth[(last, 0)] == max_depth:
             fold_into = (last, 0)
             ready[last] = -1                              # no separate sum for it
         for level in range(max_depth + 1):
@@ -1148,7 +1199,8 @@ class _BackboneMixin:
             for (i, j), dep in depth.items():
                 if level < dep:
                     fl = rows[i][j]
-                    conv, bnm = (fl[0], fl[1]) if j > i else (fl[level][0], fl[level][1])
+                    step = level + done[(i, j)]          # index of the conv on its path
+                    conv, bnm = (fl[0], fl[1]) if j > i else (fl[step][0], fl[step][1])
                     relu = False if j > i else (level != dep - 1)
                     xin = cur[(i, j)]
                     key = (id(xin.base), xin.coff, xin.C, conv.kernel_size, conv.stride)
@@ -1164,7 +1216,7 @@ class _BackboneMixin:
                         cur[ij] = v
                 else:
                     for ij, xin, conv, bnm, relu in items:
-                        nm = f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level}")
+                        nm = f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level + done[ij]}")
                         if ij == fold_into and level == depth[ij] - 1:
                             # the sum of the lowest-resolution output rides on the last conv that feeds it: every other
                             # addend (the identity and the shorter strided chains) was finished at an earlier level
