@@ -20,8 +20,20 @@
 // MFMA mapping, weight packing and LDS pixel layout are those of conv_igemm.hip.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 #define RSG_CHAIN_MAX_LAYERS 8
+// pixel groups of the grouped launch's chains whose block input waits in registers (chain_body NHELD) instead of the
+// global workspace; -DRSG_CHAIN_HELD64=0 -DRSG_CHAIN_HELD32=0 builds the all-workspace form for a same-visit A/B
+#ifndef RSG_CHAIN_HELD64
+#define RSG_CHAIN_HELD64 6
+#endif
+#ifndef RSG_CHAIN_HELD32
+#define RSG_CHAIN_HELD32 4
+#endif
+#ifndef RSG_CHAIN_NPF32
+#define RSG_CHAIN_NPF32 6      // weight-fragment ring depth of the C = 32 chains (3 leaves room for a 5th held group)
+#endif
 
 // Diagnostic build (-DRSG_CHAIN_STAMPS): wave 0 of every workgroup records shader-clock stamps at the phase
 // boundaries into a side buffer that nothing else reads (tools/chain_stamps.py prints the shares).  The
@@ -151,8 +163,13 @@ __device__ __forceinline__ void chain_tail_conv(const ChainTail& t, const char* 
     }
 }
 
-template <class DT, int C, int WM, int WN, int NT, bool DUAL = false>
+// NHELD: the block input of the first NHELD pixel groups waits in REGISTERS instead of the global workspace (in-place
+// mode only): each lane reads its own pixels of the block input from the LDS image just before it overwrites them with
+// the first conv's output and keeps them (8 vector registers per group) across the second conv's k-loop.  As many
+// groups as the NT*16 accumulators leave room for: all 6 at C = 64 (96 + 48 of 256 registers), some of the 7 at C = 32.
+template <class DT, int C, int WM, int WN, int NT, bool DUAL = false, int NHELD = 0>
 __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_id, char* smem, const unsigned pf = 0) {
+    static_assert(!(DUAL && NHELD) && NHELD <= NT, "ping-pong images keep the block input in LDS already");
     constexpr int NTHR = 64 * WM * WN;
     constexpr int CINB = (C % 64 == 0) ? 64 : 32;      // same k order as rsg_pack_conv_weights_host
     constexpr int NCH = C / CINB, KPT = CINB / 16;
@@ -298,7 +315,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     asm volatile("" ::"v"(pf));                           // the grouped launch's weight prefetch loads end here
     RSG_STAMP(2);
 
-    constexpr int NPF = (C >= 128) ? 9 : (C == 64 ? 4 : 6);   // ring depth; must divide KS (18, 36, 72, 144)
+    constexpr int NPF = (C >= 128) ? 9 : (C == 64 ? 4 : RSG_CHAIN_NPF32);   // ring depth; must divide KS (18, 36, 72, 144)
     static_assert(KS % NPF == 0, "prefetch ring must wrap at the layer boundary");
     uint4 aq[NPF];
     // block-input slots of this lane, through a buffer descriptor: uniform base in SGPRs, ONE address VGPR (the
@@ -314,9 +331,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ws_rsrc, ws_lane, (g * 2 + k) * NTHR * 16, 0);
     };
     const int own_delta = cbase * 2 - hh * 16;           // pixoff -> this lane's 16 channels of the pixel
+    uint4 held[NHELD ? NHELD : 1][2];                    // the block input of the block in flight, groups [0, NHELD)
     if (!dual) {
 #pragma unroll
-        for (int g = 0; g < NT; ++g) {                   // the first block's input, from the staged image
+        for (int g = NHELD; g < NT; ++g) {               // the first block's input, from the staged image
             ws_store(g, 0, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta));
             ws_store(g, 1, *reinterpret_cast<const uint4*>(smem + pixoff[g] + own_delta + 16));
         }
@@ -350,6 +368,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             }
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
+                if (g < NHELD) continue;                 // the epilogue reads `held` itself
                 res[g][0] = ws_load(g, 0);
                 res[g][1] = ws_load(g, 1);
             }
@@ -445,12 +464,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             for (int g = 0; g < NT; ++g) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, res[g][k]), f32x8);
+                    const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, g < NHELD ? held[g < NHELD ? g : 0][k] : res[g][k]), f32x8);
                     f32x8 v;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = acc[g][k * 8 + e] + rf[e];
                     o[g][k] = __builtin_bit_cast(uint4, DT::relu_pack(v));
-                    if (l + 1 < p.nlayers && !dual) ws_store(g, k, o[g][k]); // the next block's input
+                    if (l + 1 < p.nlayers && !dual && g >= NHELD) ws_store(g, k, o[g][k]); // the next block's input
                 }
             }
         } else {
@@ -469,6 +488,15 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         if (!dual) __syncthreads();                    // in place: every wave has finished reading the image
         int wd = own_delta;
         asm volatile("" : "+v"(wd));                     // keep the 2*NT write addresses out of the loop preheader
+        if constexpr (NHELD > 0) {
+            if (!(l & 1)) {                              // first conv of a block: pick up the block input before it is overwritten
+#pragma unroll
+                for (int g = 0; g < NHELD; ++g) {
+                    held[g][0] = *reinterpret_cast<const uint4*>(wr + pixoff[g] + wd);
+                    held[g][1] = *reinterpret_cast<const uint4*>(wr + pixoff[g] + wd + 16);
+                }
+            }
+        }
 #pragma unroll
         for (int g = 0; g < NT; ++g) {
             if (live[g]) {
@@ -563,9 +591,11 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
             if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6>(g.a[i], bid, smem, pf);
-            else chain_body<DT, 32, 1, 8, 7>(g.a[i], bid, smem, pf);
+            else chain_body<DT, 32, 1, 8, 7, false, std::is_same<DT, F16>::value ? RSG_CHAIN_HELD32 : 0>(g.a[i], bid, smem, pf);
             break;
-        case 64: chain_body<DT, 64, 2, 4, 6>(g.a[i], bid, smem, pf); break;
+        case 64:     // bf16 has no packed max: its ReLU epilogue needs the registers the held block input would take
+            chain_body<DT, 64, 2, 4, 6, false, std::is_same<DT, F16>::value ? RSG_CHAIN_HELD64 : 0>(g.a[i], bid, smem, pf);
+            break;
         case 128:  // 16x12 maps: one image = 6 pixel groups over 2 wave columns; two images per workgroup = 12
             if (g.a[i].dual) chain_body<DT, 128, 4, 2, 3, true>(g.a[i], bid, smem, pf);
             else chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem, pf);
