@@ -93,6 +93,22 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0, gpu_model=None):
         out["parity_vs_fp32_cpu"] = {k: {"max_abs_err": float(f"{(g.float().cpu() - r).abs().max().item():.3e}"),
                                          "ref_abs_max": round(float(r.abs().max()), 3),
                                          "ref_std": round(float(r.std()), 3)} for k, g, r in pairs}
+        out["parity_vs_fp32_cpu"]["weights"] = "calibrated trained-like weights (heat maps peak near 1): bar 0.05 x ref_std"
+        if cfg.MODEL.NAME == "pose_hrnet":
+            # BASELINE configs[0], the case the metric's 1e-3 max-abs bar is written for: the reference's own
+            # random-init network (torch default init, identity BatchNorm), batch 4, GPU against the fp32 CPU forward
+            from rsgnet_amd import models
+            from rsgnet_amd.weights import synth_state_dict
+            m0 = models.pose_hrnet.get_pose_net(cfg, is_train=False)
+            sd0 = synth_state_dict(m0.state_dict(), 0, regime="init")
+            m0.load_state_dict(sd0)
+            m0 = m0.eval().to(next(gpu_model.parameters()).device)
+            r0 = po.hrnet_forward(sd0, cfg, x)
+            with torch.no_grad():
+                g0 = m0(x.to(next(m0.parameters()).device)).float().cpu()
+            out["heatmap_max_abs_err_random_init"] = {"value": float(f"{(g0 - r0).abs().max().item():.3e}"), "bar": 1e-3,
+                                                      "ref_abs_max": float(f"{r0.abs().max().item():.3e}"),
+                                                      "config": "BASELINE configs[0]: random-init HRNet-W32 256x192, batch 4"}
     return out
 
 

@@ -160,3 +160,76 @@ def test_training_loop_with_fused_adam_reduces_the_loss():
     # the gradients went into the optimizer's flat buffer, not into stray tensors
     p = next(model.parameters())
     assert p.grad.data_ptr() == opt.flat_grad.data_ptr() + 0 and opt.step_count == 6
+
+
+def _dp_gpu_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rsgnet_amd.loss import JointsMSELoss
+    from rsgnet_amd.optim import FusedAdam
+    from rsgnet_amd.parallel import DataParallelStep
+    cfg, model, sd, x, target, tw, gold = _case()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    step = DataParallelStep(model, JointsMSELoss(True), opt)
+    sl = slice(rank, rank + 1)                         # one crop per rank
+    losses = []
+    for _ in range(3):
+        loss, _ = step(x[sl].cuda(), target[sl].cuda(), tw[sl].cuda())
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    flat = opt.flat_param.detach().cpu().numpy().copy()
+    q.put((rank, losses, flat, opt.grad_scale))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_data_parallel_training_two_ranks_on_the_gpu():
+    """SURVEY 8(e) config 4 on the real kernels: two processes (one crop each, both on cuda:0, gloo for the exchange)
+    run three DataParallelStep iterations with FusedAdam.  The flat gradient buffer is all-reduced in buckets on a side
+    stream and 1/world rides in the Adam kernel: both ranks must end with bit-identical parameters, and they must equal
+    a single process that computes the two per-crop gradients one after the other and averages them itself."""
+    import torch.multiprocessing as mp
+    from rsgnet_amd.loss import JointsMSELoss
+    from rsgnet_amd.optim import FusedAdam
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in ps:
+        r, losses, flat, gs = q.get(timeout=300)
+        res[r] = (losses, flat, gs)
+    for p in ps:
+        p.join(60)
+    assert res[0][2] == 0.5 and np.array_equal(res[0][1], res[1][1])          # replicas stay identical, bit for bit
+    assert all(np.isfinite(res[r][0]).all() for r in res)
+    # the same three steps in one process: gradients of crop 0 and crop 1 separately (per-replica BatchNorm statistics,
+    # as DataParallel has them), summed, Adam with grad_scale 1/2
+    cfg, model, sd, x, target, tw, gold = _case()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    opt.grad_scale = 0.5
+    crit = JointsMSELoss(True)
+    bn_state = [{k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k} for _ in range(2)]
+    for it in range(3):
+        total = torch.zeros_like(opt.flat_grad)
+        for r in range(2):
+            model.load_state_dict(bn_state[r], strict=False)        # every replica keeps its own running statistics
+            out = model(x[r:r + 1].cuda())
+            loss = crit(out, target[r:r + 1].cuda(), tw[r:r + 1].cuda())
+            opt.zero_grad()
+            loss.backward()
+            total += opt.flat_grad
+            bn_state[r] = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+            assert abs(float(loss.detach()) - res[r][0][it]) <= 1e-6 * abs(res[r][0][it]) + 1e-9
+        opt.flat_grad.copy_(total)
+        opt.step()
+    torch.cuda.synchronize()
+    assert np.array_equal(opt.flat_param.detach().cpu().numpy(), res[0][1])
