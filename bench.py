@@ -242,7 +242,8 @@ def train_bench(a, rank, world, local, dev, dist):
     fams = {}
     for name_ops, ops in (("forward", plan.fwd), ("backward", plan.bwd)):
         evs = []
-        for nm, op in ops:
+        for rec in ops:
+            nm, op = rec[0], rec[1]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             op(st)
@@ -251,11 +252,11 @@ def train_bench(a, rank, world, local, dev, dist):
         torch.cuda.synchronize()
         for nm, e0, e1 in evs:
             if name_ops == "forward":
-                kind = "input" if nm == "input" else "batchnorm" if nm.endswith(".bn") else \
+                kind = "input" if nm == "input" else "batchnorm" if ".bn" in nm else \
                     "fuse sum" if ".fuse." in nm and nm.count(".") == 3 else "conv"
             else:
-                kind = "wgrad" if nm.endswith(".wgrad") else "dgrad" if nm.endswith((".dgrad", ".spread")) else \
-                    "batchnorm" if nm.endswith(".bn") else "gradient plumbing"
+                kind = "wgrad" if ".wgrad" in nm else "dgrad" if (".dgrad" in nm or ".spread" in nm) else \
+                    "batchnorm" if ".bn" in nm else "gradient plumbing"
             d = fams.setdefault(f"{name_ops}: {kind}", {"launches": 0, "us": 0.0})
             d["launches"] += 1
             d["us"] += e0.elapsed_time(e1) * 1e3

@@ -337,6 +337,22 @@ int rsg_bn_apply(const void* y, const float* mean, const float* invstd, const fl
 int rsg_bn_backward(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                     const float* gamma, void* dy, void* dres, float* dgamma, float* dbeta, float* workspace,
                     int64_t pixels, int32_t c, int32_t dtype, void* stream);
+/* Up to 8 INDEPENDENT BatchNorms (the branches of a HighResolutionModule, pose_hrnet.py:254-255) as three launches
+ * instead of three each.  Forward: fields y, gamma, beta, residual (or NULL), relu, out, mean, invstd, running_* (or
+ * NULL), workspace are read as by rsg_bn_stats + rsg_bn_apply.  Backward: y, dz, z (or NULL), mean, invstd, gamma,
+ * out (= dy), dres (or NULL), dgamma, dbeta, workspace as by rsg_bn_backward.  Every item needs a workspace of its
+ * own (rsg_bn_workspace_bytes).  Same arithmetic, same fixed reduction order as the single-map entry points. */
+typedef struct rsg_bn_item {
+    const void* y; const void* dz; const void* z; const void* residual;
+    void* out; void* dres;
+    const float* gamma; const float* beta;
+    float* mean; float* invstd; float* running_mean; float* running_var; float* dgamma; float* dbeta;
+    float* workspace;
+    int64_t pixels;
+    int32_t c, relu;
+} rsg_bn_item;
+int rsg_bn_forward_group(const rsg_bn_item* items, int32_t n, float momentum, float eps, int32_t dtype, void* stream);
+int rsg_bn_backward_group(const rsg_bn_item* items, int32_t n, int32_t dtype, void* stream);
 /* g = dout * (out > 0): the ReLU that ends a fuse sum (pose_hrnet.py:266);  out = a + b: a map with two consumers */
 int rsg_relu_backward(const void* dout, const void* out, void* g, int64_t n, int32_t dtype, void* stream);
 int rsg_add16(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);
@@ -357,6 +373,14 @@ size_t rsg_conv_wgrad_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w,
 int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, int32_t batch, int32_t in_h, int32_t in_w,
                    int32_t cin, int32_t cin_pad, int32_t out_h, int32_t out_w, int32_t cout, int32_t cout_pad, int32_t kh,
                    int32_t kw, int32_t stride, int32_t pad, int32_t dtype, void* stream);
+
+/* Up to 4 independent weight gradients of the same kernel size in one launch pair (the same conv position of a
+ * HighResolutionModule's branches); fields as the arguments of rsg_conv_wgrad, a workspace per item. */
+typedef struct rsg_wgrad_item {
+    const void* x; const void* dy; float* dw; void* workspace;
+    int32_t batch, in_h, in_w, cin, cin_pad, out_h, out_w, cout, cout_pad, kh, kw, stride, pad, reserved;
+} rsg_wgrad_item;
+int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int32_t dtype, void* stream);
 
 /* ---- crop producer ---------------------------------------------------------------
  * One person box per entry: `cv2.warpAffine(img, trans, (out_w, out_h), flags=INTER_LINEAR)` (constant border 0)

@@ -366,3 +366,219 @@ extern "C" int rsg_channel_sum_nchw_f32(const float* x, float* out, int32_t batc
     RSG_CHECK_LAUNCH("channel_sum");
     return 0;
 }
+
+// ---- grouped BatchNorm launches ------------------------------------------------------------------------------------
+// The four branches of a HighResolutionModule are independent, and on most of their maps a BatchNorm pass is a
+// launch-latency-sized kernel (3.2 us per kernel in a replayed graph against ~1 us of work): up to 8 independent
+// BatchNorms run as ONE partial, ONE final and ONE apply launch.  A workgroup finds its item by a scan of the block
+// offsets (static indices: the item arrives with one batch of scalar loads) and then runs the single-map code.
+#define RSG_BN_GROUP_MAX 8
+struct BnGroupItem {
+    const char* y; const char* dz; const char* z; const char* res;
+    char* out; char* dres;
+    const float* gamma; const float* beta;
+    float* mean; float* invstd; float* run_mean; float* run_var; float* dgamma; float* dbeta; float* part;
+    long pixels;
+    int C, relu, nb, na;
+};
+struct BnGroupArgs {
+    int n;
+    float momentum, eps;
+    int first_p[RSG_BN_GROUP_MAX + 1], first_f[RSG_BN_GROUP_MAX + 1], first_a[RSG_BN_GROUP_MAX + 1];
+    BnGroupItem it[RSG_BN_GROUP_MAX];
+};
+
+__device__ __forceinline__ int bn_group_pick(const int (&first)[RSG_BN_GROUP_MAX + 1], int n, BnGroupItem& it, const BnGroupArgs& g, int& local) {
+    int idx = 0;
+#pragma unroll
+    for (int k = 1; k < RSG_BN_GROUP_MAX; ++k) idx += (k < n && (int)blockIdx.x >= first[k]) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < RSG_BN_GROUP_MAX; ++k)
+        if (k == idx) { it = g.it[k]; local = (int)blockIdx.x - first[k]; }
+    return idx;
+}
+
+template <class DT, int MODE>
+__global__ void __launch_bounds__(256) bn_partial_group_kernel(const BnGroupArgs g) {
+    __shared__ float red[2][256][8];
+    BnGroupItem it; int blk = 0;
+    bn_group_pick(g.first_p, g.n, it, g, blk);
+    const int C = it.C, CP = C / 8, tid = threadIdx.x;
+    const int cc = tid % CP, pl = tid / CP, PPB = 256 / CP;
+    const long per = (it.pixels + it.nb - 1) / it.nb;
+    const long p0 = (long)blk * per, p1 = min(it.pixels, p0 + per);
+    f32x8 s0 = {0, 0, 0, 0, 0, 0, 0, 0}, s1 = s0, mu = s0, is = s0;
+    if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mu[e] = it.mean[cc * 8 + e]; is[e] = it.invstd[cc * 8 + e]; }
+    }
+    for (long p = p0 + pl; p < p1; p += PPB) {
+        const long off = (p * C + cc * 8) * 2;
+        const f32x8 v = load8<DT>(it.y + off);
+        if (MODE == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s0[e] += v[e]; s1[e] += v[e] * v[e]; }
+        } else {
+            f32x8 gq = load8<DT>(it.dz + off);
+            if (it.z) {
+                const f32x8 zz = load8<DT>(it.z + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gq[e] = zz[e] > 0.f ? gq[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s0[e] += gq[e]; s1[e] += gq[e] * ((v[e] - mu[e]) * is[e]); }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][tid][e] = s0[e]; red[1][tid][e] = s1[e]; }
+    __syncthreads();
+    if (tid < C) {
+        const int c8 = tid / 8, e = tid % 8;
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < PPB; ++k) { a += red[0][k * CP + c8][e]; b += red[1][k * CP + c8][e]; }
+        it.part[((long)blk * 2 + 0) * C + tid] = a;
+        it.part[((long)blk * 2 + 1) * C + tid] = b;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(64) bn_final_group_kernel(const BnGroupArgs g) {
+    __shared__ double ra[64], rb[64];
+    BnGroupItem it; int c = 0;
+    bn_group_pick(g.first_f, g.n, it, g, c);
+    const int t = threadIdx.x, C = it.C;
+    double a = 0.0, b = 0.0;
+    for (int k = t; k < it.nb; k += 64) { a += (double)it.part[((long)k * 2 + 0) * C + c]; b += (double)it.part[((long)k * 2 + 1) * C + c]; }
+    ra[t] = a; rb[t] = b;
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) {
+        if (t < w) { ra[t] += ra[t + w]; rb[t] += rb[t + w]; }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    a = ra[0]; b = rb[0];
+    if (MODE == 0) {
+        const double m = a / (double)it.pixels;
+        double var = b / (double)it.pixels - m * m;
+        if (var < 0.0) var = 0.0;
+        it.mean[c] = (float)m;
+        it.invstd[c] = (float)(1.0 / sqrt(var + (double)g.eps));
+        if (it.run_mean) it.run_mean[c] = (float)((1.0 - g.momentum) * (double)it.run_mean[c] + g.momentum * m);
+        if (it.run_var) {
+            const double unb = it.pixels > 1 ? var * (double)it.pixels / (double)(it.pixels - 1) : var;
+            it.run_var[c] = (float)((1.0 - g.momentum) * (double)it.run_var[c] + g.momentum * unb);
+        }
+    } else {
+        it.dbeta[c] = (float)a;
+        it.dgamma[c] = (float)b;
+    }
+}
+
+// MODE 0: forward apply; MODE 1: backward apply
+template <class DT, int MODE>
+__global__ void __launch_bounds__(256) bn_apply_group_kernel(const BnGroupArgs g) {
+    BnGroupItem it; int blk = 0;
+    bn_group_pick(g.first_a, g.n, it, g, blk);
+    const int C = it.C, CP = C / 8, tid = threadIdx.x, cc = tid % CP, pl = tid / CP, PPB = 256 / CP;
+    if (MODE == 0) {
+        f32x8 a, b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cc * 8 + e;
+            a[e] = it.gamma[c] * it.invstd[c];
+            b[e] = it.beta[c] - it.mean[c] * a[e];
+        }
+        for (long p = (long)blk * PPB + pl; p < it.pixels; p += (long)it.na * PPB) {
+            const long off = (p * C + cc * 8) * 2;
+            f32x8 v = load8<DT>(it.y + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * a[e] + b[e];
+            if (it.res) {
+                const f32x8 r = load8<DT>(it.res + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (it.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            store8<DT>(it.out + off, v);
+        }
+    } else {
+        const float invM = 1.f / (float)it.pixels;
+        f32x8 mu, is, a, m1, m2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cc * 8 + e;
+            mu[e] = it.mean[c]; is[e] = it.invstd[c]; a[e] = it.gamma[c] * it.invstd[c];
+            m1[e] = it.dbeta[c] * invM; m2[e] = it.dgamma[c] * invM;
+        }
+        for (long p = (long)blk * PPB + pl; p < it.pixels; p += (long)it.na * PPB) {
+            const long off = (p * C + cc * 8) * 2;
+            const f32x8 v = load8<DT>(it.y + off);
+            f32x8 gq = load8<DT>(it.dz + off);
+            if (it.z) {
+                const f32x8 zz = load8<DT>(it.z + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gq[e] = zz[e] > 0.f ? gq[e] : 0.f;
+            }
+            if (it.dres) store8<DT>(it.dres + off, gq);
+            f32x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = a[e] * (gq[e] - m1[e] - (v[e] - mu[e]) * is[e] * m2[e]);
+            store8<DT>(it.out + off, o);
+        }
+    }
+}
+
+static int bn_group_fill(const rsg_bn_item* items, int n, int backward, BnGroupArgs& g, const char* what) {
+    if (!items || n < 1 || n > RSG_BN_GROUP_MAX) RSG_FAIL("%s: 1..%d items", what, RSG_BN_GROUP_MAX);
+    memset(&g, 0, sizeof(g));
+    g.n = n;
+    int fp = 0, ff = 0, fa = 0;
+    for (int k = 0; k < n; ++k) {
+        const rsg_bn_item& s = items[k];
+        if (!s.y || !s.mean || !s.invstd || !s.gamma || !s.workspace || !s.out) RSG_FAIL("%s: item %d: null pointer", what, k);
+        if (backward ? (!s.dz || !s.dgamma || !s.dbeta) : !s.beta) RSG_FAIL("%s: item %d: null pointer", what, k);
+        if (!bn_check(s.c, s.pixels)) RSG_FAIL("%s: item %d: channels %d must be a power of two in [8, 256]", what, k, s.c);
+        BnGroupItem& d = g.it[k];
+        d.y = (const char*)s.y; d.dz = (const char*)s.dz; d.z = (const char*)s.z; d.res = (const char*)s.residual;
+        d.out = (char*)s.out; d.dres = (char*)s.dres; d.gamma = s.gamma; d.beta = s.beta; d.mean = s.mean; d.invstd = s.invstd;
+        d.run_mean = s.running_mean; d.run_var = s.running_var; d.dgamma = s.dgamma; d.dbeta = s.dbeta; d.part = s.workspace;
+        d.pixels = s.pixels; d.C = s.c; d.relu = s.relu;
+        d.nb = bn_blocks(s.pixels, s.c);
+        const long ppb = 256 / (s.c / 8);
+        d.na = (int)min((s.pixels + ppb - 1) / ppb, (long)1024);
+        g.first_p[k] = fp; g.first_f[k] = ff; g.first_a[k] = fa;
+        fp += d.nb; ff += s.c; fa += d.na;
+    }
+    g.first_p[n] = fp; g.first_f[n] = ff; g.first_a[n] = fa;
+    return 0;
+}
+
+extern "C" int rsg_bn_forward_group(const rsg_bn_item* items, int32_t n, float momentum, float eps, int32_t dtype, void* stream) {
+    BnGroupArgs g;
+    if (bn_group_fill(items, n, 0, g, "bn_forward_group")) return 1;
+    g.momentum = momentum; g.eps = eps;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RSG_BF16) RSG_LAUNCH((bn_partial_group_kernel<BF16, 0>), dim3(g.first_p[n]), dim3(256), 0, s, g);
+    else RSG_LAUNCH((bn_partial_group_kernel<F16, 0>), dim3(g.first_p[n]), dim3(256), 0, s, g);
+    RSG_LAUNCH(bn_final_group_kernel<0>, dim3(g.first_f[n]), dim3(64), 0, s, g);
+    if (dtype == RSG_BF16) RSG_LAUNCH((bn_apply_group_kernel<BF16, 0>), dim3(g.first_a[n]), dim3(256), 0, s, g);
+    else RSG_LAUNCH((bn_apply_group_kernel<F16, 0>), dim3(g.first_a[n]), dim3(256), 0, s, g);
+    RSG_CHECK_LAUNCH("bn_forward_group");
+    return 0;
+}
+
+extern "C" int rsg_bn_backward_group(const rsg_bn_item* items, int32_t n, int32_t dtype, void* stream) {
+    BnGroupArgs g;
+    if (bn_group_fill(items, n, 1, g, "bn_backward_group")) return 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == RSG_BF16) RSG_LAUNCH((bn_partial_group_kernel<BF16, 1>), dim3(g.first_p[n]), dim3(256), 0, s, g);
+    else RSG_LAUNCH((bn_partial_group_kernel<F16, 1>), dim3(g.first_p[n]), dim3(256), 0, s, g);
+    RSG_LAUNCH(bn_final_group_kernel<1>, dim3(g.first_f[n]), dim3(64), 0, s, g);
+    if (dtype == RSG_BF16) RSG_LAUNCH((bn_apply_group_kernel<BF16, 1>), dim3(g.first_a[n]), dim3(256), 0, s, g);
+    else RSG_LAUNCH((bn_apply_group_kernel<F16, 1>), dim3(g.first_a[n]), dim3(256), 0, s, g);
+    RSG_CHECK_LAUNCH("bn_backward_group");
+    return 0;
+}

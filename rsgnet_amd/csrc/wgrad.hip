@@ -42,11 +42,10 @@ __device__ __forceinline__ s16x4 tr_read(const char* lds, int off) {
 }
 
 template <class DT, int NT>
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pair = blockIdx.x / a.nslices, slice = blockIdx.x - pair * a.nslices;
+    const int pair = block / a.nslices, slice = block - pair * a.nslices;
     const int ot = pair / a.n_it, it = pair - ot * a.n_it;
     char* const sdy = smem;                                   // [P16][64 B]
     char* const sx = smem + a.P16 * 64;                       // [xrows * xcols][64 B]
@@ -156,15 +155,42 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     }
 }
 
+template <class DT, int NT>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_body<DT, NT>(a, blockIdx.x, smem);
+}
+
+// Up to 4 independent weight gradients (the same conv position of a HighResolutionModule's branches) in one launch
+#define RSG_WGRAD_GROUP_MAX 4
+struct WgradGroupArgs {
+    int n;
+    int first[RSG_WGRAD_GROUP_MAX + 1];
+    WgradArgs a[RSG_WGRAD_GROUP_MAX];
+};
+template <class DT, int NT>
+__global__ void __launch_bounds__(256) wgrad_group_kernel(const WgradGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int idx = 0;
+#pragma unroll
+    for (int k = 1; k < RSG_WGRAD_GROUP_MAX; ++k) idx += (k < g.n && (int)blockIdx.x >= g.first[k]) ? 1 : 0;
+    WgradArgs a;
+    int block = 0;
+#pragma unroll
+    for (int k = 0; k < RSG_WGRAD_GROUP_MAX; ++k)
+        if (k == idx) { a = g.a[k]; block = (int)blockIdx.x - g.first[k]; }
+    wgrad_body<DT, NT>(a, block, smem);
+}
+
 // dW[o][i][t] = sum over slices of part[(ot, it)][slice][t][o % 32][i % 32], in a fixed order: a workgroup owns a
 // quarter (256 elements) of one (pair, tap) tile; lane l of slice group sg (4 groups) adds the float4 l of slices
 // sg, sg+4, ... and the four group sums are added in group order through LDS.  Every read is a coalesced 1 KB row.
 // (The first version gave each thread one output element and walked the slices with a 36 KB stride: uncoalesced, a
 // quarter of the training step.)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int cout, int cin,
-                                                           int ntaps, int n_it, int nslices) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int cout, int cin,
+                                                  int ntaps, int n_it, int nslices, const int block) {
     __shared__ float4 red[3][64];
-    const int tile = blockIdx.x >> 2, quarter = blockIdx.x & 3;          // tile = pair * ntaps + t
+    const int tile = block >> 2, quarter = block & 3;                    // tile = pair * ntaps + t
     const int pair = tile / ntaps, t = tile - pair * ntaps;
     const int l = threadIdx.x & 63, sg = threadIdx.x >> 6;
     const float4* p = reinterpret_cast<const float4*>(part + ((size_t)pair * nslices * ntaps + t) * 1024) + quarter * 64 + l;
@@ -186,6 +212,29 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (i0 + j < cin) dw[((size_t)o * cin + i0 + j) * ntaps + t] = v[j];
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int cout, int cin,
+                                                           int ntaps, int n_it, int nslices) {
+    wgrad_reduce_body(part, dw, cout, cin, ntaps, n_it, nslices, blockIdx.x);
+}
+struct WgradReduceGroupArgs {
+    int n, ntaps;
+    int first[RSG_WGRAD_GROUP_MAX + 1];
+    const float* part[RSG_WGRAD_GROUP_MAX];
+    float* dw[RSG_WGRAD_GROUP_MAX];
+    int cout[RSG_WGRAD_GROUP_MAX], cin[RSG_WGRAD_GROUP_MAX], n_it[RSG_WGRAD_GROUP_MAX], nslices[RSG_WGRAD_GROUP_MAX];
+};
+__global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradReduceGroupArgs g) {
+    int idx = 0;
+#pragma unroll
+    for (int k = 1; k < RSG_WGRAD_GROUP_MAX; ++k) idx += (k < g.n && (int)blockIdx.x >= g.first[k]) ? 1 : 0;
+    const float* part = nullptr; float* dw = nullptr;
+    int cout = 0, cin = 0, n_it = 0, nslices = 0, block = 0;
+#pragma unroll
+    for (int k = 0; k < RSG_WGRAD_GROUP_MAX; ++k)
+        if (k == idx) { part = g.part[k]; dw = g.dw[k]; cout = g.cout[k]; cin = g.cin[k]; n_it = g.n_it[k]; nslices = g.nslices[k]; block = (int)blockIdx.x - g.first[k]; }
+    wgrad_reduce_body(part, dw, cout, cin, g.ntaps, n_it, nslices, block);
 }
 
 struct WgradPlan { WgradArgs a; int lds, grid, ntaps; };
@@ -251,5 +300,47 @@ extern "C" int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
     RSG_LAUNCH(wgrad_reduce_kernel, dim3(p.a.n_ot * p.a.n_it * p.ntaps * 4), dim3(256), 0, s, (const float*)workspace, dw, cout, cin,
                p.ntaps, p.a.n_it, p.a.nslices);
     RSG_CHECK_LAUNCH("conv_wgrad");
+    return 0;
+}
+
+
+extern "C" int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int32_t dtype, void* stream) {
+    if (!items || n < 1 || n > RSG_WGRAD_GROUP_MAX) RSG_FAIL("conv_wgrad_group: 1..%d items", RSG_WGRAD_GROUP_MAX);
+    WgradGroupArgs g;
+    WgradReduceGroupArgs r;
+    memset(&g, 0, sizeof(g));
+    memset(&r, 0, sizeof(r));
+    g.n = r.n = n;
+    int lds = 0, blocks = 0, rblocks = 0, ntaps = 0;
+    for (int k = 0; k < n; ++k) {
+        const rsg_wgrad_item& it = items[k];
+        if (!it.x || !it.dy || !it.dw || !it.workspace) RSG_FAIL("conv_wgrad_group: item %d: null pointer", k);
+        if (((uintptr_t)it.x | (uintptr_t)it.dy | (uintptr_t)it.workspace) & 15) RSG_FAIL("conv_wgrad_group: item %d: alignment", k);
+        if (it.cin < 1 || it.cin > it.cin_pad || it.cout < 1 || it.cout > it.cout_pad) RSG_FAIL("conv_wgrad_group: item %d: channels", k);
+        WgradPlan p;
+        if (wgrad_plan(it.batch, it.in_h, it.in_w, it.cin_pad, it.out_h, it.out_w, it.cout_pad, it.kh, it.kw, it.stride, it.pad, p))
+            RSG_FAIL("conv_wgrad_group: item %d: unsupported geometry", k);
+        if ((long long)it.batch * it.in_h * it.in_w * it.cin_pad * 2 >= (1LL << 31) || (long long)it.batch * it.out_h * it.out_w * it.cout_pad * 2 >= (1LL << 31))
+            RSG_FAIL("conv_wgrad_group: item %d: map too large for 32-bit offsets", k);
+        if (k && p.ntaps != ntaps) RSG_FAIL("conv_wgrad_group: every item must have the same kernel size");
+        ntaps = p.ntaps;
+        p.a.x = (const char*)it.x; p.a.dy = (const char*)it.dy; p.a.part = (float*)it.workspace;
+        g.a[k] = p.a;
+        g.first[k] = blocks; blocks += p.grid;
+        lds = max(lds, p.lds);
+        r.part[k] = (const float*)it.workspace; r.dw[k] = it.dw; r.cout[k] = it.cout; r.cin[k] = it.cin;
+        r.n_it[k] = p.a.n_it; r.nslices[k] = p.a.nslices;
+        r.first[k] = rblocks; rblocks += p.a.n_ot * p.a.n_it * p.ntaps * 4;
+    }
+    g.first[n] = blocks; r.first[n] = rblocks; r.ntaps = ntaps;
+    hipStream_t s = (hipStream_t)stream;
+    void (*fn)(const WgradGroupArgs) = nullptr;
+    if (dtype == RSG_BF16) fn = ntaps == 9 ? wgrad_group_kernel<BF16, 9> : wgrad_group_kernel<BF16, 1>;
+    else fn = ntaps == 9 ? wgrad_group_kernel<F16, 9> : wgrad_group_kernel<F16, 1>;
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        RSG_FAIL("conv_wgrad_group: cannot reserve %d B of LDS", lds);
+    RSG_LAUNCH(fn, dim3(blocks), dim3(256), lds, s, g);
+    RSG_LAUNCH(wgrad_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, r);
+    RSG_CHECK_LAUNCH("conv_wgrad_group");
     return 0;
 }

@@ -58,6 +58,19 @@ class PackItem(C.Structure):
                 ("kw", C.c_int32), ("transpose", C.c_int32), ("first_block", C.c_int32)]
 
 
+class BnItem(C.Structure):
+    """struct rsg_bn_item (include/rsgnet_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("y", "dz", "z", "residual", "out", "dres", "gamma", "beta", "mean", "invstd",
+                                          "running_mean", "running_var", "dgamma", "dbeta", "workspace")] + \
+               [("pixels", C.c_int64), ("c", C.c_int32), ("relu", C.c_int32)]
+
+
+class WgradItem(C.Structure):
+    """struct rsg_wgrad_item (include/rsgnet_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p)] + \
+               [(n, C.c_int32) for n in "batch in_h in_w cin cin_pad out_h out_w cout cout_pad kh kw stride pad reserved".split()]
+
+
 class CropDesc(C.Structure):
     """struct rsg_crop_desc (include/rsgnet_hip.h)."""
     _fields_ = [("image", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("stride", C.c_int32),
@@ -121,6 +134,8 @@ SYMBOLS = {
     "rsg_bn_stats": (C.c_int, [_vp, C.c_int64, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp]),
     "rsg_bn_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_int64, _i, _i, _vp]),
     "rsg_bn_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _i, _i, _vp]),
+    "rsg_bn_forward_group": (C.c_int, [C.POINTER(BnItem), _i, C.c_float, C.c_float, _i, _vp]),
+    "rsg_bn_backward_group": (C.c_int, [C.POINTER(BnItem), _i, _i, _vp]),
     "rsg_relu_backward": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
     "rsg_add16": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
     "rsg_upsample_nearest_backward": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -128,6 +143,7 @@ SYMBOLS = {
     "rsg_channel_sum_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "rsg_conv_wgrad_workspace_bytes": (C.c_size_t, [_i] * 11),
     "rsg_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp]),
+    "rsg_conv_wgrad_group": (C.c_int, [C.POINTER(WgradItem), _i, _i, _vp]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }

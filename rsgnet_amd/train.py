@@ -55,23 +55,29 @@ class TrainPlan:
     def __init__(self, model: nn.Module, batch: int, device: torch.device):
         self.lib = hip.lib()
         self.model, self.batch, self.device = model, batch, device
-        self.fwd: List[Tuple[str, Callable[[int], None]]] = []
-        self.bwd: List[Tuple[str, Callable[[int], None]]] = []
+        self.fwd: List[tuple] = []      # (name, launch(stream), group kind or None, group item maker or None)
+        self.bwd: List[tuple] = []
         self._ops: List[dict] = []
         self._keep: List[object] = []
         self._packs: List[dict] = []            # one entry per packed weight (forward and data-gradient forms)
         self._bn_ws = torch.empty(self.lib.rsg_bn_workspace_bytes(256), dtype=torch.uint8, device=device)
-        self._wgrad_ws: Optional[torch.Tensor] = None
-        self._wgrad_need = 0
+        self._wgrad_lane_need: Dict[int, int] = {}
+        self._wgrad_lane_ws: Dict[int, torch.Tensor] = {}
+        self._bwd_lane = 0
         self._zero_bias = torch.zeros(256, dtype=torch.float32, device=device)
         self._param_ptrs: Optional[Tuple[int, ...]] = None
         self._gbuf: Dict[int, torch.Tensor] = {}
+        self._sink: Dict[str, Optional[list]] = {"fwd": None, "bwd": None}
+        self._region: Optional[Tuple[int, int]] = None
+        self._rid = 0
+        self._bn_momentum, self._bn_eps = 0.1, 1e-5
         self._params = [p for p in model.parameters() if p.requires_grad]
         self._sig: Optional[Tuple[int, ...]] = None
         self._graphs: Optional[Tuple[torch.cuda.CUDAGraph, torch.cuda.CUDAGraph]] = None
         self._warm = 0
         import os
         self.use_graph = os.environ.get("RSGNET_HIP_TRAIN_GRAPH", "1") != "0"
+        self.use_lanes = os.environ.get("RSGNET_HIP_TRAIN_LANES", "1") != "0"
         self.flops_fwd = 0
         W, H = model.cfg.MODEL.IMAGE_SIZE
         self.H, self.W, self.J = H, W, model.cfg.MODEL.NUM_JOINTS
@@ -80,7 +86,7 @@ class TrainPlan:
         self.dheat = torch.zeros_like(self.heat)
         self._record(model)
         self._record_backward()
-        self._wgrad_ws = torch.empty(max(self._wgrad_need, 16), dtype=torch.uint8, device=device)
+        self._wgrad_lane_ws = {k: torch.empty(max(v, 16), dtype=torch.uint8, device=device) for k, v in self._wgrad_lane_need.items()}
         self._build_pack_table()
         self._bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
         self._nbt = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
@@ -89,6 +95,103 @@ class TrainPlan:
     def _chk(self, rc: int, what: str):
         if rc:
             hip.check(rc, what)
+
+    # ---- launch lists: entries are (name, fn) with optional grouping info; independent lanes (the branches of a
+    # HighResolutionModule) are recorded side by side and zipped position by position, so that the k-th BatchNorm of
+    # every branch lands next to its siblings and the run becomes ONE grouped launch (rsg_bn_*_group): a replayed graph
+    # pays ~3.2 us per kernel whatever its size, and most of these kernels are smaller than that
+    def _emit(self, which: str, name: str, fn: Callable[[int], None], gkind: Optional[str] = None, item=None):
+        rec = (name, fn, gkind, item)
+        sink = self._sink.get(which)
+        (sink if sink is not None else getattr(self, which)).append(rec)
+
+    def _emit_op(self, op: dict):
+        if self._region is not None:
+            rid, lane = self._region
+            self._region_ops[lane].append(op)
+            op["region"] = (rid, lane)
+        else:
+            self._ops.append(op)
+
+    def _begin_lanes(self, n: int):
+        self._rid += 1
+        self._region = (self._rid, 0)
+        self._region_ops = [[] for _ in range(n)]
+        self._region_fwd = [[] for _ in range(n)]
+
+    def _lane(self, k: int):
+        self._region = (self._region[0], k)
+        self._sink["fwd"] = self._region_fwd[k]
+
+    def _end_lanes(self):
+        lanes_ops, lanes_fwd = self._region_ops, self._region_fwd
+        self._region, self._sink["fwd"] = None, None
+        for pos in range(max(len(l) for l in lanes_ops)):
+            for lane in lanes_ops:
+                if pos < len(lane):
+                    lane[pos]["region"] = lane[pos]["region"] + (pos,)
+                    self._ops.append(lane[pos])
+        self.fwd.extend(self._merge(self._zip(lanes_fwd)))
+
+    @staticmethod
+    def _zip(lanes: List[list]) -> list:
+        out = []
+        for pos in range(max((len(l) for l in lanes), default=0)):
+            for lane in lanes:
+                if pos < len(lane):
+                    out.append(lane[pos])
+        return out
+
+    def _merge(self, recs: list) -> list:
+        """Runs of adjacent groupable launches of one kind -> one grouped launch each."""
+        out, i = [], 0
+        while i < len(recs):
+            name, fn, gkind, item = recs[i]
+            j = i + 1
+            if gkind is not None:
+                cap = 4 if gkind.startswith("wgrad") else {"conv": 12}.get(gkind, 8)
+                while j < len(recs) and recs[j][2] == gkind and j - i < cap:
+                    j += 1
+            if j - i >= 2:
+                out.append((f"{name}(+{j - i - 1})", self._group_launch(gkind, [r[3] for r in recs[i:j]]), None, None))
+            else:
+                out.append(recs[i])
+                j = i + 1
+            i = j
+        return out
+
+    def _group_launch(self, gkind: str, makers: list) -> Callable[[int], None]:
+        lib, n = self.lib, len(makers)
+        if gkind == "conv":        # rsg_conv_fuse_group: every address in the descriptors is static, plan once
+            import numpy as np
+            cd = (hip.ConvDesc * n)(*makers)
+            fi = (hip.FuseItem * 1)()
+            table = np.zeros(lib.rsg_group_table_bytes(), np.uint8)
+            launch2 = (C.c_int32 * 2)()
+            hip.check(lib.rsg_conv_fuse_group_plan(cd, n, fi, 0, BF16, table.ctypes.data, launch2), "conv group plan")
+            self._keep += [cd, table]
+            tptr, blocks, lds = table.ctypes.data, launch2[0], launch2[1]
+            return lambda s: self._chk(lib.rsg_conv_fuse_group_run(tptr, blocks, lds, BF16, s), "conv group")
+        if gkind.startswith("wgrad"):
+            warr = (hip.WgradItem * n)()
+            self._keep.append(warr)
+
+            def wlaunch(s):
+                for k, mk in enumerate(makers):
+                    mk(warr[k])
+                self._chk(lib.rsg_conv_wgrad_group(warr, n, BF16, s), "conv_wgrad_group")
+            return wlaunch
+        arr = (hip.BnItem * n)()
+        self._keep.append(arr)
+
+        def launch(s):
+            for k, mk in enumerate(makers):      # addresses are read at launch time (a re-seated parameter re-captures)
+                mk(arr[k])
+            if gkind == "bn_fwd":
+                self._chk(lib.rsg_bn_forward_group(arr, n, self._bn_momentum, self._bn_eps, BF16, s), "bn_forward_group")
+            else:
+                self._chk(lib.rsg_bn_backward_group(arr, n, BF16, s), "bn_backward_group")
+        return launch
 
     def _grad_of(self, p: torch.nn.Parameter) -> torch.Tensor:
         """The fp32 buffer the kernels write this parameter's gradient into.  It is the parameter's own `.grad` when
@@ -172,8 +275,9 @@ class TrainPlan:
         wp = self._packed(m.weight, False)
         d = self._conv_desc(x.data, wp, self._zero_bias, y.data, None, x.H, x.W, cin_pad, O, k, stride)
         fn, ref = self.lib.rsg_conv_igemm, C.byref(d)
-        self.fwd.append((name, lambda s, fn=fn, ref=ref, nm=name: self._chk(fn(ref, s), nm)))
-        self._ops.append(dict(kind="conv", x=x, y=y, m=m, name=name, cin_pad=cin_pad))
+        gk = "conv" if self.lib.rsg_conv_groupable(ref) else None
+        self._emit("fwd", name, lambda s, fn=fn, ref=ref, nm=name: self._chk(fn(ref, s), nm), gk, d)
+        self._emit_op(dict(kind="conv", x=x, y=y, m=m, name=name, cin_pad=cin_pad))
         self.flops_fwd += 2 * self.batch * y.H * y.W * O * I * k * k
         return y
 
@@ -182,8 +286,16 @@ class TrainPlan:
         z = T(self, y.H, y.W, y.C, name)
         mean = torch.zeros(y.C, dtype=torch.float32, device=self.device)
         invstd = torch.zeros(y.C, dtype=torch.float32, device=self.device)
-        lib, ws, px, Cc = self.lib, self._bn_ws, y.pixels, y.C
+        lib, px, Cc = self.lib, y.pixels, y.C
         mom, eps = float(m.momentum), float(m.eps)
+
+        ws = torch.empty(lib.rsg_bn_workspace_bytes(Cc), dtype=torch.uint8, device=self.device)   # own: BatchNorms may share a launch
+
+        def item(it):
+            it.y, it.out, it.residual = y.data.data_ptr(), z.data.data_ptr(), (res.data.data_ptr() if res is not None else None)
+            it.gamma, it.beta, it.mean, it.invstd = m.weight.data_ptr(), m.bias.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+            it.running_mean, it.running_var, it.workspace = m.running_mean.data_ptr(), m.running_var.data_ptr(), ws.data_ptr()
+            it.pixels, it.c, it.relu = px, Cc, int(relu)
 
         def launch(s):
             self._chk(lib.rsg_bn_stats(y.data.data_ptr(), px, Cc, BF16, ws.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
@@ -192,8 +304,10 @@ class TrainPlan:
                                        m.bias.data_ptr(), res.data.data_ptr() if res is not None else None, int(relu),
                                        z.data.data_ptr(), px, Cc, BF16, s), name)
 
-        self.fwd.append((name, launch))
-        self._ops.append(dict(kind="bn", y=y, z=z, m=m, relu=relu, res=res, mean=mean, invstd=invstd, name=name))
+        if (mom, eps) != (self._bn_momentum, self._bn_eps):
+            raise NotImplementedError(f"{name}: BatchNorm momentum/eps {mom}/{eps} (the reference uses 0.1 / 1e-5 everywhere)")
+        self._emit("fwd", name, launch, "bn_fwd", item)
+        self._emit_op(dict(kind="bn", y=y, z=z, m=m, relu=relu, res=res, mean=mean, invstd=invstd, name=name, ws=ws))
         return z
 
     def unit(self, x: T, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, name: str, res: Optional[T] = None) -> T:
@@ -208,16 +322,16 @@ class TrainPlan:
         ls = (C.c_int32 * max(len(low), 1))(*[s for _, s in low])
         self._keep += [sp, lp, ls]
         lib, B = self.lib, self.batch
-        self.fwd.append((name, lambda s: self._chk(lib.rsg_hr_fuse_sum(sp, len(same), lp, ls, len(low), out.data.data_ptr(), B,
-                                                                     out.H, out.W, out.C, BF16, s), name)))
-        self._ops.append(dict(kind="fuse", same=list(same), low=list(low), out=out, name=name))
+        self._emit("fwd", name, lambda s: self._chk(lib.rsg_hr_fuse_sum(sp, len(same), lp, ls, len(low), out.data.data_ptr(), B,
+                                                                     out.H, out.W, out.C, BF16, s), name))
+        self._emit_op(dict(kind="fuse", same=list(same), low=list(low), out=out, name=name))
         return out
 
     def _record(self, m: nn.Module):
         lib, B, H, W = self.lib, self.batch, self.H, self.W
         x16 = T(self, H, W, 16, "x_nhwc16", needs_grad=False)
-        self.fwd.append(("input", lambda s: self._chk(lib.rsg_nchw_f32_to_nhwc16(self.x_f32.data_ptr(), x16.data.data_ptr(), B, 3,
-                                                                              H, W, 16, BF16, s), "input")))
+        self._emit("fwd", "input", lambda s: self._chk(lib.rsg_nchw_f32_to_nhwc16(self.x_f32.data_ptr(), x16.data.data_ptr(), B, 3,
+                                                                              H, W, 16, BF16, s), "input"))
         x = self.unit(x16, m.conv1, m.bn1, True, "conv1")
         x = self.unit(x, m.conv2, m.bn2, True, "conv2")
         for k, blk in enumerate(m.layer1):
@@ -252,8 +366,8 @@ class TrainPlan:
             bias32[:J].copy_(fl.bias.detach())
             self._chk(lib.rsg_conv_igemm(ref, s), "final_layer")
 
-        self.fwd.append(("final_layer", launch))
-        self._ops.append(dict(kind="final", x=x0, m=fl, name="final_layer"))
+        self._emit("fwd", "final_layer", launch)
+        self._emit_op(dict(kind="final", x=x0, m=fl, name="final_layer"))
         self.flops_fwd += 2 * B * x0.H * x0.W * J * x0.C
 
     def _block(self, x: T, blk, name: str) -> T:
@@ -270,9 +384,16 @@ class TrainPlan:
     def _hr_module(self, xs: List[T], mod, name: str) -> List[T]:
         """HighResolutionModule.forward (pose_hrnet.py:250-268), training mode."""
         xs = list(xs)
+        same_shape = len({len(br) for br in mod.branches}) == 1 and len(mod.branches) > 1 and self.use_lanes
+        if same_shape:
+            self._begin_lanes(len(mod.branches))
         for b, branch in enumerate(mod.branches):
+            if same_shape:
+                self._lane(b)
             for k, blk in enumerate(branch):
                 xs[b] = self._block(xs[b], blk, f"{name}.branches.{b}.{k}")
+        if same_shape:
+            self._end_lanes()
         if mod.fuse_layers is None:
             return xs
         outs = []
@@ -303,7 +424,7 @@ class TrainPlan:
         lib, n = self.lib, src.numel()
         a = t.grad
         dst = torch.empty_like(a) if t.grad_shared else a
-        self.bwd.append((name + ".add", lambda s: self._chk(lib.rsg_add16(a.data_ptr(), src.data_ptr(), dst.data_ptr(), n, BF16, s), name)))
+        self._emit("bwd", name + ".add", lambda s: self._chk(lib.rsg_add16(a.data_ptr(), src.data_ptr(), dst.data_ptr(), n, BF16, s), name))
         t.grad, t.grad_shared = dst, False
 
     def _new_like(self, t: T) -> torch.Tensor:
@@ -311,16 +432,33 @@ class TrainPlan:
 
     def _record_backward(self):
         lib, B = self.lib, self.batch
+        bucket: Dict[int, list] = {}             # lane -> backward launches of the lanes' ops at the current position
+        cur_key = None
+
+        def flush():
+            nonlocal bucket
+            if bucket:
+                self._sink["bwd"] = None
+                self.bwd.extend(self._merge(self._zip([bucket[k] for k in sorted(bucket, reverse=True)])))
+                bucket = {}
+
         for op in reversed(self._ops):
             kind, name = op["kind"], op["name"]
+            reg = op.get("region")
+            key = (reg[0], reg[2]) if reg is not None else None
+            if key != cur_key:
+                flush()
+                cur_key = key
+            self._sink["bwd"] = bucket.setdefault(reg[1], []) if reg is not None else None
+            self._bwd_lane = reg[1] if reg is not None else 0
             if kind == "final":
                 x, fl = op["x"], op["m"]
                 J = self.J
                 d16 = torch.zeros(B, x.H, x.W, 32, dtype=torch.bfloat16, device=self.device)
-                self.bwd.append((name + ".dheat", lambda s, d16=d16, x=x: self._chk(
-                    lib.rsg_nchw_f32_to_nhwc16(self.dheat.data_ptr(), d16.data_ptr(), B, J, x.H, x.W, 32, BF16, s), "dheat")))
-                self.bwd.append((name + ".dbias", lambda s, fl=fl, x=x: self._chk(
-                    lib.rsg_channel_sum_nchw_f32(self.dheat.data_ptr(), self._grad_of(fl.bias).data_ptr(), B, J, x.H * x.W, s), "dbias")))
+                self._emit("bwd", name + ".dheat", lambda s, d16=d16, x=x: self._chk(
+                    lib.rsg_nchw_f32_to_nhwc16(self.dheat.data_ptr(), d16.data_ptr(), B, J, x.H, x.W, 32, BF16, s), "dheat"))
+                self._emit("bwd", name + ".dbias", lambda s, fl=fl, x=x: self._chk(
+                    lib.rsg_channel_sum_nchw_f32(self.dheat.data_ptr(), self._grad_of(fl.bias).data_ptr(), B, J, x.H * x.W, s), "dbias"))
                 self._wgrad(x.data, d16, fl.weight, x.H, x.W, x.C, x.C, x.H, x.W, J, 32, 1, 1, name)
                 self._dgrad(x, d16, fl.weight, 32, 1, 1, x.H, x.W, name)
             elif kind == "fuse":
@@ -329,14 +467,14 @@ class TrainPlan:
                     continue                              # an output nobody consumed (does not occur in pose_hrnet)
                 g = torch.zeros_like(out.data)
                 dout, n = out.grad, out.data.numel()
-                self.bwd.append((name + ".relu", lambda s, dout=dout, out=out, g=g, n=n: self._chk(
-                    lib.rsg_relu_backward(dout.data_ptr(), out.data.data_ptr(), g.data_ptr(), n, BF16, s), "relu_backward")))
+                self._emit("bwd", name + ".relu", lambda s, dout=dout, out=out, g=g, n=n: self._chk(
+                    lib.rsg_relu_backward(dout.data_ptr(), out.data.data_ptr(), g.data_ptr(), n, BF16, s), "relu_backward"))
                 for t in op["same"]:
                     self._contribute(t, g, True, name)
                 for t, sh in op["low"]:
                     lo = torch.zeros_like(t.data)
-                    self.bwd.append((name + ".up", lambda s, g=g, lo=lo, t=t, sh=sh: self._chk(
-                        lib.rsg_upsample_nearest_backward(g.data_ptr(), lo.data_ptr(), B, t.H, t.W, t.C, sh, BF16, s), "upsample_bwd")))
+                    self._emit("bwd", name + ".up", lambda s, g=g, lo=lo, t=t, sh=sh: self._chk(
+                        lib.rsg_upsample_nearest_backward(g.data_ptr(), lo.data_ptr(), B, t.H, t.W, t.C, sh, BF16, s), "upsample_bwd"))
                     self._contribute(t, lo, False, name)
             elif kind == "bn":
                 y, z, m, res = op["y"], op["z"], op["m"], op["res"]
@@ -345,16 +483,23 @@ class TrainPlan:
                 dz = z.grad
                 y.grad = torch.zeros_like(y.data)
                 dres = torch.zeros_like(z.data) if res is not None and res.needs_grad else None
-                mean, invstd, relu, ws, px, Cc = op["mean"], op["invstd"], op["relu"], self._bn_ws, y.pixels, y.C
+                mean, invstd, relu, ws, px, Cc = op["mean"], op["invstd"], op["relu"], op["ws"], y.pixels, y.C
 
-                def launch(s, dz=dz, y=y, z=z, m=m, dres=dres, mean=mean, invstd=invstd, relu=relu, px=px, Cc=Cc):
+                def item(it, dz=dz, y=y, z=z, m=m, dres=dres, mean=mean, invstd=invstd, relu=relu, px=px, Cc=Cc, ws=ws):
+                    it.y, it.dz, it.z = y.data.data_ptr(), dz.data_ptr(), (z.data.data_ptr() if relu else None)
+                    it.out, it.dres = y.grad.data_ptr(), (dres.data_ptr() if dres is not None else None)
+                    it.gamma, it.mean, it.invstd = m.weight.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+                    it.dgamma, it.dbeta, it.workspace = self._grad_of(m.weight).data_ptr(), self._grad_of(m.bias).data_ptr(), ws.data_ptr()
+                    it.pixels, it.c, it.relu = px, Cc, int(relu)
+
+                def launch(s, dz=dz, y=y, z=z, m=m, dres=dres, mean=mean, invstd=invstd, relu=relu, px=px, Cc=Cc, ws=ws):
                     self._chk(lib.rsg_bn_backward(dz.data_ptr(), z.data.data_ptr() if relu else None, y.data.data_ptr(),
                                                   mean.data_ptr(), invstd.data_ptr(), m.weight.data_ptr(), y.grad.data_ptr(),
                                                   dres.data_ptr() if dres is not None else None,
                                                   self._grad_of(m.weight).data_ptr(), self._grad_of(m.bias).data_ptr(),
                                                   ws.data_ptr(), px, Cc, BF16, s), "bn_backward")
 
-                self.bwd.append((name, launch))
+                self._emit("bwd", name, launch, "bn_bwd", item)
                 if dres is not None:
                     self._contribute(res, dres, False, name)
             elif kind == "conv":
@@ -364,19 +509,28 @@ class TrainPlan:
                 self._wgrad(x.data, y.grad, m.weight, x.H, x.W, I, op["cin_pad"], y.H, y.W, O, O, k, stride, name)
                 if x.needs_grad:
                     self._dgrad(x, y.grad, m.weight, O, k, stride, y.H, y.W, name)
+        flush()
+        self._sink["bwd"] = None
 
     def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, w: torch.nn.Parameter, H, W, cin, cin_pad, Ho, Wo, cout, cout_pad, k, stride, name):
         lib, B, pad = self.lib, self.batch, (k - 1) // 2
         need = int(lib.rsg_conv_wgrad_workspace_bytes(B, H, W, cin_pad, Ho, Wo, cout_pad, k, k, stride, pad))
         if not need:
             raise NotImplementedError(f"{name}: weight gradient of a {k}x{k} stride-{stride} conv")
-        self._wgrad_need = max(self._wgrad_need, need)
+
+        lane = self._bwd_lane                    # grouped launches run several weight gradients at once: a workspace per lane
+        self._wgrad_lane_need[lane] = max(self._wgrad_lane_need.get(lane, 0), need)
+
+        def item(it):
+            it.x, it.dy, it.dw, it.workspace = x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_lane_ws[lane].data_ptr()
+            it.batch, it.in_h, it.in_w, it.cin, it.cin_pad = B, H, W, cin, cin_pad
+            it.out_h, it.out_w, it.cout, it.cout_pad, it.kh, it.kw, it.stride, it.pad = Ho, Wo, cout, cout_pad, k, k, stride, pad
 
         def launch(s):
-            self._chk(lib.rsg_conv_wgrad(x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_ws.data_ptr(), B, H, W,
+            self._chk(lib.rsg_conv_wgrad(x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_lane_ws[lane].data_ptr(), B, H, W,
                                          cin, cin_pad, Ho, Wo, cout, cout_pad, k, k, stride, pad, BF16, s), name + ".wgrad")
 
-        self.bwd.append((name + ".wgrad", launch))
+        self._emit("bwd", name + ".wgrad", launch, f"wgrad{k}", item)
 
     def _dgrad(self, x: T, dy: torch.Tensor, w: torch.nn.Parameter, dy_c: int, k: int, stride: int, Ho: int, Wo: int, name: str):
         """dx = conv_transpose(dy, w): a stride-1 conv of dy (stride 2: of dy spread onto the input grid with zeros
@@ -388,7 +542,7 @@ class TrainPlan:
             if (2 * Ho, 2 * Wo) != (x.H, x.W):
                 raise NotImplementedError(f"{name}: stride-2 data gradient on an odd map")
             src = torch.zeros(B, 2 * Ho, 2 * Wo, dy_c, dtype=torch.bfloat16, device=self.device)
-            self.bwd.append((name + ".spread", lambda s: self._chk(lib.rsg_zero_insert2x(dy.data_ptr(), src.data_ptr(), B, Ho, Wo, dy_c, s), name)))
+            self._emit("bwd", name + ".spread", lambda s: self._chk(lib.rsg_zero_insert2x(dy.data_ptr(), src.data_ptr(), B, Ho, Wo, dy_c, s), name))
             sh, sw = 2 * Ho, 2 * Wo
         dx = torch.zeros_like(x.data)
         cin_real = w.shape[1]
@@ -396,7 +550,8 @@ class TrainPlan:
         if _round_up(cin_real, 32) != x.C:
             raise NotImplementedError(f"{name}: data gradient into a {x.C}-channel map")
         ref = C.byref(d)
-        self.bwd.append((name + ".dgrad", lambda s: self._chk(lib.rsg_conv_igemm(ref, s), name + ".dgrad")))
+        self._emit("bwd", name + ".dgrad", lambda s: self._chk(lib.rsg_conv_igemm(ref, s), name + ".dgrad"),
+                   "conv" if lib.rsg_conv_groupable(ref) else None, d)
         self._contribute(x, dx, False, name)
 
     # ------------------------------------------------------------------ execution
@@ -404,14 +559,14 @@ class TrainPlan:
         s = torch.cuda.current_stream(self.device).cuda_stream
         self._chk(self.lib.rsg_pack_conv_weights_device(self._pack_items.data_ptr(), len(self._packs), self._pack_blocks, BF16, s),
                   "pack_weights")
-        for _, op in self.fwd:
-            op(s)
+        for rec in self.fwd:
+            rec[1](s)
         torch._foreach_add_(self._nbt, 1)            # num_batches_tracked of every BatchNorm, one launch
 
     def _run_backward(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
-        for _, op in self.bwd:
-            op(s)
+        for rec in self.bwd:
+            rec[1](s)
 
     def _prepare(self):
         """Before a forward: follow re-seated parameters / gradients, and (re)capture the two HIP graphs once the

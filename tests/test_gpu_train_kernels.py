@@ -251,3 +251,75 @@ def test_gradient_plumbing_kernels():
     hip.check(lib.rsg_channel_sum_nchw_f32(xd.data_ptr(), out.data_ptr(), 3, 17, 64 * 48, _stream()))
     torch.cuda.synchronize()
     assert (out.cpu().double() - x.double().sum((0, 2))).abs().max() < 1e-3
+
+
+def test_grouped_batchnorm_and_wgrad_equal_the_single_launches():
+    """rsg_bn_forward_group / rsg_bn_backward_group / rsg_conv_wgrad_group over three differently shaped items give
+    bit for bit what the per-map entry points give (same arithmetic, same reduction order)."""
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(77)
+    shapes = [(2, 64, 48, 32), (2, 16, 12, 128), (3, 8, 6, 256)]
+    n = len(shapes)
+    T = lambda *s: torch.randn(*s, generator=g)
+    ys = [T(*s).to(torch.bfloat16).to(DEV) for s in shapes]
+    rs = [T(*s).to(torch.bfloat16).to(DEV) for s in shapes]
+    dzs = [T(*s).to(torch.bfloat16).to(DEV) for s in shapes]
+    gam = [(torch.rand(s[3], generator=g) + 0.5).to(DEV) for s in shapes]
+    bet = [(T(s[3]) * 0.1).to(DEV) for s in shapes]
+
+    def run(grouped):
+        outs = []
+        mean = [torch.zeros(s[3], device=DEV) for s in shapes]
+        inv = [torch.zeros(s[3], device=DEV) for s in shapes]
+        rm = [torch.zeros(s[3], device=DEV) for s in shapes]
+        rv = [torch.ones(s[3], device=DEV) for s in shapes]
+        z = [torch.empty_like(y) for y in ys]
+        dy = [torch.empty_like(y) for y in ys]
+        dres = [torch.empty_like(y) for y in ys]
+        dg = [torch.zeros(s[3], device=DEV) for s in shapes]
+        db = [torch.zeros(s[3], device=DEV) for s in shapes]
+        ws = [torch.empty(lib.rsg_bn_workspace_bytes(s[3]), dtype=torch.uint8, device=DEV) for s in shapes]
+        px = [s[0] * s[1] * s[2] for s in shapes]
+        if grouped:
+            it = (hip.BnItem * n)()
+            for k in range(n):
+                it[k].y, it[k].out, it[k].residual = ys[k].data_ptr(), z[k].data_ptr(), rs[k].data_ptr()
+                it[k].gamma, it[k].beta, it[k].mean, it[k].invstd = gam[k].data_ptr(), bet[k].data_ptr(), mean[k].data_ptr(), inv[k].data_ptr()
+                it[k].running_mean, it[k].running_var, it[k].workspace = rm[k].data_ptr(), rv[k].data_ptr(), ws[k].data_ptr()
+                it[k].pixels, it[k].c, it[k].relu = px[k], shapes[k][3], 1
+            hip.check(lib.rsg_bn_forward_group(it, n, 0.1, 1e-5, BF, _stream()), "bn_forward_group")
+            for k in range(n):
+                it[k].dz, it[k].z, it[k].out, it[k].dres = dzs[k].data_ptr(), z[k].data_ptr(), dy[k].data_ptr(), dres[k].data_ptr()
+                it[k].dgamma, it[k].dbeta = dg[k].data_ptr(), db[k].data_ptr()
+            hip.check(lib.rsg_bn_backward_group(it, n, BF, _stream()), "bn_backward_group")
+        else:
+            for k in range(n):
+                Cc = shapes[k][3]
+                hip.check(lib.rsg_bn_stats(ys[k].data_ptr(), px[k], Cc, BF, ws[k].data_ptr(), mean[k].data_ptr(), inv[k].data_ptr(),
+                                           rm[k].data_ptr(), rv[k].data_ptr(), 0.1, 1e-5, _stream()))
+                hip.check(lib.rsg_bn_apply(ys[k].data_ptr(), mean[k].data_ptr(), inv[k].data_ptr(), gam[k].data_ptr(), bet[k].data_ptr(),
+                                           rs[k].data_ptr(), 1, z[k].data_ptr(), px[k], Cc, BF, _stream()))
+                hip.check(lib.rsg_bn_backward(dzs[k].data_ptr(), z[k].data_ptr(), ys[k].data_ptr(), mean[k].data_ptr(), inv[k].data_ptr(),
+                                              gam[k].data_ptr(), dy[k].data_ptr(), dres[k].data_ptr(), dg[k].data_ptr(), db[k].data_ptr(),
+                                              ws[k].data_ptr(), px[k], Cc, BF, _stream()))
+        torch.cuda.synchronize()
+        return mean + inv + rm + rv + z + dy + dres + dg + db
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
+    # weight gradients: 3x3 stride 1 at three widths
+    xs = [T(*s).to(torch.bfloat16).to(DEV) for s in shapes]
+    dws = [[torch.full((s[3], s[3], 3, 3), float("nan"), device=DEV) for s in shapes] for _ in range(2)]
+    wss = [torch.empty(lib.rsg_conv_wgrad_workspace_bytes(s[0], s[1], s[2], s[3], s[1], s[2], s[3], 3, 3, 1, 1), dtype=torch.uint8, device=DEV)
+           for s in shapes]
+    wi = (hip.WgradItem * n)()
+    for k, s in enumerate(shapes):
+        wi[k].x, wi[k].dy, wi[k].dw, wi[k].workspace = xs[k].data_ptr(), dzs[k].data_ptr(), dws[0][k].data_ptr(), wss[k].data_ptr()
+        wi[k].batch, wi[k].in_h, wi[k].in_w, wi[k].cin, wi[k].cin_pad = s[0], s[1], s[2], s[3], s[3]
+        wi[k].out_h, wi[k].out_w, wi[k].cout, wi[k].cout_pad, wi[k].kh, wi[k].kw, wi[k].stride, wi[k].pad = s[1], s[2], s[3], s[3], 3, 3, 1, 1
+    hip.check(lib.rsg_conv_wgrad_group(wi, n, BF, _stream()), "wgrad_group")
+    for k, s in enumerate(shapes):
+        hip.check(lib.rsg_conv_wgrad(xs[k].data_ptr(), dzs[k].data_ptr(), dws[1][k].data_ptr(), wss[k].data_ptr(), s[0], s[1], s[2], s[3], s[3],
+                                     s[1], s[2], s[3], s[3], 3, 3, 1, 1, BF, _stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(dws[0][k], dws[1][k]), k

@@ -221,7 +221,9 @@ def test_data_parallel_training_two_ranks_on_the_gpu():
     for it in range(3):
         total = torch.zeros_like(opt.flat_grad)
         for r in range(2):
-            model.load_state_dict(bn_state[r], strict=False)        # every replica keeps its own running statistics
+            live = model.state_dict()                                # every replica keeps its own running statistics
+            for k, v in bn_state[r].items():
+                live[k].copy_(v)
             out = model(x[r:r + 1].cuda())
             loss = crit(out, target[r:r + 1].cuda(), tw[r:r + 1].cuda())
             opt.zero_grad()
