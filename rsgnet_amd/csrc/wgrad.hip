@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradRedu
 struct WgradPlan { WgradArgs a; int lds, grid, ntaps; };
 
 static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int out_w, int cout_pad, int kh, int kw, int stride,
-                      int pad, WgradPlan& p) {
+                      int pad, WgradPlan& p, int target_wgs = 512) {
     memset(&p, 0, sizeof(p));
     if (!((kh == 3 && kw == 3 && pad == 1) || (kh == 1 && kw == 1 && pad == 0)) || (stride != 1 && stride != 2)) return 1;
     if (cin_pad % 8 || cout_pad % 8 || batch < 1) return 1;
@@ -266,7 +266,7 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
     // (the cross-wave add through LDS and a taps x 4 KB partial tile written and read back), so a slice should own
     // several chunks when the pairs alone already give the parallelism (256-channel maps: 64 pairs of 8x6 chunks)
     const int pairs = a.n_ot * a.n_it, chunks = batch * a.nbands;
-    a.nslices = max(1, min(chunks, ceil_div(512, pairs)));
+    a.nslices = max(1, min(chunks, ceil_div(target_wgs, pairs)));
     p.grid = pairs * a.nslices;
     return 0;
 }
@@ -318,7 +318,10 @@ extern "C" int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int3
         if (((uintptr_t)it.x | (uintptr_t)it.dy | (uintptr_t)it.workspace) & 15) RSG_FAIL("conv_wgrad_group: item %d: alignment", k);
         if (it.cin < 1 || it.cin > it.cin_pad || it.cout < 1 || it.cout > it.cout_pad) RSG_FAIL("conv_wgrad_group: item %d: channels", k);
         WgradPlan p;
-        if (wgrad_plan(it.batch, it.in_h, it.in_w, it.cin_pad, it.out_h, it.out_w, it.cout_pad, it.kh, it.kw, it.stride, it.pad, p))
+        // the group fills the chip together: fewer, longer slices per item (a quarter of the partial tiles to write,
+        // read back and add; the workspace of rsg_conv_wgrad_workspace_bytes is sized for the single launch's 512)
+        if (wgrad_plan(it.batch, it.in_h, it.in_w, it.cin_pad, it.out_h, it.out_w, it.cout_pad, it.kh, it.kw, it.stride, it.pad, p,
+                       max(128, 768 / n)))
             RSG_FAIL("conv_wgrad_group: item %d: unsupported geometry", k);
         if ((long long)it.batch * it.in_h * it.in_w * it.cin_pad * 2 >= (1LL << 31) || (long long)it.batch * it.out_h * it.out_w * it.cout_pad * 2 >= (1LL << 31))
             RSG_FAIL("conv_wgrad_group: item %d: map too large for 32-bit offsets", k);
