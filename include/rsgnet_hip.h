@@ -362,8 +362,10 @@ int rsg_upsample_nearest_backward(const void* grad_hi, void* grad_lo, int32_t ba
                                   int32_t c, int32_t shift, int32_t dtype, void* stream);
 /* out [batch, 2h, 2w, c] = in [batch, h, w, c] on the even positions, zeros elsewhere (data gradient of stride-2 convs) */
 int rsg_zero_insert2x(const void* in, void* out, int32_t batch, int32_t h, int32_t w, int32_t c, void* stream);
-/* out[c] = sum over batch and pixels of x [batch, c, hw] fp32 (bias gradient of the classifier conv) */
-int rsg_channel_sum_nchw_f32(const float* x, float* out, int32_t batch, int32_t c, int32_t hw, void* stream);
+/* out[c] = sum over batch and pixels of x [batch, c, hw] fp32 (bias gradient of the classifier conv); workspace:
+ * rsg_channel_sum_workspace_bytes(c) bytes, 8-byte aligned */
+size_t rsg_channel_sum_workspace_bytes(int32_t c);
+int rsg_channel_sum_nchw_f32(const float* x, float* out, void* workspace, int32_t batch, int32_t c, int32_t hw, void* stream);
 /* Weight gradient of nn.Conv2d (3x3 pad 1 or 1x1 pad 0, stride 1 or 2) on the matrix cores:
  *   dw[o][i][ky][kx] (fp32, nn.Conv2d layout, cout x cin real channels) = sum dy[b,r,c,o] * x[b, r*s+ky-p, c*s+kx-p, i]
  * x: [batch,in_h,in_w,cin_pad], dy: [batch,out_h,out_w,cout_pad] dense NHWC 16-bit (padding channels are ignored).
@@ -381,6 +383,8 @@ typedef struct rsg_wgrad_item {
     int32_t batch, in_h, in_w, cin, cin_pad, out_h, out_w, cout, cout_pad, kh, kw, stride, pad, reserved;
 } rsg_wgrad_item;
 int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int32_t dtype, void* stream);
+/* experiment switch (process-wide): 0 = every weight gradient in the one-tile-pair-per-workgroup form */
+void rsg_wgrad_set_quad(int32_t on);
 
 /* ---- crop producer ---------------------------------------------------------------
  * One person box per entry: `cv2.warpAffine(img, trans, (out_w, out_h), flags=INTER_LINEAR)` (constant border 0)

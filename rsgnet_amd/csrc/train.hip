@@ -340,12 +340,14 @@ extern "C" int rsg_zero_insert2x(const void* in, void* out, int32_t batch, int32
 }
 
 // Bias gradient of the classifier conv (pose_hrnet.py:326-332): out[c] = sum over batch and pixels of the fp32 NCHW
-// heat-map gradient.  One workgroup per channel, fixed order, fp64 combine.
-__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int batch, int C, int hw) {
+// heat-map gradient.  Workgroup (c, s) sums the planes b = s, s + S, ... of channel c (fixed order), the last-level sum
+// over the S segments runs in the second kernel, in segment order, in fp64.
+#define CSUM_SEGS 32
+__global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restrict__ x, double* __restrict__ part, int batch, int C, int hw) {
     __shared__ double red[256];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, seg = blockIdx.y;
     double s = 0.0;
-    for (int b = 0; b < batch; ++b) {
+    for (int b = seg; b < batch; b += CSUM_SEGS) {
         const float* p = x + ((long)b * C + c) * hw;
         float t = 0.f;
         for (int i = threadIdx.x; i < hw; i += 256) t += p[i];
@@ -357,12 +359,22 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(const float* __restric
         if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[c] = (float)red[0];
+    if (threadIdx.x == 0) part[c * CSUM_SEGS + seg] = red[0];
+}
+__global__ void __launch_bounds__(64) channel_sum_final_kernel(const double* __restrict__ part, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < CSUM_SEGS; ++k) s += part[c * CSUM_SEGS + k];
+    out[c] = (float)s;
 }
 
-extern "C" int rsg_channel_sum_nchw_f32(const float* x, float* out, int32_t batch, int32_t c, int32_t hw, void* stream) {
-    if (!x || !out || batch < 1 || c < 1 || hw < 1) RSG_FAIL("channel_sum: bad arguments");
-    RSG_LAUNCH(channel_sum_kernel, dim3(c), dim3(256), 0, (hipStream_t)stream, x, out, batch, c, hw);
+extern "C" size_t rsg_channel_sum_workspace_bytes(int32_t c) { return (size_t)c * CSUM_SEGS * sizeof(double); }
+
+extern "C" int rsg_channel_sum_nchw_f32(const float* x, float* out, void* workspace, int32_t batch, int32_t c, int32_t hw, void* stream) {
+    if (!x || !out || !workspace || batch < 1 || c < 1 || hw < 1) RSG_FAIL("channel_sum: bad arguments");
+    RSG_LAUNCH(channel_sum_kernel, dim3(c, CSUM_SEGS), dim3(256), 0, (hipStream_t)stream, x, (double*)workspace, batch, c, hw);
+    RSG_LAUNCH(channel_sum_final_kernel, dim3(ceil_div(c, 64)), dim3(64), 0, (hipStream_t)stream, (const double*)workspace, out, c);
     RSG_CHECK_LAUNCH("channel_sum");
     return 0;
 }

@@ -16,6 +16,7 @@
 // dW (fp32, nn.Conv2d layout): no atomics, bit-reproducible.
 #include "common.h"
 
+#define NLD 8            // staging loads in flight per thread
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -27,8 +28,10 @@ struct WgradArgs {
     int kh, kw, stride, pad;
     int n_ot, n_it, nslices;
     int RB, nbands;    // output rows per chunk, chunks per image
+    int nimg;          // > 1: a chunk is `nimg` whole images (small maps: 8x6 is 3 k-steps, too little between two barriers)
     int xrows, xcols;  // x tile: (RB-1)*stride + kh rows, Win + 2*pad columns
     int P16;           // pixels of a chunk, padded to a multiple of 16
+    int quad;          // 1: a workgroup owns a 2x2 block of tile pairs, one per wave (wgrad_quad_body)
 };
 
 template <class DT>
@@ -49,7 +52,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block, 
     const int ot = pair / a.n_it, it = pair - ot * a.n_it;
     char* const sdy = smem;                                   // [P16][64 B]
     char* const sx = smem + a.P16 * 64;                       // [xrows * xcols][64 B]
-    int* const soff = reinterpret_cast<int*>(sx + a.xrows * a.xcols * 64);   // [P16]: byte offset of a pixel's tap (0,0) in sx
+    int* const soff = reinterpret_cast<int*>(sx + a.nimg * a.xrows * a.xcols * 64);   // [P16]: byte offset of a pixel's tap (0,0) in sx
 
     // fragment geometry of this lane (see the header): 16-lane group g reads channels cb..cb+15, k rows kb..kb+7
     const int grp = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
@@ -62,42 +65,63 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int nchunks = a.B * a.nbands;
+    const int nchunks = a.nimg > 1 ? (a.B + a.nimg - 1) / a.nimg : a.B * a.nbands;
+    const int xtile = a.xrows * a.xcols, opix = a.Hout * a.Wout;
     for (int chunk = slice; chunk < nchunks; chunk += a.nslices) {
-        const int b = chunk / a.nbands, band = chunk - b * a.nbands;
+        const int b = a.nimg > 1 ? chunk * a.nimg : chunk / a.nbands, band = a.nimg > 1 ? 0 : chunk - b * a.nbands;
+        const int nim = a.nimg > 1 ? min(a.nimg, a.B - b) : 1;
         const int r0 = band * a.RB;                           // first output row of the chunk
         const int rows = min(a.RB, a.Hout - r0);
-        const int P = rows * a.Wout;                          // valid pixels
+        const int P = nim * rows * a.Wout;                    // valid pixels (whole images are contiguous in memory)
         __syncthreads();                                      // the previous chunk's reads are done
         // ---- dy tile: the band is one contiguous pixel range of the image
         {
+            // NLD loads in flight per thread, then the LDS writes (one load per iteration waited for its own latency)
             const char* src = a.dy + ((size_t)(b * a.Hout + r0) * a.Wout) * a.CoutP * 2 + ot * 64;
-            for (int i = tid; i < a.P16 * 4; i += 256) {
-                const int p = i >> 2, c4 = i & 3;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (p < P && ot * 32 + c4 * 8 < a.CoutP) v = *reinterpret_cast<const uint4*>(src + (size_t)p * a.CoutP * 2 + c4 * 16);
-                *reinterpret_cast<uint4*>(sdy + i * 16) = v;
+            for (int base = 0; base < a.P16 * 4; base += 256 * NLD) {
+                uint4 v[NLD];
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid, p = i >> 2, c4 = i & 3;
+                    v[j] = make_uint4(0, 0, 0, 0);
+                    if (i < a.P16 * 4 && p < P && ot * 32 + c4 * 8 < a.CoutP) v[j] = *reinterpret_cast<const uint4*>(src + (size_t)p * a.CoutP * 2 + c4 * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid;
+                    if (i < a.P16 * 4) *reinterpret_cast<uint4*>(sdy + i * 16) = v[j];
+                }
             }
         }
         // ---- x tile with its zero border
         {
             const int iy0 = r0 * a.stride - a.pad;
-            const int npix = a.xrows * a.xcols;
-            for (int i = tid; i < npix * 4; i += 256) {
-                const int p = i >> 2, c4 = i & 3;
-                const int ry = p / a.xcols, cx = p - ry * a.xcols;
-                const int iy = iy0 + ry, ix = cx - a.pad;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && it * 32 + c4 * 8 < a.CinP)
-                    v = *reinterpret_cast<const uint4*>(a.x + ((size_t)(b * a.Hin + iy) * a.Win + ix) * a.CinP * 2 + it * 64 + c4 * 16);
-                *reinterpret_cast<uint4*>(sx + i * 16) = v;
+            const int npix = nim * xtile;
+            for (int base = 0; base < npix * 4; base += 256 * NLD) {
+                uint4 v[NLD];
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid, p = i >> 2, c4 = i & 3;
+                    const int im = p / xtile, pr = p - im * xtile;
+                    const int ry = pr / a.xcols, cx = pr - ry * a.xcols;
+                    const int iy = iy0 + ry, ix = cx - a.pad;
+                    v[j] = make_uint4(0, 0, 0, 0);
+                    if (i < npix * 4 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && it * 32 + c4 * 8 < a.CinP)
+                        v[j] = *reinterpret_cast<const uint4*>(a.x + ((size_t)((b + im) * a.Hin + iy) * a.Win + ix) * a.CinP * 2 + it * 64 + c4 * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid;
+                    if (i < npix * 4) *reinterpret_cast<uint4*>(sx + i * 16) = v[j];
+                }
             }
         }
         for (int p = tid; p < a.P16; p += 256) {
             int o = 0;
             if (p < P) {
-                const int r = p / a.Wout, c = p - r * a.Wout;
-                o = ((r * a.stride) * a.xcols + c * a.stride) * 64;
+                const int im = a.nimg > 1 ? p / opix : 0, pr = p - im * opix;
+                const int r = pr / a.Wout, c = pr - r * a.Wout;
+                o = (im * xtile + (r * a.stride) * a.xcols + c * a.stride) * 64;
             }
             soff[p] = o;                                      // padded pixels: dy is zero there, any finite x will do
         }
@@ -155,10 +179,124 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block, 
     }
 }
 
+// Maps with at least 64 channels on both sides: a workgroup owns a 2x2 block of (cout tile, cin tile) pairs, ONE PAIR PER
+// WAVE.  The dy and x tiles are staged 64 channels wide once for all four pairs (the one-pair form stages the same 32-channel
+// slices in two workgroups each), every wave walks ALL k-steps of the chunk for its own pair, so there is no cross-wave add
+// through LDS and twice the MFMA work per staged byte.  Pixel pitch 144 B (64 channels + 16): the four rows of a transposed
+// read then start 36 banks apart.
+template <class DT, int NT>
+__device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int block, char* smem) {
+    constexpr int PSQ = 144;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq_i = (a.n_it + 1) >> 1;
+    const int quad = block / a.nslices, slice = block - quad * a.nslices;
+    const int oq = quad / nq_i, iq = quad - oq * nq_i;
+    const int ot = oq * 2 + (wave >> 1), it = iq * 2 + (wave & 1);
+    const bool active = ot < a.n_ot && it < a.n_it;          // wave-uniform
+    char* const sdy = smem;                                   // [P16][144 B]
+    char* const sx = smem + a.P16 * PSQ;                      // [xrows * xcols][144 B]
+    int* const soff = reinterpret_cast<int*>(sx + a.nimg * a.xrows * a.xcols * PSQ);
+    const int grp = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+    const int cb = 16 * (grp & 1), kb = 8 * (grp >> 1);
+    const int col_a = (cb + 4 * pp) * 2 + (wave >> 1) * 64, col_b = (cb + 4 * pp) * 2 + (wave & 1) * 64;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nchunks = a.nimg > 1 ? (a.B + a.nimg - 1) / a.nimg : a.B * a.nbands;
+    const int xtile = a.xrows * a.xcols, opix = a.Hout * a.Wout;
+    for (int chunk = slice; chunk < nchunks; chunk += a.nslices) {
+        const int b = a.nimg > 1 ? chunk * a.nimg : chunk / a.nbands, band = a.nimg > 1 ? 0 : chunk - b * a.nbands;
+        const int nim = a.nimg > 1 ? min(a.nimg, a.B - b) : 1;
+        const int r0 = band * a.RB;
+        const int rows = min(a.RB, a.Hout - r0);
+        const int P = nim * rows * a.Wout;
+        __syncthreads();
+        {
+            const char* src = a.dy + ((size_t)(b * a.Hout + r0) * a.Wout) * a.CoutP * 2 + oq * 128;
+            for (int base = 0; base < a.P16 * 8; base += 256 * NLD) {
+                uint4 v[NLD];
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                    v[j] = make_uint4(0, 0, 0, 0);
+                    if (i < a.P16 * 8 && p < P && oq * 64 + c8 * 8 < a.CoutP) v[j] = *reinterpret_cast<const uint4*>(src + (size_t)p * a.CoutP * 2 + c8 * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                    if (i < a.P16 * 8) *reinterpret_cast<uint4*>(sdy + p * PSQ + c8 * 16) = v[j];
+                }
+            }
+        }
+        {
+            const int iy0 = r0 * a.stride - a.pad;
+            const int npix = nim * xtile;
+            for (int base = 0; base < npix * 8; base += 256 * NLD) {
+                uint4 v[NLD];
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                    const int im = p / xtile, pr = p - im * xtile;
+                    const int ry = pr / a.xcols, cx = pr - ry * a.xcols;
+                    const int iy = iy0 + ry, ix = cx - a.pad;
+                    v[j] = make_uint4(0, 0, 0, 0);
+                    if (i < npix * 8 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win && iq * 64 + c8 * 8 < a.CinP)
+                        v[j] = *reinterpret_cast<const uint4*>(a.x + ((size_t)((b + im) * a.Hin + iy) * a.Win + ix) * a.CinP * 2 + iq * 128 + c8 * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                    if (i < npix * 8) *reinterpret_cast<uint4*>(sx + p * PSQ + c8 * 16) = v[j];
+                }
+            }
+        }
+        for (int p = tid; p < a.P16; p += 256) {
+            int o = 0;
+            if (p < P) {
+                const int im = a.nimg > 1 ? p / opix : 0, pr = p - im * opix;
+                const int r = pr / a.Wout, c = pr - r * a.Wout;
+                o = (im * xtile + (r * a.stride) * a.xcols + c * a.stride) * PSQ;
+            }
+            soff[p] = o;
+        }
+        __syncthreads();
+        const int ksteps = (P + 15) >> 4;
+        if (active) {
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int pix0 = ks * 16 + kb + q, pix1 = pix0 + 4;
+                const s16x4 a0 = tr_read(sdy, pix0 * PSQ + col_a), a1 = tr_read(sdy, pix1 * PSQ + col_a);
+                const s16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const int x0 = soff[pix0] + col_b, x1 = soff[pix1] + col_b;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    constexpr int KW = NT == 9 ? 3 : 1;
+                    const int toff = ((t / KW) * a.xcols + (t % KW)) * PSQ;
+                    const s16x4 b0 = tr_read(sx, x0 + toff), b1 = tr_read(sx, x1 + toff);
+                    const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[t] = wg_mfma<DT>(af, bf, acc[t]);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    float* dst = a.part + ((size_t)(ot * a.n_it + it) * a.nslices + slice) * NT * 1024;
+    const int col = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = acc[t][r];
+}
+
 template <class DT, int NT>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    wgrad_body<DT, NT>(a, blockIdx.x, smem);
+    if (a.quad) wgrad_quad_body<DT, NT>(a, blockIdx.x, smem);
+    else wgrad_body<DT, NT>(a, blockIdx.x, smem);
 }
 
 // Up to 4 independent weight gradients (the same conv position of a HighResolutionModule's branches) in one launch
@@ -179,7 +317,8 @@ __global__ void __launch_bounds__(256) wgrad_group_kernel(const WgradGroupArgs g
 #pragma unroll
     for (int k = 0; k < RSG_WGRAD_GROUP_MAX; ++k)
         if (k == idx) { a = g.a[k]; block = (int)blockIdx.x - g.first[k]; }
-    wgrad_body<DT, NT>(a, block, smem);
+    if (a.quad) wgrad_quad_body<DT, NT>(a, block, smem);
+    else wgrad_body<DT, NT>(a, block, smem);
 }
 
 // dW[o][i][t] = sum over slices of part[(ot, it)][slice][t][o % 32][i % 32], in a fixed order: a workgroup owns a
@@ -238,6 +377,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradRedu
 }
 
 struct WgradPlan { WgradArgs a; int lds, grid, ntaps; };
+static int g_wgrad_quad = 1;       // RSGNET_HIP_WGRAD_QUAD=0: the one-pair form everywhere (A/B)
 
 static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int out_w, int cout_pad, int kh, int kw, int stride,
                       int pad, WgradPlan& p, int target_wgs = 512) {
@@ -251,31 +391,45 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
     a.n_ot = ceil_div(cout_pad, 32); a.n_it = ceil_div(cin_pad, 32);
     a.xcols = in_w + 2 * pad;
     p.ntaps = kh * kw;
-    const int red_bytes = 2 * p.ntaps * 16 * 64 * 4;
+    a.quad = (a.n_ot >= 2 && a.n_it >= 2 && g_wgrad_quad) ? 1 : 0;
+    const int pitch = a.quad ? 144 : 64;
+    const int red_bytes = a.quad ? 0 : 2 * p.ntaps * 16 * 64 * 4;
     const int budget = 72 * 1024;                           // two workgroups per CU
     int rb = 0;
     for (int r = max(1, min(out_h, 512 / out_w)); r >= 1; --r) {
         const int p16 = round_up(r * out_w, 16), xr = (r - 1) * stride + kh;
-        if (p16 * 64 + xr * a.xcols * 64 + p16 * 4 <= budget) { rb = r; break; }
+        if (p16 * pitch + xr * a.xcols * pitch + p16 * 4 <= budget) { rb = r; break; }
     }
     if (!rb) return 1;
     a.RB = rb; a.nbands = ceil_div(out_h, rb);
-    a.P16 = round_up(rb * out_w, 16); a.xrows = (rb - 1) * stride + kh;
-    p.lds = max(a.P16 * 64 + a.xrows * a.xcols * 64 + a.P16 * 4, red_bytes);
-    // pixel slices per tile pair: enough workgroups to fill the chip (2 per CU), but every slice pays a fixed price
-    // (the cross-wave add through LDS and a taps x 4 KB partial tile written and read back), so a slice should own
-    // several chunks when the pairs alone already give the parallelism (256-channel maps: 64 pairs of 8x6 chunks)
-    const int pairs = a.n_ot * a.n_it, chunks = batch * a.nbands;
-    a.nslices = max(1, min(chunks, ceil_div(target_wgs, pairs)));
-    p.grid = pairs * a.nslices;
+    a.xrows = (rb - 1) * stride + kh;
+    a.nimg = 1;
+    if (a.nbands == 1) {                                    // small maps: several whole images per chunk
+        for (int n = min(batch, 512 / max(1, out_h * out_w)); n >= 2; --n) {
+            const int p16 = round_up(n * out_h * out_w, 16);
+            if (p16 * pitch + n * a.xrows * a.xcols * pitch + p16 * 4 <= budget) { a.nimg = n; break; }
+        }
+    }
+    a.P16 = round_up(a.nimg * rb * out_w, 16);
+    p.lds = max(a.P16 * pitch + a.nimg * a.xrows * a.xcols * pitch + a.P16 * 4, red_bytes);
+    // pixel slices per workgroup column (a tile pair, or a 2x2 block of pairs): enough workgroups to fill the chip (2 per
+    // CU), but every slice pays a fixed price (a taps x 4 KB partial tile per pair written and read back; the one-pair form
+    // also its cross-wave add through LDS), so a slice should own several chunks when the columns alone already give
+    // the parallelism (256-channel maps: 64 pairs of 8x6 chunks)
+    const int cols = a.quad ? ceil_div(a.n_ot, 2) * ceil_div(a.n_it, 2) : a.n_ot * a.n_it;
+    const int chunks = a.nimg > 1 ? ceil_div(batch, a.nimg) : batch * a.nbands;
+    a.nslices = max(1, min(chunks, ceil_div(target_wgs, cols)));
+    p.grid = cols * a.nslices;
     return 0;
 }
+
+extern "C" void rsg_wgrad_set_quad(int32_t on) { g_wgrad_quad = on ? 1 : 0; }
 
 extern "C" size_t rsg_conv_wgrad_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t cin_pad, int32_t out_h,
                                                  int32_t out_w, int32_t cout_pad, int32_t kh, int32_t kw, int32_t stride, int32_t pad) {
     WgradPlan p;
     if (wgrad_plan(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p)) return 0;
-    return (size_t)p.grid * p.ntaps * 1024 * sizeof(float);
+    return (size_t)p.a.n_ot * p.a.n_it * p.a.nslices * p.ntaps * 1024 * sizeof(float);
 }
 
 extern "C" int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, int32_t batch, int32_t in_h, int32_t in_w,

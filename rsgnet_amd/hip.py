@@ -140,10 +140,12 @@ SYMBOLS = {
     "rsg_add16": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
     "rsg_upsample_nearest_backward": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsg_zero_insert2x": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsg_channel_sum_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "rsg_channel_sum_workspace_bytes": (C.c_size_t, [_i]),
+    "rsg_channel_sum_nchw_f32": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsg_conv_wgrad_workspace_bytes": (C.c_size_t, [_i] * 11),
     "rsg_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "rsg_conv_wgrad_group": (C.c_int, [C.POINTER(WgradItem), _i, _i, _vp]),
+    "rsg_wgrad_set_quad": (None, [_i]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
@@ -176,6 +178,8 @@ def lib() -> C.CDLL:
                          ("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug"), ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual")):
             if os.environ.get(env):
                 l.rsg_tune(key, int(os.environ[env]))
+        if os.environ.get("RSGNET_HIP_WGRAD_QUAD"):
+            l.rsg_wgrad_set_quad(int(os.environ["RSGNET_HIP_WGRAD_QUAD"]))
         _lib = l
     return _lib
 

@@ -287,6 +287,9 @@ class TrainPlan:
         mean = torch.zeros(y.C, dtype=torch.float32, device=self.device)
         invstd = torch.zeros(y.C, dtype=torch.float32, device=self.device)
         lib, px, Cc = self.lib, y.pixels, y.C
+        if m.momentum is None or not m.track_running_stats or m.running_mean is None or not m.affine:
+            raise NotImplementedError(f"{name}: BatchNorm2d without momentum / running statistics / affine terms "
+                                      "(the reference builds every BatchNorm2d with momentum 0.1 and the defaults)")
         mom, eps = float(m.momentum), float(m.eps)
 
         ws = torch.empty(lib.rsg_bn_workspace_bytes(Cc), dtype=torch.uint8, device=self.device)   # own: BatchNorms may share a launch
@@ -457,8 +460,9 @@ class TrainPlan:
                 d16 = torch.zeros(B, x.H, x.W, 32, dtype=torch.bfloat16, device=self.device)
                 self._emit("bwd", name + ".dheat", lambda s, d16=d16, x=x: self._chk(
                     lib.rsg_nchw_f32_to_nhwc16(self.dheat.data_ptr(), d16.data_ptr(), B, J, x.H, x.W, 32, BF16, s), "dheat"))
-                self._emit("bwd", name + ".dbias", lambda s, fl=fl, x=x: self._chk(
-                    lib.rsg_channel_sum_nchw_f32(self.dheat.data_ptr(), self._grad_of(fl.bias).data_ptr(), B, J, x.H * x.W, s), "dbias"))
+                csw = torch.empty(lib.rsg_channel_sum_workspace_bytes(J), dtype=torch.uint8, device=self.device)
+                self._emit("bwd", name + ".dbias", lambda s, fl=fl, x=x, csw=csw: self._chk(
+                    lib.rsg_channel_sum_nchw_f32(self.dheat.data_ptr(), self._grad_of(fl.bias).data_ptr(), csw.data_ptr(), B, J, x.H * x.W, s), "dbias"))
                 self._wgrad(x.data, d16, fl.weight, x.H, x.W, x.C, x.C, x.H, x.W, J, 32, 1, 1, name)
                 self._dgrad(x, d16, fl.weight, 32, 1, 1, x.H, x.W, name)
             elif kind == "fuse":

@@ -248,7 +248,8 @@ def test_gradient_plumbing_kernels():
     x = torch.randn(3, 17, 64 * 48, generator=g)
     out = torch.empty(17, device=DEV)
     xd = x.to(DEV)
-    hip.check(lib.rsg_channel_sum_nchw_f32(xd.data_ptr(), out.data_ptr(), 3, 17, 64 * 48, _stream()))
+    csw = torch.empty(lib.rsg_channel_sum_workspace_bytes(17), dtype=torch.uint8, device=DEV)
+    hip.check(lib.rsg_channel_sum_nchw_f32(xd.data_ptr(), out.data_ptr(), csw.data_ptr(), 3, 17, 64 * 48, _stream()))
     torch.cuda.synchronize()
     assert (out.cpu().double() - x.double().sum((0, 2))).abs().max() < 1e-3
 
