@@ -315,7 +315,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     asm volatile("" ::"v"(pf));                           // the grouped launch's weight prefetch loads end here
     RSG_STAMP(2);
 
-    constexpr int NPF = (C >= 128) ? 9 : (C == 64 ? 4 : RSG_CHAIN_NPF32);   // ring depth; must divide KS (18, 36, 72, 144)
+    // ring depth; must divide KS (18, 36, 72, 144).  C = 128 with six pixel groups per wave has 6 x 128 = 768 cycles of
+    // MFMA per k-step: a 6-deep ring covers an L2 miss as well as 9 did with three groups, and frees 12 registers
+    constexpr int NPF = (C == 256) ? 9 : (C == 128 ? (NT >= 6 ? 6 : 9) : (C == 64 ? 4 : RSG_CHAIN_NPF32));
     static_assert(KS % NPF == 0, "prefetch ring must wrap at the layer boundary");
     uint4 aq[NPF];
     // block-input slots of this lane, through a buffer descriptor: uniform base in SGPRs, ONE address VGPR (the
@@ -597,8 +599,17 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
             chain_body<DT, 64, 2, 4, 6, false, std::is_same<DT, F16>::value ? RSG_CHAIN_HELD64 : 0>(g.a[i], bid, smem, pf);
             break;
         case 128:  // 16x12 maps: one image = 6 pixel groups over 2 wave columns; two images per workgroup = 12
-            if (g.a[i].dual) chain_body<DT, 128, 4, 2, 3, true>(g.a[i], bid, smem, pf);
-            else chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem, pf);
+            // fp16: FOUR waves (one per SIMD, six pixel groups each; waves 4-7 leave at once) -- half the weight-fragment
+            // loads, one wave per matrix pipe; same-visit A/B 1.774 -> 1.743 ms (profiles/r02m_ab_w4_c128.txt).  bf16
+            // (fp32 ReLU epilogue) does not fit six groups in 256 registers and keeps 8 waves x 3 groups.
+            if constexpr (std::is_same<DT, F16>::value) {
+                if (threadIdx.x >= 256) return;
+                if (g.a[i].dual) chain_body<DT, 128, 4, 1, 6, true>(g.a[i], bid, smem, pf);
+                else chain_body<DT, 128, 4, 1, 6>(g.a[i], bid, smem, pf);
+            } else {
+                if (g.a[i].dual) chain_body<DT, 128, 4, 2, 3, true>(g.a[i], bid, smem, pf);
+                else chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem, pf);
+            }
             break;
         case 256:   // NT follows the pixels a workgroup owns (1 image = 48 px = 2 groups, 2 images = 3 groups)
             if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) {
