@@ -31,6 +31,9 @@ class HipPoseModule(nn.Module):
         super().__init__()
         self._plans = {}
         self._train_plans = {}
+        #: callables(pending_parameters) the training backward pass calls after each of its segments
+        #: (rsgnet_amd.parallel.DataParallelStep starts the all-reduce of the finished tail of the gradient buffer)
+        self.grad_ready_hooks = []
 
     # -- plan lifecycle ---------------------------------------------------------------------
     def invalidate_plan(self) -> None:

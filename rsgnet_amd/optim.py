@@ -69,6 +69,13 @@ class FusedAdam(torch.optim.Optimizer):
         p, o = self._params[i], self._offsets[i]
         return flat[o:o + p.numel()].view_as(p)
 
+    def flat_offset_of(self, p: torch.nn.Parameter):
+        """Element offset of a parameter in the flat buffers (None for a frozen one)."""
+        m = getattr(self, "_offset_map", None)
+        if m is None:
+            m = self._offset_map = {id(q): o for q, o in zip(self._params, self._offsets)}
+        return m.get(id(p))
+
     @property
     def step_count(self) -> int:
         """Steps taken by the most-stepped parameter (all parameters, unless some had no gradient)."""

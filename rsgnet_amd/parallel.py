@@ -30,31 +30,54 @@ class FlatGradReducer:
         n = flat_grad.numel()
         # buckets from the END of the buffer: the last parameters get their gradients first in a backward pass
         self.buckets: List[torch.Tensor] = []
+        self.ranges: List[tuple] = []
         hi = n
         while hi > 0:
             lo = max(0, hi - per)
             self.buckets.append(flat_grad[lo:hi])
+            self.ranges.append((lo, hi))
             hi = lo
         self._stream = torch.cuda.Stream(flat_grad.device) if flat_grad.is_cuda else None
+        self._done = [False] * len(self.buckets)
 
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
-    def reduce(self):
-        if self.world == 1:
+    def begin(self):
+        """Start of a step: no bucket has been exchanged yet."""
+        self._done = [False] * len(self.buckets)
+
+    def _launch(self, idx: List[int]):
+        if not idx or self.world == 1:
+            for k in idx:
+                self._done[k] = True
             return
         if self._stream is None:                       # CPU tensors (gloo tests)
-            works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for b in self.buckets]
+            works = [dist.all_reduce(self.buckets[k], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for k in idx]
             for w in works:
                 w.wait()
-            return
-        cur = torch.cuda.current_stream(self.flat.device)
-        self._stream.wait_stream(cur)
-        with torch.cuda.stream(self._stream):
-            for b in self.buckets:
-                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
-        cur.wait_stream(self._stream)
+        else:
+            cur = torch.cuda.current_stream(self.flat.device)
+            self._stream.wait_stream(cur)              # the gradients of these buckets are final on the current stream
+            with torch.cuda.stream(self._stream):
+                for k in idx:
+                    dist.all_reduce(self.buckets[k], op=dist.ReduceOp.SUM, group=self.group)
+        for k in idx:
+            self._done[k] = True
+
+    def ready(self, lo_elem: int):
+        """Every gradient element at flat offset >= lo_elem is final (the backward pass has moved on to earlier
+        parameters): the buckets that lie wholly in that tail start their all-reduce now, on the side stream, under the
+        rest of the backward pass."""
+        self._launch([k for k, (lo, _hi) in enumerate(self.ranges) if lo >= lo_elem and not self._done[k]])
+
+    def reduce(self):
+        """Exchange whatever `ready` has not started yet; the current stream then waits for every bucket."""
+        self._launch([k for k in range(len(self.buckets)) if not self._done[k]])
+        if self._stream is not None and self.world > 1:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self._stream)
+        self._done = [False] * len(self.buckets)
 
 
 class DataParallelStep:
@@ -73,6 +96,21 @@ class DataParallelStep:
         if flat is not None and self.world > 1:
             self.reducer = FlatGradReducer(flat, bucket_bytes, group)
             optimizer.grad_scale = self.reducer.grad_scale
+            # overlap: the HIP backward pass (rsgnet_amd/train.py) reports after each of its segments which parameters
+            # have their final gradient; the flat buffer keeps parameters in forward order, so what is final is a tail
+            hooks = getattr(model, "grad_ready_hooks", None)
+            if hooks is not None and hasattr(optimizer, "flat_offset_of"):
+                hooks.clear()
+                hooks.append(self._on_grads_ready)
+
+    def _on_grads_ready(self, pending_params):
+        """`pending_params`: the parameters whose gradient is NOT final yet."""
+        hi = 0
+        for p in pending_params:
+            off = self.optimizer.flat_offset_of(p)
+            if off is not None:
+                hi = max(hi, off + p.numel())
+        self.reducer.ready(hi)
 
     def exchange(self):
         if self.world == 1:
@@ -93,6 +131,8 @@ class DataParallelStep:
         out = self.model(x)
         loss = self.criterion(out, target, target_weight)
         self.optimizer.zero_grad()
+        if self.reducer is not None:
+            self.reducer.begin()
         loss.backward()
         self.exchange()
         self.optimizer.step()

@@ -73,7 +73,7 @@ class TrainPlan:
         self._bn_momentum, self._bn_eps = 0.1, 1e-5
         self._params = [p for p in model.parameters() if p.requires_grad]
         self._sig: Optional[Tuple[int, ...]] = None
-        self._graphs: Optional[Tuple[torch.cuda.CUDAGraph, torch.cuda.CUDAGraph]] = None
+        self._graphs: Optional[tuple] = None         # (forward graph, [one graph per backward segment])
         self._warm = 0
         import os
         self.use_graph = os.environ.get("RSGNET_HIP_TRAIN_GRAPH", "1") != "0"
@@ -100,8 +100,8 @@ class TrainPlan:
     # HighResolutionModule) are recorded side by side and zipped position by position, so that the k-th BatchNorm of
     # every branch lands next to its siblings and the run becomes ONE grouped launch (rsg_bn_*_group): a replayed graph
     # pays ~3.2 us per kernel whatever its size, and most of these kernels are smaller than that
-    def _emit(self, which: str, name: str, fn: Callable[[int], None], gkind: Optional[str] = None, item=None):
-        rec = (name, fn, gkind, item)
+    def _emit(self, which: str, name: str, fn: Callable[[int], None], gkind: Optional[str] = None, item=None, params=()):
+        rec = (name, fn, gkind, item, tuple(params))    # params: the parameters whose gradient this launch finalises
         sink = self._sink.get(which)
         (sink if sink is not None else getattr(self, which)).append(rec)
 
@@ -146,14 +146,15 @@ class TrainPlan:
         """Runs of adjacent groupable launches of one kind -> one grouped launch each."""
         out, i = [], 0
         while i < len(recs):
-            name, fn, gkind, item = recs[i]
+            name, fn, gkind, item = recs[i][:4]
             j = i + 1
             if gkind is not None:
                 cap = 4 if gkind.startswith("wgrad") else {"conv": 12}.get(gkind, 8)
                 while j < len(recs) and recs[j][2] == gkind and j - i < cap:
                     j += 1
             if j - i >= 2:
-                out.append((f"{name}(+{j - i - 1})", self._group_launch(gkind, [r[3] for r in recs[i:j]]), None, None))
+                out.append((f"{name}(+{j - i - 1})", self._group_launch(gkind, [r[3] for r in recs[i:j]]), None, None,
+                            tuple(q for r in recs[i:j] for q in r[4])))
             else:
                 out.append(recs[i])
                 j = i + 1
@@ -462,7 +463,8 @@ class TrainPlan:
                     lib.rsg_nchw_f32_to_nhwc16(self.dheat.data_ptr(), d16.data_ptr(), B, J, x.H, x.W, 32, BF16, s), "dheat"))
                 csw = torch.empty(lib.rsg_channel_sum_workspace_bytes(J), dtype=torch.uint8, device=self.device)
                 self._emit("bwd", name + ".dbias", lambda s, fl=fl, x=x, csw=csw: self._chk(
-                    lib.rsg_channel_sum_nchw_f32(self.dheat.data_ptr(), self._grad_of(fl.bias).data_ptr(), csw.data_ptr(), B, J, x.H * x.W, s), "dbias"))
+                    lib.rsg_channel_sum_nchw_f32(self.dheat.data_ptr(), self._grad_of(fl.bias).data_ptr(), csw.data_ptr(), B, J, x.H * x.W, s), "dbias"),
+                    params=(fl.bias,))
                 self._wgrad(x.data, d16, fl.weight, x.H, x.W, x.C, x.C, x.H, x.W, J, 32, 1, 1, name)
                 self._dgrad(x, d16, fl.weight, 32, 1, 1, x.H, x.W, name)
             elif kind == "fuse":
@@ -503,7 +505,7 @@ class TrainPlan:
                                                   self._grad_of(m.weight).data_ptr(), self._grad_of(m.bias).data_ptr(),
                                                   ws.data_ptr(), px, Cc, BF16, s), "bn_backward")
 
-                self._emit("bwd", name, launch, "bn_bwd", item)
+                self._emit("bwd", name, launch, "bn_bwd", item, params=(m.weight, m.bias))
                 if dres is not None:
                     self._contribute(res, dres, False, name)
             elif kind == "conv":
@@ -515,6 +517,25 @@ class TrainPlan:
                     self._dgrad(x, y.grad, m.weight, O, k, stride, y.H, y.W, name)
         flush()
         self._sink["bwd"] = None
+        # Segments of the backward list for the data-parallel overlap: cut where the pass leaves stage 4 and stage 3 (the
+        # two stages hold 93 % of the parameters, and the flat gradient buffer keeps parameters in forward order, so
+        # what is final after a segment is a tail of that buffer).  After each segment the model's grad_ready_hooks
+        # are told which parameters are still pending.
+        def top(nm):
+            return nm.split(".")[0]
+        cuts = []
+        for k in range(1, len(self.bwd)):
+            a, b = top(self.bwd[k - 1][0]), top(self.bwd[k][0])
+            if a != b and a in ("stage4", "stage3") and b not in ("stage4", "stage3"):
+                cuts.append(k)
+        bounds = [0] + cuts + [len(self.bwd)]
+        self._bwd_segments = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if bounds[i] < bounds[i + 1]]
+        done = set()
+        self._pending_after = []
+        for lo, hi in self._bwd_segments:
+            for rec in self.bwd[lo:hi]:
+                done.update(id(q) for q in rec[4])
+            self._pending_after.append([q for q in self._params if id(q) not in done])
 
     def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, w: torch.nn.Parameter, H, W, cin, cin_pad, Ho, Wo, cout, cout_pad, k, stride, name):
         lib, B, pad = self.lib, self.batch, (k - 1) // 2
@@ -534,7 +555,7 @@ class TrainPlan:
             self._chk(lib.rsg_conv_wgrad(x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_lane_ws[lane].data_ptr(), B, H, W,
                                          cin, cin_pad, Ho, Wo, cout, cout_pad, k, k, stride, pad, BF16, s), name + ".wgrad")
 
-        self._emit("bwd", name + ".wgrad", launch, f"wgrad{k}", item)
+        self._emit("bwd", name + ".wgrad", launch, f"wgrad{k}", item, params=(w,))
 
     def _dgrad(self, x: T, dy: torch.Tensor, w: torch.nn.Parameter, dy_c: int, k: int, stride: int, Ho: int, Wo: int, name: str):
         """dx = conv_transpose(dy, w): a stride-1 conv of dy (stride 2: of dy spread onto the input grid with zeros
@@ -567,9 +588,10 @@ class TrainPlan:
             rec[1](s)
         torch._foreach_add_(self._nbt, 1)            # num_batches_tracked of every BatchNorm, one launch
 
-    def _run_backward(self):
+    def _run_backward(self, seg: Optional[int] = None):
         s = torch.cuda.current_stream(self.device).cuda_stream
-        for rec in self.bwd:
+        lo, hi = (0, len(self.bwd)) if seg is None else self._bwd_segments[seg]
+        for rec in self.bwd[lo:hi]:
             rec[1](s)
 
     def _prepare(self):
@@ -588,13 +610,15 @@ class TrainPlan:
         self.x_f32.copy_(x)
         if self.use_graph and self._graphs is None and self._warm >= 1:
             torch.cuda.synchronize(self.device)
-            gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            gf = torch.cuda.CUDAGraph()
+            gb = [torch.cuda.CUDAGraph() for _ in self._bwd_segments]
             nbt = [t.clone() for t in self._nbt]
             stats = [(m.running_mean.clone(), m.running_var.clone()) for m in self._bns]
             with torch.cuda.graph(gf):
                 self._run_forward()
-            with torch.cuda.graph(gb):
-                self._run_backward()
+            for k, g in enumerate(gb):
+                with torch.cuda.graph(g):
+                    self._run_backward(k)
             # capture does not execute, but be explicit that nothing observable moved
             for t, c in zip(self._nbt, nbt):
                 t.copy_(c)
@@ -610,10 +634,16 @@ class TrainPlan:
 
     def backward(self, dheat: torch.Tensor) -> None:
         self.dheat.copy_(dheat)
-        if self._graphs is not None:
-            self._graphs[1].replay()
-        else:
-            self._run_backward()
+        hooks = getattr(self.model, "grad_ready_hooks", ())
+        for k in range(len(self._bwd_segments)):
+            if self._graphs is not None:
+                self._graphs[1][k].replay()
+            else:
+                self._run_backward(k)
+            if k + 1 < len(self._bwd_segments):
+                for cb in hooks:                 # e.g. DataParallelStep: all-reduce the finished tail under the rest
+                    cb(self._pending_after[k])
+        if self._graphs is None:
             self._warm += 1
         self._publish_grads()
 

@@ -23,7 +23,18 @@ def _reducer_worker(rank, world, port, q):
     red = FlatGradReducer(g, bucket_bytes=1 << 20)
     red.reduce()
     want = torch.arange(n, dtype=torch.float32) * sum(r + 1 for r in range(world))
-    q.put((rank, bool(torch.equal(g, want)), len(red.buckets), red.grad_scale))
+    ok = bool(torch.equal(g, want))
+    # overlap protocol: the tail of the buffer is announced final first (its buckets go out at once), the rest at the
+    # end -- every bucket must be exchanged exactly once (a second all-reduce would double it)
+    g2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red2 = FlatGradReducer(g2, bucket_bytes=1 << 20)
+    red2.begin()
+    red2.ready(n // 2)
+    early = sum(red2._done)
+    red2.ready(n // 4)
+    red2.reduce()
+    ok = ok and bool(torch.equal(g2, want)) and 0 < early < len(red2.buckets) and not any(red2._done)
+    q.put((rank, ok, len(red.buckets), red.grad_scale))
     dist.destroy_process_group()
 
 
