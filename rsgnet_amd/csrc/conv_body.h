@@ -19,7 +19,7 @@ static __device__ unsigned long long* g_conv_stamps = nullptr;      // [blocks][
 #define RSG_CSTAMP(slot) do {} while (0)
 #endif
 
-template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false, int HEAD = 0>
+template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false, int HEAD = 0, bool NEXT = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, const int block_y, char* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KPT = CINB / 16;       // k-steps per filter tap
@@ -249,6 +249,125 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
         }
         __syncthreads();
         const int ntile2 = p.C2 / 32;
+        if constexpr (NEXT) {
+            // ---- pair + the NEXT Bottleneck's conv1 (pose_hrnet.py:85-87 of the following block): the block output is
+            // the 1x1 conv1's input pixel for pixel, so it never has to be read back.  The tail runs pixel-major -- a wave
+            // owns two pixel groups and walks all output-channel tiles of conv3 -- and each finished tile (after residual
+            // and ReLU, packed to 16 bits for the store) is at once the B operand of two k-steps of conv1: an accumulator
+            // tile has its column (pixel) on the lane and 16 consecutive channels in the registers, which is an MFMA B
+            // fragment when the weights are packed with the matching channel order (plan.py: within every 32 channels the
+            // k-step bit and the lane-half bit swap places).  One launch and 100 MB of reads less per Bottleneck.
+            static_assert(WM * WN == 4 && NP2 == 8, "four waves, two pixel groups each");
+            constexpr int KSN = 16;                            // k-steps of the next conv1: 256 input channels
+            int op[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = (wave + 4 * j) * 32 + n;
+                const int py = q / p.TW, px = q - py * p.TW;
+                const bool ok = q < p.TH * p.TW && y0 + py < p.Hout && x0 + px < p.Wout;
+                op[j] = ok ? (b * p.Hout + y0 + py) * p.Wout + x0 + px : -1;
+            }
+            f32x16 t1[2][2];                                    // [conv1 output tile][pixel group]
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float bn[16];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias3 + c * 32 + hh * 16 + r4 * 4);
+                    bn[r4 * 4 + 0] = bv.x; bn[r4 * 4 + 1] = bv.y; bn[r4 * 4 + 2] = bv.z; bn[r4 * 4 + 3] = bv.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t1[c][j][r] = bn[r];
+            }
+            for (int ct2 = 0; ct2 < ntile2; ++ct2) {
+                const int cb2 = ct2 * 32 + hh * 16;
+                uint4 a2[KS2], an[2][2];
+#pragma unroll
+                for (int k = 0; k < KS2; ++k) a2[k] = p.wpk2[((size_t)ct2 * KS2 + k) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) an[c][k] = p.wpk3[((size_t)c * KSN + 2 * ct2 + k) * 64 + lane];
+                uint4 rv[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    rv[j][0] = rv[j][1] = make_uint4(0, 0, 0, 0);
+                    if (p.res && op[j] >= 0) {
+                        const char* rp = p.res + ((size_t)op[j] * p.ldr + cb2) * 2;
+                        rv[j][0] = *reinterpret_cast<const uint4*>(rp);
+                        rv[j][1] = *reinterpret_cast<const uint4*>(rp + 16);
+                    }
+                }
+                float bias2[16];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias2 + cb2 + r4 * 4);
+                    bias2[r4 * 4 + 0] = bv.x; bias2[r4 * 4 + 1] = bv.y; bias2[r4 * 4 + 2] = bv.z; bias2[r4 * 4 + 3] = bv.w;
+                }
+                f32x16 acc2[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[j][r] = bias2[r];
+#pragma unroll
+                for (int k = 0; k < KS2; ++k) {
+                    const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, a2[k]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int q = (wave + 4 * j) * 32 + n;
+                        const uint4 bv = *reinterpret_cast<const uint4*>(smem + (q < p.TH * p.TW ? q : 0) * PS2 + k * 32 + hh * 16);
+                        acc2[j] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc2[j]);
+                    }
+                }
+                const bool relu2 = (p.relu >> (ct2 & 31)) & 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint4 o[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv[j][k]), f32x8);
+                        f32x8 f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = acc2[j][k * 8 + e] + rf[e];
+                            f[e] = relu2 ? fmaxf(v, 0.f) : v;
+                        }
+                        o[k] = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+                    }
+                    if (op[j] >= 0) {
+                        char* dst = p.out + ((size_t)op[j] * p.ldo + cb2) * 2;
+                        *reinterpret_cast<uint4*>(dst) = o[0];
+                        *reinterpret_cast<uint4*>(dst + 16) = o[1];
+                    }
+                    // the stored 16-bit values ARE conv1's input: registers 8k..8k+7 of this lane = channels
+                    // cb2 + 8k .. + 7 = the B fragment of k-step 2*ct2 + k under the permuted pack
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k)
+                            t1[c][j] = DT::mfma(__builtin_bit_cast(typename DT::vec8, an[c][k]), __builtin_bit_cast(typename DT::vec8, o[k]), t1[c][j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (op[j] < 0) continue;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    char* dst = p.out3 + ((size_t)op[j] * p.ldo3 + c * 32 + hh * 16) * 2;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        f32x8 f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f[e] = t1[c][j][k * 8 + e];
+                        *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, DT::relu_pack(f));
+                    }
+                }
+            }
+            RSG_CSTAMP(4);
+            return;
+        }
         // the pixel groups of the tile in two passes: half the accumulators, and the residual of a pass is requested
         // before its MFMAs so that it lands under them (3 workgroups per CU need <= 168 registers)
         constexpr int NPH = (NP2 + 1) / 2;

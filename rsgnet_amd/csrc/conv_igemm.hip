@@ -218,6 +218,7 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     a.nchunks = d->in_c / t.CINB;
     a.KS = a.nchunks * d->kh * d->kw * (t.CINB / 16);
     a.wpk2 = nullptr; a.bias2 = nullptr; a.C2 = 0;
+    a.wpk3 = nullptr; a.bias3 = nullptr; a.out3 = nullptr; a.ldo3 = 0;
     a.in0 = nullptr; a.wpk0 = nullptr; a.bias0 = nullptr; a.ldi0 = 0;
     grid = dim3(d->batch * t.tiles_y * t.tiles_x, cout_pad / (32 * t.WM));
     return 0;
@@ -227,6 +228,13 @@ template <class DT>
 __global__ void __launch_bounds__(256) conv_pair_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     conv_body<DT, 64, 3, 3, 2, 2, 3, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
+}
+
+// conv2 -> conv3 (+x, ReLU) -> the NEXT Bottleneck's conv1 (1x1 256 -> 64, ReLU), 256-pixel tiles (conv_body NEXT)
+template <class DT>
+__global__ void __launch_bounds__(256) conv_pair_next_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_body<DT, 64, 3, 3, 2, 2, 4, true, 0, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 
 // Whole Bottleneck (pose_hrnet.py:85-101) in one launch: conv1 1x1 (head, into LDS) -> conv2 3x3 -> conv3 1x1 + x.
@@ -243,7 +251,9 @@ int g_bottleneck_debug = 0;    // rsg_tune("bottleneck_debug", 1): timing experi
 static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t head_ld, const void* head_w,
                        const float* head_bias, const void* tail_w_packed, const float* tail_bias,
                        int32_t tail_out_c, const void* residual, int32_t res_ld, void* out16, int32_t out_ld,
-                       int32_t relu, void* stream) {
+                       int32_t relu, void* stream, const void* next_w = nullptr, const float* next_bias = nullptr,
+                       void* next_out = nullptr, int32_t next_ld = 0) {
+    const int tile_px = next_w ? 256 : 192;             // pixels per workgroup: 2 x 2 waves x NT (3 or 4) groups of 32
     if (!inner || !tail_w_packed || !tail_bias || !out16) RSG_FAIL("conv_pair: null pointer");
     if (inner->kh != 3 || inner->kw != 3 || inner->stride != 1 || inner->out_c != 64 || inner->in_c % 64 ||
         inner->up != 1 || inner->out_nchw_f32)
@@ -262,18 +272,18 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
         static const int tws[] = {96, 64, 48, 32, 24, 16, 12, 8};
         for (int tw : tws) {
             if (tw > d.out_w) tw = d.out_w;
-            int th = 192 / tw;
+            int th = tile_px / tw;
             if (th > d.out_h) th = d.out_h;
             if (th < 1) continue;
             const int tih = th + 2, tiw = tw + 2;
             const int rp = tiw * 144 + ((((tw * 144) % 256) - (tiw * 144)) % 256 + 256) % 256;
             if (tih * rp > g_conv_lds_limit) continue;
-            const double use = (double)d.out_h * d.out_w / ((double)ceil_div(d.out_h, th) * ceil_div(d.out_w, tw) * 192);
+            const double use = (double)d.out_h * d.out_w / ((double)ceil_div(d.out_h, th) * ceil_div(d.out_w, tw) * tile_px);
             if (use > best) { best = use; best_h = th; best_w = tw; }
         }
         if (!best_h) RSG_FAIL("conv_pair: no tile fits");
     }
-    d.tile_hint = 2 | (3 << 4) | (best_h << 8) | (best_w << 16);
+    d.tile_hint = 2 | ((next_w ? 4 : 3) << 4) | (best_h << 8) | (best_w << 16);
     ConvArgs a;
     TilePlan t;
     dim3 grid;
@@ -283,6 +293,16 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
     a.relu = relu ? -1 : 0; a.Cout = tail_out_c; a.CoutStore = tail_out_c;
     a.wpk2 = (const uint4*)tail_w_packed; a.bias2 = tail_bias; a.C2 = tail_out_c;
     if (t.lds < t.TH * t.TW * 144) t.lds = t.TH * t.TW * 144;
+    if (next_w) {
+        if (tail_out_c != 256 || !next_bias || !next_out || next_ld < 64 || next_ld % 8 ||
+            (((uintptr_t)next_w | (uintptr_t)next_bias | (uintptr_t)next_out) & 15))
+            RSG_FAIL("conv_pair_next: needs a 256-channel tail, 16-byte aligned next_* pointers and next_ld >= 64");
+        a.wpk3 = (const uint4*)next_w; a.bias3 = next_bias; a.out3 = (char*)next_out; a.ldo3 = next_ld;
+        if (inner->dtype == RSG_BF16) RSG_LAUNCH(conv_pair_next_kernel<BF16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+        else RSG_LAUNCH(conv_pair_next_kernel<F16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+        RSG_CHECK_LAUNCH("conv_pair_next");
+        return 0;
+    }
     if (head_x) {
         a.in0 = (const char*)head_x; a.ldi0 = head_ld; a.wpk0 = (const uint4*)head_w; a.bias0 = head_bias;
         if (g_bottleneck_debug & 1) a.res = nullptr;
@@ -307,6 +327,18 @@ extern "C" int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_pack
                              int32_t relu, void* stream) {
     return pair_launch(inner, nullptr, 0, nullptr, nullptr, tail_w_packed, tail_bias, tail_out_c, residual, res_ld,
                        out16, out_ld, relu, stream);
+}
+
+// rsg_conv_pair + the following Bottleneck's conv1 (1x1, 256 -> 64, BatchNorm folded, ReLU) in the same launch; next_w_packed
+// must be packed from conv1's weight with its INPUT channels permuted: packed channel l = source channel
+// rsg_conv_pair_next_perm(l) (the order in which an accumulator tile serves as the next MFMA's B operand).
+extern "C" int32_t rsg_conv_pair_next_perm(int32_t l) { return (l & ~0x18) | (((l >> 3) & 1) << 4) | (((l >> 4) & 1) << 3); }
+extern "C" int rsg_conv_pair_next(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias,
+                                  const void* residual, int32_t res_ld, void* out16, int32_t out_ld, const void* next_w_packed,
+                                  const float* next_bias, void* next_out16, int32_t next_out_ld, void* stream) {
+    if (!next_w_packed) RSG_FAIL("conv_pair_next: null pointer");
+    return pair_launch(inner, nullptr, 0, nullptr, nullptr, tail_w_packed, tail_bias, 256, residual, res_ld, out16, out_ld, 1,
+                       stream, next_w_packed, next_bias, next_out16, next_out_ld);
 }
 
 // logical input channel l of the head's packed weights <-> channel of x (see conv_body HEAD)

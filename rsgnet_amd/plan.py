@@ -287,20 +287,32 @@ class Plan:
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
 
-    def conv_pair(self, x: VT, conv_a, bn_a, conv_b, bn_b, residual: Optional[VT], name="") -> VT:
+    def conv_pair(self, x: VT, conv_a, bn_a, conv_b, bn_b, residual: Optional[VT], name="", next_unit=None):
         """Record Bottleneck conv2 (3x3, 64 outputs, BN, ReLU) + conv3 (1x1, BN, + residual, ReLU) as ONE launch
-        (rsg_conv_pair): the 64-channel map between them stays in LDS."""
+        (rsg_conv_pair): the 64-channel map between them stays in LDS.  next_unit = (conv1, bn1) of the FOLLOWING
+        Bottleneck: its 1x1 conv runs in the same launch on the block output (rsg_conv_pair_next) and the call returns
+        (block output, that conv1's 64-channel output)."""
         sa, ha = self.bn_fold(bn_a)
         wpa, boa, Ia, Oa = self.pack_conv(conv_a.weight, sa, ha, conv_a.bias)
         sb, hb = self.bn_fold(bn_b)
         wpb, bob, Ib, Ob = self.pack_conv(conv_b.weight, sb, hb, conv_b.bias)
         out = self.new(x.H, x.W, _round_up(Ob, 32), name=name)
-        self._record(dict(kind="conv_pair", x=x, wp=wpa, bias=boa, wp2=wpb, bias2=bob, res=residual, out=out,
-                          out_f32=None, I=self.lib.rsg_conv_padded_cin(Ia), O=Oa, O2=Ob, kh=3, kw=3, stride=1, pad=(1, 1),
-                          up=(1, 0, 0), out_hw=(x.H, x.W), phys_hw=(x.H, x.W), relu=True, name=name),
-                     [x, residual], [out])
+        rec = dict(kind="conv_pair", x=x, wp=wpa, bias=boa, wp2=wpb, bias2=bob, res=residual, out=out,
+                   out_f32=None, I=self.lib.rsg_conv_padded_cin(Ia), O=Oa, O2=Ob, kh=3, kw=3, stride=1, pad=(1, 1),
+                   up=(1, 0, 0), out_hw=(x.H, x.W), phys_hw=(x.H, x.W), relu=True, name=name)
         self.flops += 2 * self.batch * x.H * x.W * (Oa * Ia * 9 + Ob * Ib)
-        return out
+        if next_unit is None:
+            self._record(rec, [x, residual], [out])
+            return out
+        conv_n, bn_n = next_unit
+        perm = [self.lib.rsg_conv_pair_next_perm(l) for l in range(Ob)]
+        sn, hn = self.bn_fold(bn_n)
+        wpn, bon, In, On = self.pack_conv(conv_n.weight.detach().float().cpu()[:, perm].contiguous(), sn, hn, conv_n.bias)
+        t_next = self.new(x.H, x.W, On, name=name + "+next.conv1")
+        rec.update(wp3=wpn, bias3=bon, out3=t_next, O3=On)
+        self._record(rec, [x, residual], [out, t_next])
+        self.flops += 2 * self.batch * x.H * x.W * On * In
+        return out, t_next
 
     def bottleneck(self, x: VT, blk, name="") -> VT:
         """Record a whole Bottleneck without downsample branch (pose_hrnet.py:85-101) as ONE launch
@@ -581,7 +593,15 @@ class Plan:
         args = (C.byref(d), r["wp2"].data_ptr(), r["bias2"].data_ptr(), r["O2"], res.ptr() if res is not None else None,
                 res.ld if res is not None else 0, out.ptr(), out.ld, 1)
         fn, nm = self.lib.rsg_conv_pair, r["name"]
-        self.conv_log.append(dict(name=nm, cin=r["I"], cout=r["O2"], k=3, s=1, hw=r["out_hw"], pair=True))
+        entry = dict(name=nm, cin=r["I"], cout=r["O2"], k=3, s=1, hw=r["out_hw"], pair=True)
+        if r.get("out3") is not None:          # + the next Bottleneck's conv1 in the same launch
+            t3 = r["out3"]
+            fn = self.lib.rsg_conv_pair_next
+            args = (C.byref(d), r["wp2"].data_ptr(), r["bias2"].data_ptr(), res.ptr() if res is not None else None,
+                    res.ld if res is not None else 0, out.ptr(), out.ld, r["wp3"].data_ptr(), r["bias3"].data_ptr(), t3.ptr(), t3.ld)
+            entry = dict(name=nm, flops=float(2 * self.batch * r["out_hw"][0] * r["out_hw"][1] *
+                                             (r["I"] * 64 * 9 + 64 * r["O2"] + r["O2"] * r["O3"])))
+        self.conv_log.append(entry)
 
         def launch(stream):
             rc = fn(*args, stream)
@@ -1040,6 +1060,14 @@ class _BackboneMixin:
     def _unit(self: Plan, x: VT, conv: nn.Conv2d, bn, **kw) -> VT:
         return self.conv(x, conv.weight, bn, conv.bias, stride=conv.stride[0], **kw)
 
+    @staticmethod
+    def _plain_bottleneck(blk) -> bool:
+        return hasattr(blk, "conv3") and blk.downsample is None and blk.conv1.kernel_size == (1, 1) and \
+            blk.conv1.stride == (1, 1) and blk.conv1.in_channels == 256 and blk.conv1.out_channels == 64 and \
+            blk.conv1.bias is None and blk.conv2.kernel_size == (3, 3) and blk.conv2.stride == (1, 1) and \
+            blk.conv2.in_channels == 64 and blk.conv2.out_channels == 64 and blk.conv3.kernel_size == (1, 1) and \
+            blk.conv3.out_channels == 256
+
     def _residual_block(self: Plan, x: VT, blk, name: str) -> VT:
         """BasicBlock / Bottleneck (pose_hrnet.py:30-101)."""
         res = x
@@ -1271,8 +1299,27 @@ class _BackboneMixin:
         else:
             x = self.stem_to(m, None) if x is None else self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
             rest, k0 = list(m.layer1), 0
-        for k, blk in enumerate(rest, k0):
-            x = self._residual_block(x, blk, f"layer1.{k}")
+        # runs of plain Bottlenecks: each block's launch also computes the next block's conv1 (RSGNET_HIP_PAIR_NEXT=0: off)
+        k = 0
+        use_next = os.environ.get("RSGNET_HIP_PAIR_NEXT", "1") != "0" and os.environ.get("RSGNET_HIP_PAIR", "1") != "0" \
+            and os.environ.get("RSGNET_HIP_BOTTLENECK", "0") != "1"
+        while k < len(rest):
+            run = []
+            while use_next and k + len(run) < len(rest) and self._plain_bottleneck(rest[k + len(run)]) and x.C == 256 and x.coff == 0:
+                rest[k + len(run)]._rsg_name = f"layer1.{k0 + k + len(run)}"
+                run.append(rest[k + len(run)])
+            if len(run) >= 2:
+                t = self._unit(x, run[0].conv1, run[0].bn1, relu=True, name=f"{run[0]._rsg_name}.conv1")
+                for j, blk in enumerate(run):
+                    if j + 1 < len(run):
+                        x, t = self.conv_pair(t, blk.conv2, blk.bn2, blk.conv3, blk.bn3, x,
+                                              name=f"{blk._rsg_name}.conv2+conv3+next.conv1", next_unit=(run[j + 1].conv1, run[j + 1].bn1))
+                    else:
+                        x = self.conv_pair(t, blk.conv2, blk.bn2, blk.conv3, blk.bn3, x, name=f"{blk._rsg_name}.conv2+conv3")
+                k += len(run)
+            else:
+                x = self._residual_block(x, rest[k], f"layer1.{k0 + k}")
+                k += 1
         ys = [x]
         for s in (2, 3, 4):
             trans = getattr(m, f"transition{s - 1}")

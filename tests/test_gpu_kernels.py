@@ -458,6 +458,64 @@ def test_conv_pair_equals_two_convs(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 48), (3, 13, 9), (1, 96, 72), (1, 5, 70)], ids=str)
+def test_conv_pair_next_equals_pair_plus_conv1(shape):
+    """rsg_conv_pair_next (conv2 -> conv3 + x -> the NEXT Bottleneck's conv1 in one launch, the finished accumulator tiles
+    as conv1's B operand) against rsg_conv_pair followed by rsg_conv_igemm: the 256-channel block output is bit-identical;
+    conv1's output sums its 256 input channels in another order (tile by tile, the lane-half and k-step bits swapped), so
+    it agrees to fp32 summation noise rounded to 16 bits."""
+    B, H, W = shape
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(7 * H + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w1 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    s1, h1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    s2, h2 = torch.rand(256, generator=g) * 0.4 + 0.1, torch.randn(256, generator=g) * 0.1
+    w3 = torch.randn(64, 256, 1, 1, generator=g) * (2.0 / 256) ** 0.5
+    s3, h3 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    res = torch.randn(B, 256, H, W, generator=g)
+    mid, _ = run_conv(x, w1, s1, h1, relu=True)
+    want, _ = run_conv(mid, w2, s2, h2, relu=True, residual=res)
+    want_t, _ = run_conv(want, w3, s3, h3, relu=True)
+
+    def pack(w, s, h):
+        O, I, kh, kw = w.shape
+        wp = np.zeros(lib.rsg_conv_packed_bytes(I, O, kh, kw), np.uint8)
+        bo = np.zeros(O, np.float32)
+        hip.check(lib.rsg_pack_conv_weights_host(np.ascontiguousarray(w.numpy()).ctypes.data, s.numpy().ctypes.data,
+                                                 h.numpy().ctypes.data, None, I, O, kh, kw, 0, wp.ctypes.data, bo.ctypes.data))
+        return torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+
+    perm = [lib.rsg_conv_pair_next_perm(l) for l in range(256)]
+    assert sorted(perm) == list(range(256))
+    wp1, b1 = pack(w1, s1, h1)
+    wp2, b2 = pack(w2, s2, h2)
+    wp3, b3 = pack(w3[:, perm].contiguous(), s3, h3)
+    xin = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    rin = res.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    out = torch.full((B, H, W, 256), float("nan"), dtype=torch.float16, device=DEV)
+    tn = torch.full((B, H, W, 64), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.ConvDesc()
+    d.inp, d.w_packed, d.bias = xin.data_ptr(), wp1.data_ptr(), b1.data_ptr()
+    d.out16 = out.data_ptr()
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, H, W, 64, 64
+    d.out_h, d.out_w, d.out_c, d.out_ld = H, W, 64, 64
+    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = 3, 3, 1, 1, 1
+    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, H, W
+    d.relu, d.dtype = 1, 0
+    hip.check(lib.rsg_conv_pair_next(C.byref(d), wp2.data_ptr(), b2.data_ptr(), rin.data_ptr(), 256, out.data_ptr(), 256,
+                                     wp3.data_ptr(), b3.data_ptr(), tn.data_ptr(), 64, _stream()), "conv_pair_next")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    got_t = tn.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all() and torch.isfinite(got_t).all()
+    assert torch.equal(got, want)
+    err = (got_t - want_t).abs().max().item()
+    assert err <= 2 ** -9 * want_t.abs().max().item(), (err, want_t.abs().max().item())
+    assert (got_t != want_t).float().mean().item() < 0.05           # and only the odd last bit at that
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 48), (3, 13, 9), (1, 96, 72), (1, 5, 70)], ids=str)
 def test_bottleneck_fused_equals_three_convs(shape):
     """rsg_bottleneck_fused (conv1 1x1 evaluated per tile into LDS -> conv2 3x3 -> conv3 1x1 + x, one launch) against
     the three rsg_conv_igemm launches.  The head sums its 256 input channels in a different order, so the 16-bit
