@@ -92,11 +92,14 @@ int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_packed, const f
  * of the following block: 1x1 256 -> 64, BatchNorm folded, ReLU) on the block output it has just produced: the finished
  * accumulator tiles are the B operand of conv1's MFMAs, so the 256-channel map is not read back.  next_w_packed: conv1's
  * weights packed by rsg_pack_conv_weights_host AFTER permuting its input channels, packed channel l = source channel
- * rsg_conv_pair_next_perm(l); next_out16: [batch,h,w] pixels of 64 channels (stride next_out_ld). */
+ * rsg_conv_pair_next_perm(l); next_out16: [batch,h,w] pixels of 64 channels (stride next_out_ld).
+ * cat_x != NULL: the FIRST Bottleneck, whose residual is projected (pose_hrnet.py:93-101 with `downsample`): the tail is a
+ * 1x1 conv over the channel concat [conv2 output | block input x] (tail_w_packed packed with cin = 128, weights
+ * [s3*W3 | sd*Wd]); cat_x: the 64-channel block input (pixel stride cat_ld), residual must be NULL. */
 int32_t rsg_conv_pair_next_perm(int32_t l);
 int rsg_conv_pair_next(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias, const void* residual,
                        int32_t res_ld, void* out16, int32_t out_ld, const void* next_w_packed, const float* next_bias,
-                       void* next_out16, int32_t next_out_ld, void* stream);
+                       void* next_out16, int32_t next_out_ld, const void* cat_x, int32_t cat_ld, void* stream);
 /* A whole Bottleneck without downsample branch (pose_hrnet.py:85-101: conv1 1x1 256->64, conv2 3x3, conv3 1x1
  * 64->256, each + BatchNorm, + x, ReLU) in ONE launch: conv1 is evaluated per tile (with its one-pixel halo) straight
  * into LDS, so neither 64-channel map ever reaches HBM.  x: 256-channel NHWC map (pixel stride x_ld elements), also

@@ -25,17 +25,24 @@ struct ConvArgs {
     const uint4* wpk2;
     const float* bias2;
     int C2;          // output channels of the tail (multiple of 32)
-    // ... and the NEXT block's conv1 on the tail's output (conv_body<..., NEXT>, rsg_conv_pair_next): 256 -> 64, ReLU
-    const uint4* wpk3;      // packed with the accumulator-as-operand channel order (rsg_conv_pair_next_perm)
-    const float* bias3;
-    char* out3;
-    int ldo3;
+
     // fused 1x1 head (conv_body<..., HEAD=true>, rsg_bottleneck_fused): the conv's 64-channel input tile is not read
     // from `in` but computed in place, ReLU(conv1x1(in0) + bias0), from a 256-channel map (Bottleneck conv1)
     const char* in0;
     const uint4* wpk0;      // packed with the head's channel permutation (rsg_bottleneck_head_perm)
     const float* bias0;
     int ldi0;
+};
+
+// rsg_conv_pair_next only (kept out of ConvArgs: twelve of those travel as ONE kernel argument in group.hip)
+struct ConvNextArgs : ConvArgs {
+    // the NEXT block's conv1 on the tail's output (conv_body<..., NEXT>): 256 -> 64, ReLU
+    const uint4* wpk3;      // packed with the accumulator-as-operand channel order (rsg_conv_pair_next_perm)
+    const float* bias3;
+    char* out3;
+    int ldo3;
+    const char* in2;        // KCAT: the block input x (64 channels per pixel, stride ldi2), second half of the tail's K
+    int ldi2;
 };
 
 struct TilePlan {

@@ -19,8 +19,9 @@ static __device__ unsigned long long* g_conv_stamps = nullptr;      // [blocks][
 #define RSG_CSTAMP(slot) do {} while (0)
 #endif
 
-template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false, int HEAD = 0, bool NEXT = false>
-__device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, const int block_y, char* smem) {
+template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false, int HEAD = 0, bool NEXT = false, bool KCAT = false,
+          class ARGS = ConvArgs>
+__device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, const int block_y, char* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KPT = CINB / 16;       // k-steps per filter tap
     constexpr int NTAPS = TAPH * TAPW;
@@ -259,6 +260,25 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
             // k-step bit and the lane-half bit swap places).  One launch and 100 MB of reads less per Bottleneck.
             static_assert(WM * WN == 4 && NP2 == 8, "four waves, two pixel groups each");
             constexpr int KSN = 16;                            // k-steps of the next conv1: 256 input channels
+            // KCAT (layer1.0, pose_hrnet.py:93-101 with its downsample branch): the tail is a 1x1 conv over the channel
+            // concat [conv2 output | block input x] with weights [s3*W3 | sd*Wd] -- conv3 and the projected residual in
+            // one contraction (K = 128).  The second half of K comes from the tile's own pixels of x, staged behind the
+            // conv2 image; there is no residual operand.
+            constexpr int KSE = KCAT ? 2 * KS2 : KS2;
+            char* const sx2 = smem + NP2 * 32 * PS2;
+            if constexpr (KCAT) {
+                constexpr int CH = C1 / 8;                     // 16-byte chunks per pixel of x
+                uint4 v[CH];
+                const int q = tid;                             // 256 threads, 256 pixels: one pixel each
+                const int py = q / p.TW, px = q - py * p.TW;
+                const bool ok = q < p.TH * p.TW && y0 + py < p.Hout && x0 + px < p.Wout;
+                const char* src = p.in2 + ((size_t)((b * p.Hout + y0 + py) * p.Wout + x0 + px) * p.ldi2) * 2;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) v[c] = ok ? *reinterpret_cast<const uint4*>(src + c * 16) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) *reinterpret_cast<uint4*>(sx2 + q * PS2 + c * 16) = v[c];
+                __syncthreads();
+            }
             int op[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -283,9 +303,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
             }
             for (int ct2 = 0; ct2 < ntile2; ++ct2) {
                 const int cb2 = ct2 * 32 + hh * 16;
-                uint4 a2[KS2], an[2][2];
+                uint4 a2[KSE], an[2][2];
 #pragma unroll
-                for (int k = 0; k < KS2; ++k) a2[k] = p.wpk2[((size_t)ct2 * KS2 + k) * 64 + lane];
+                for (int k = 0; k < KSE; ++k) a2[k] = p.wpk2[((size_t)ct2 * KSE + k) * 64 + lane];
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -312,12 +332,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int block_x, 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc2[j][r] = bias2[r];
 #pragma unroll
-                for (int k = 0; k < KS2; ++k) {
+                for (int k = 0; k < KSE; ++k) {
                     const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, a2[k]);
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int q = (wave + 4 * j) * 32 + n;
-                        const uint4 bv = *reinterpret_cast<const uint4*>(smem + (q < p.TH * p.TW ? q : 0) * PS2 + k * 32 + hh * 16);
+                        const char* img = k < KS2 ? smem : sx2;
+                        const uint4 bv = *reinterpret_cast<const uint4*>(img + (q < p.TH * p.TW ? q : 0) * PS2 + (k % KS2) * 32 + hh * 16);
                         acc2[j] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bv), acc2[j]);
                     }
                 }

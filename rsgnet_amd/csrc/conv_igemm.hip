@@ -218,7 +218,7 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     a.nchunks = d->in_c / t.CINB;
     a.KS = a.nchunks * d->kh * d->kw * (t.CINB / 16);
     a.wpk2 = nullptr; a.bias2 = nullptr; a.C2 = 0;
-    a.wpk3 = nullptr; a.bias3 = nullptr; a.out3 = nullptr; a.ldo3 = 0;
+
     a.in0 = nullptr; a.wpk0 = nullptr; a.bias0 = nullptr; a.ldi0 = 0;
     grid = dim3(d->batch * t.tiles_y * t.tiles_x, cout_pad / (32 * t.WM));
     return 0;
@@ -232,9 +232,16 @@ __global__ void __launch_bounds__(256) conv_pair_kernel(const ConvArgs p) {
 
 // conv2 -> conv3 (+x, ReLU) -> the NEXT Bottleneck's conv1 (1x1 256 -> 64, ReLU), 256-pixel tiles (conv_body NEXT)
 template <class DT>
-__global__ void __launch_bounds__(256) conv_pair_next_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(256) conv_pair_next_kernel(const ConvNextArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     conv_body<DT, 64, 3, 3, 2, 2, 4, true, 0, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
+}
+
+// ... with the tail's K = 128: [conv2 output | block input] (the first Bottleneck's conv3 + projected residual in one conv)
+template <class DT>
+__global__ void __launch_bounds__(256) conv_pair_next_cat_kernel(const ConvNextArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_body<DT, 64, 3, 3, 2, 2, 4, true, 0, true, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 
 // Whole Bottleneck (pose_hrnet.py:85-101) in one launch: conv1 1x1 (head, into LDS) -> conv2 3x3 -> conv3 1x1 + x.
@@ -252,7 +259,7 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
                        const float* head_bias, const void* tail_w_packed, const float* tail_bias,
                        int32_t tail_out_c, const void* residual, int32_t res_ld, void* out16, int32_t out_ld,
                        int32_t relu, void* stream, const void* next_w = nullptr, const float* next_bias = nullptr,
-                       void* next_out = nullptr, int32_t next_ld = 0) {
+                       void* next_out = nullptr, int32_t next_ld = 0, const void* cat_x = nullptr, int32_t cat_ld = 0) {
     const int tile_px = next_w ? 256 : 192;             // pixels per workgroup: 2 x 2 waves x NT (3 or 4) groups of 32
     if (!inner || !tail_w_packed || !tail_bias || !out16) RSG_FAIL("conv_pair: null pointer");
     if (inner->kh != 3 || inner->kw != 3 || inner->stride != 1 || inner->out_c != 64 || inner->in_c % 64 ||
@@ -297,9 +304,22 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
         if (tail_out_c != 256 || !next_bias || !next_out || next_ld < 64 || next_ld % 8 ||
             (((uintptr_t)next_w | (uintptr_t)next_bias | (uintptr_t)next_out) & 15))
             RSG_FAIL("conv_pair_next: needs a 256-channel tail, 16-byte aligned next_* pointers and next_ld >= 64");
-        a.wpk3 = (const uint4*)next_w; a.bias3 = next_bias; a.out3 = (char*)next_out; a.ldo3 = next_ld;
-        if (inner->dtype == RSG_BF16) RSG_LAUNCH(conv_pair_next_kernel<BF16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
-        else RSG_LAUNCH(conv_pair_next_kernel<F16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
+        ConvNextArgs na;
+        static_cast<ConvArgs&>(na) = a;
+        na.wpk3 = (const uint4*)next_w; na.bias3 = next_bias; na.out3 = (char*)next_out; na.ldo3 = next_ld;
+        na.in2 = nullptr; na.ldi2 = 0;
+        if (cat_x) {
+            if (residual || cat_ld < 64 || cat_ld % 8 || ((uintptr_t)cat_x & 15) || t.TH * t.TW > 256)
+                RSG_FAIL("conv_pair_next: the K-concat form takes no residual; cat_x 16-byte aligned, cat_ld >= 64");
+            na.in2 = (const char*)cat_x; na.ldi2 = cat_ld;
+            const int lds = 2 * 256 * 144;                  // conv2 image + x image
+            if (t.lds < lds) t.lds = lds;
+            void (*fn)(const ConvNextArgs) = inner->dtype == RSG_BF16 ? conv_pair_next_cat_kernel<BF16> : conv_pair_next_cat_kernel<F16>;
+            if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, t.lds) != hipSuccess)
+                RSG_FAIL("conv_pair_next: cannot reserve %d B of LDS", t.lds);
+            RSG_LAUNCH(fn, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, na);
+        } else if (inner->dtype == RSG_BF16) RSG_LAUNCH(conv_pair_next_kernel<BF16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, na);
+        else RSG_LAUNCH(conv_pair_next_kernel<F16>, dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, na);
         RSG_CHECK_LAUNCH("conv_pair_next");
         return 0;
     }
@@ -335,10 +355,11 @@ extern "C" int rsg_conv_pair(const rsg_conv_desc* inner, const void* tail_w_pack
 extern "C" int32_t rsg_conv_pair_next_perm(int32_t l) { return (l & ~0x18) | (((l >> 3) & 1) << 4) | (((l >> 4) & 1) << 3); }
 extern "C" int rsg_conv_pair_next(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias,
                                   const void* residual, int32_t res_ld, void* out16, int32_t out_ld, const void* next_w_packed,
-                                  const float* next_bias, void* next_out16, int32_t next_out_ld, void* stream) {
+                                  const float* next_bias, void* next_out16, int32_t next_out_ld, const void* cat_x, int32_t cat_ld,
+                                  void* stream) {
     if (!next_w_packed) RSG_FAIL("conv_pair_next: null pointer");
     return pair_launch(inner, nullptr, 0, nullptr, nullptr, tail_w_packed, tail_bias, 256, residual, res_ld, out16, out_ld, 1,
-                       stream, next_w_packed, next_bias, next_out16, next_out_ld);
+                       stream, next_w_packed, next_bias, next_out16, next_out_ld, cat_x, cat_ld);
 }
 
 // logical input channel l of the head's packed weights <-> channel of x (see conv_body HEAD)

@@ -287,17 +287,21 @@ class Plan:
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
 
-    def conv_pair(self, x: VT, conv_a, bn_a, conv_b, bn_b, residual: Optional[VT], name="", next_unit=None):
+    def conv_pair(self, x: VT, conv_a, bn_a, conv_b, bn_b, residual: Optional[VT], name="", next_unit=None,
+                  tail=None, cat_x: Optional[VT] = None):
         """Record Bottleneck conv2 (3x3, 64 outputs, BN, ReLU) + conv3 (1x1, BN, + residual, ReLU) as ONE launch
         (rsg_conv_pair): the 64-channel map between them stays in LDS.  next_unit = (conv1, bn1) of the FOLLOWING
         Bottleneck: its 1x1 conv runs in the same launch on the block output (rsg_conv_pair_next) and the call returns
         (block output, that conv1's 64-channel output)."""
         sa, ha = self.bn_fold(bn_a)
         wpa, boa, Ia, Oa = self.pack_conv(conv_a.weight, sa, ha, conv_a.bias)
-        sb, hb = self.bn_fold(bn_b)
-        wpb, bob, Ib, Ob = self.pack_conv(conv_b.weight, sb, hb, conv_b.bias)
+        if tail is not None:        # (weight [O, 128, 1, 1] already scaled, shift): the K-concat tail of the first Bottleneck
+            wpb, bob, Ib, Ob = self.pack_conv(tail[0], None, tail[1], None)
+        else:
+            sb, hb = self.bn_fold(bn_b)
+            wpb, bob, Ib, Ob = self.pack_conv(conv_b.weight, sb, hb, conv_b.bias)
         out = self.new(x.H, x.W, _round_up(Ob, 32), name=name)
-        rec = dict(kind="conv_pair", x=x, wp=wpa, bias=boa, wp2=wpb, bias2=bob, res=residual, out=out,
+        rec = dict(kind="conv_pair", x=x, wp=wpa, bias=boa, wp2=wpb, bias2=bob, res=residual, out=out, cat_x=cat_x,
                    out_f32=None, I=self.lib.rsg_conv_padded_cin(Ia), O=Oa, O2=Ob, kh=3, kw=3, stride=1, pad=(1, 1),
                    up=(1, 0, 0), out_hw=(x.H, x.W), phys_hw=(x.H, x.W), relu=True, name=name)
         self.flops += 2 * self.batch * x.H * x.W * (Oa * Ia * 9 + Ob * Ib)
@@ -310,7 +314,7 @@ class Plan:
         wpn, bon, In, On = self.pack_conv(conv_n.weight.detach().float().cpu()[:, perm].contiguous(), sn, hn, conv_n.bias)
         t_next = self.new(x.H, x.W, On, name=name + "+next.conv1")
         rec.update(wp3=wpn, bias3=bon, out3=t_next, O3=On)
-        self._record(rec, [x, residual], [out, t_next])
+        self._record(rec, [x, residual, cat_x], [out, t_next])
         self.flops += 2 * self.batch * x.H * x.W * On * In
         return out, t_next
 
@@ -597,10 +601,12 @@ class Plan:
         if r.get("out3") is not None:          # + the next Bottleneck's conv1 in the same launch
             t3 = r["out3"]
             fn = self.lib.rsg_conv_pair_next
+            cx = r.get("cat_x")
             args = (C.byref(d), r["wp2"].data_ptr(), r["bias2"].data_ptr(), res.ptr() if res is not None else None,
-                    res.ld if res is not None else 0, out.ptr(), out.ld, r["wp3"].data_ptr(), r["bias3"].data_ptr(), t3.ptr(), t3.ld)
+                    res.ld if res is not None else 0, out.ptr(), out.ld, r["wp3"].data_ptr(), r["bias3"].data_ptr(), t3.ptr(), t3.ld,
+                    cx.ptr() if cx is not None else None, cx.ld if cx is not None else 0)
             entry = dict(name=nm, flops=float(2 * self.batch * r["out_hw"][0] * r["out_hw"][1] *
-                                             (r["I"] * 64 * 9 + 64 * r["O2"] + r["O2"] * r["O3"])))
+                                             (r["I"] * 64 * 9 + (128 if cx is not None else 64) * r["O2"] + r["O2"] * r["O3"])))
         self.conv_log.append(entry)
 
         def launch(stream):
@@ -1274,7 +1280,25 @@ class _BackboneMixin:
                 and hasattr(b0, "conv3") and b0.downsample[0].kernel_size == (1, 1)
                 and b0.downsample[0].stride == (1, 1) and b0.conv3.in_channels % 16 == 0
                 and m.conv2.out_channels % 16 == 0)
-        if fold:
+        use_next = os.environ.get("RSGNET_HIP_PAIR_NEXT", "1") != "0" and os.environ.get("RSGNET_HIP_PAIR", "1") != "0" \
+            and os.environ.get("RSGNET_HIP_BOTTLENECK", "0") != "1"
+        t_pre = None                # conv1 output of the NEXT block, already computed by the previous block's launch
+        l1 = list(m.layer1)
+        if fold and use_next and len(l1) > 1 and self._plain_bottleneck(l1[1]) and b0.conv2.kernel_size == (3, 3) \
+                and b0.conv2.in_channels == 64 and b0.conv2.out_channels == 64 and b0.conv3.out_channels == 256 \
+                and m.conv2.out_channels == 64 and os.environ.get("RSGNET_HIP_PAIR_CAT", "1") != "0":
+            # layer1.0 in TWO launches: conv1, then conv2 -> [conv3 | projected residual] as one K = 128 contraction over
+            # [conv2 output | x] -> conv1 of layer1.1, all from LDS (rsg_conv_pair_next with cat_x)
+            xs = self.stem_to(m, None) if x is None else self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
+            t = self._unit(xs, b0.conv1, b0.bn1, relu=True, name="layer1.0.conv1")
+            s3, h3 = self.bn_fold(b0.bn3)
+            sd, hd = self.bn_fold(b0.downsample[1])
+            w3 = b0.conv3.weight.detach().float().cpu() * s3.view(-1, 1, 1, 1)
+            wd = b0.downsample[0].weight.detach().float().cpu() * sd.view(-1, 1, 1, 1)
+            x, t_pre = self.conv_pair(t, b0.conv2, b0.bn2, None, None, None, name="layer1.0.conv2+conv3+downsample+next.conv1",
+                                      next_unit=(l1[1].conv1, l1[1].bn1), tail=(torch.cat([w3, wd], dim=1), h3 + hd), cat_x=xs)
+            rest, k0 = l1[1:], 1
+        elif fold:
             # layer1.0: relu(bn3(conv3(t)) + bn_d(conv_d(x))) is ONE 1x1 conv over the channel concat [t | x]
             # with weights [s3*W3 | sd*Wd]: the projected residual (100 MB at batch 64) is never stored.
             # The stem's conv2 writes x straight into its half of the concat buffer.
@@ -1301,15 +1325,14 @@ class _BackboneMixin:
             rest, k0 = list(m.layer1), 0
         # runs of plain Bottlenecks: each block's launch also computes the next block's conv1 (RSGNET_HIP_PAIR_NEXT=0: off)
         k = 0
-        use_next = os.environ.get("RSGNET_HIP_PAIR_NEXT", "1") != "0" and os.environ.get("RSGNET_HIP_PAIR", "1") != "0" \
-            and os.environ.get("RSGNET_HIP_BOTTLENECK", "0") != "1"
         while k < len(rest):
             run = []
             while use_next and k + len(run) < len(rest) and self._plain_bottleneck(rest[k + len(run)]) and x.C == 256 and x.coff == 0:
                 rest[k + len(run)]._rsg_name = f"layer1.{k0 + k + len(run)}"
                 run.append(rest[k + len(run)])
-            if len(run) >= 2:
-                t = self._unit(x, run[0].conv1, run[0].bn1, relu=True, name=f"{run[0]._rsg_name}.conv1")
+            if len(run) >= 2 or (run and t_pre is not None):
+                t = t_pre if t_pre is not None else self._unit(x, run[0].conv1, run[0].bn1, relu=True, name=f"{run[0]._rsg_name}.conv1")
+                t_pre = None
                 for j, blk in enumerate(run):
                     if j + 1 < len(run):
                         x, t = self.conv_pair(t, blk.conv2, blk.bn2, blk.conv3, blk.bn3, x,

@@ -504,7 +504,7 @@ def test_conv_pair_next_equals_pair_plus_conv1(shape):
     d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, H, W
     d.relu, d.dtype = 1, 0
     hip.check(lib.rsg_conv_pair_next(C.byref(d), wp2.data_ptr(), b2.data_ptr(), rin.data_ptr(), 256, out.data_ptr(), 256,
-                                     wp3.data_ptr(), b3.data_ptr(), tn.data_ptr(), 64, _stream()), "conv_pair_next")
+                                     wp3.data_ptr(), b3.data_ptr(), tn.data_ptr(), 64, None, 0, _stream()), "conv_pair_next")
     torch.cuda.synchronize()
     got = out.float().cpu().permute(0, 3, 1, 2)
     got_t = tn.float().cpu().permute(0, 3, 1, 2)
@@ -513,6 +513,61 @@ def test_conv_pair_next_equals_pair_plus_conv1(shape):
     err = (got_t - want_t).abs().max().item()
     assert err <= 2 ** -9 * want_t.abs().max().item(), (err, want_t.abs().max().item())
     assert (got_t != want_t).float().mean().item() < 0.05           # and only the odd last bit at that
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 48), (3, 13, 9), (1, 5, 70)], ids=str)
+def test_conv_pair_next_with_projected_residual(shape):
+    """The first Bottleneck (pose_hrnet.py:93-101 with `downsample`): conv2 -> ONE 1x1 conv over [conv2 output | x] with
+    weights [s3*W3 | sd*Wd] (conv3 + projected residual) -> ReLU -> conv1 of the next block, one launch
+    (rsg_conv_pair_next with cat_x) against the three rsg_conv_igemm launches it replaces."""
+    B, H, W = shape
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(11 * H + W)
+    xblk = torch.randn(B, 64, H, W, generator=g)                    # block input (stem output)
+    t = torch.relu(torch.randn(B, 64, H, W, generator=g))           # conv1 output
+    w2 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    s2, h2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    wcat = torch.randn(256, 128, 1, 1, generator=g) * (2.0 / 128) ** 0.5
+    hcat = torch.randn(256, generator=g) * 0.1
+    w3 = torch.randn(64, 256, 1, 1, generator=g) * (2.0 / 256) ** 0.5
+    s3, h3 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    mid, _ = run_conv(t, w2, s2, h2, relu=True)
+    want, _ = run_conv(torch.cat([mid, xblk.half().float()], 1), wcat, None, hcat, relu=True)
+    want_t, _ = run_conv(want, w3, s3, h3, relu=True)
+
+    def pack(w, s, h):
+        O, I, kh, kw = w.shape
+        wp = np.zeros(lib.rsg_conv_packed_bytes(I, O, kh, kw), np.uint8)
+        bo = np.zeros(O, np.float32)
+        hip.check(lib.rsg_pack_conv_weights_host(np.ascontiguousarray(w.numpy()).ctypes.data, None if s is None else s.numpy().ctypes.data,
+                                                 h.numpy().ctypes.data, None, I, O, kh, kw, 0, wp.ctypes.data, bo.ctypes.data))
+        return torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+
+    perm = [lib.rsg_conv_pair_next_perm(l) for l in range(256)]
+    wp2, b2 = pack(w2, s2, h2)
+    wpc, bc = pack(wcat, None, hcat)
+    wp3, b3 = pack(w3[:, perm].contiguous(), s3, h3)
+    tin = t.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    xin = xblk.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    out = torch.full((B, H, W, 256), float("nan"), dtype=torch.float16, device=DEV)
+    tn = torch.full((B, H, W, 64), float("nan"), dtype=torch.float16, device=DEV)
+    d = hip.ConvDesc()
+    d.inp, d.w_packed, d.bias = tin.data_ptr(), wp2.data_ptr(), b2.data_ptr()
+    d.out16 = out.data_ptr()
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, H, W, 64, 64
+    d.out_h, d.out_w, d.out_c, d.out_ld = H, W, 64, 64
+    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = 3, 3, 1, 1, 1
+    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, H, W
+    d.relu, d.dtype = 1, 0
+    hip.check(lib.rsg_conv_pair_next(C.byref(d), wpc.data_ptr(), bc.data_ptr(), None, 0, out.data_ptr(), 256,
+                                     wp3.data_ptr(), b3.data_ptr(), tn.data_ptr(), 64, xin.data_ptr(), 64, _stream()), "conv_pair_next cat")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    got_t = tn.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all() and torch.isfinite(got_t).all()
+    assert torch.equal(got, want)                                   # same k order as the K-concat conv_igemm
+    err = (got_t - want_t).abs().max().item()
+    assert err <= 2 ** -9 * want_t.abs().max().item(), (err, want_t.abs().max().item())
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 48), (3, 13, 9), (1, 96, 72), (1, 5, 70)], ids=str)
