@@ -141,7 +141,8 @@ int rsg_graph_destroy(void* graph);
  * C->C (BatchNorm folded, ReLU after each, block input added before every second ReLU), with the
  * activation tile resident in LDS for the whole chain.  in/out: dense NHWC 16-bit [batch,h,w,c],
  * in != out.  w_packed[l], bias[l]: per-layer device pointers from rsg_pack_conv_weights_host
- * (HOST arrays of nlayers device pointers).  c in {32,64,128,256}.
+ * (HOST arrays of nlayers device pointers).  c in {32,64,128,256} (HRNet-W32; 8 waves per workgroup) or
+ * {48,96,192,384} (HRNet-W48; 12 waves, one wave row per 32-channel output tile, c = 48 padded to two tiles).
  * rsg_basic_chain_supported returns 1 when (c,h,w,nlayers) can run and fills
  * info4 = {tile rows, images per workgroup, LDS bytes, workgroups}.
  * workspace: device scratch of rsg_basic_chain_workspace_bytes(...) bytes; it carries each block's input
@@ -186,6 +187,8 @@ typedef struct rsg_chain_item {
     const void* wait_flags;        /* NULL, or the done_flags of an earlier item */
     int32_t ntails;                /* 0..3 fuse convs computed from the final LDS image (whole-image maps only) */
     int32_t reserved;
+    int32_t in_ld, out_ld;         /* pixel stride (elements) of in / out; 0 = dense (= c).  Only c = 48 takes other strides
+                                      (HRNet-W48 keeps its 48-channel maps in 64-channel buffers) */
     rsg_chain_tail tails[3];
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);

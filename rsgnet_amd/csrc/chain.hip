@@ -39,13 +39,13 @@
 // boundaries into a side buffer that nothing else reads (tools/chain_stamps.py prints the shares).  The
 // production build contains none of this.
 #ifdef RSG_CHAIN_STAMPS
-__device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][8 waves][32]
+__device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][16 waves][32]
 #define RSG_STAMP(slot)                                                                              \
     do {                                                                                             \
         if (g_chain_stamps && (threadIdx.x & 63) == 0) {                                             \
             unsigned long long t__;                                                                  \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");              \
-            g_chain_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (slot)] = t__;       \
+            g_chain_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 32 + (slot)] = t__;       \
         }                                                                                            \
     } while (0)
 #else
@@ -97,6 +97,7 @@ struct ChainArgs {
     int ntails;
     ChainTail tail[RSG_CHAIN_MAX_TAILS];
     int dual;     // 1: two LDS images (ping-pong): a layer reads one and writes the other, the block input stays in LDS
+    int ldi, ldo; // pixel stride (elements) of in / out; == C except for the 48-channel maps of HRNet-W48 (kept in 64-channel buffers)
     int debug;    // experiments (rsg_tune("chain_debug")): bit 2 = no block-input fetch (WRONG results), bit 4 = producers never signal
 };
 
@@ -107,10 +108,10 @@ struct ChainArgs {
 // the same sums in the same order as conv_igemm.hip, so the results are bit-identical to the separate launch.
 template <class DT, int C, int NWAVES, int NTAPS>
 __device__ __forceinline__ void chain_tail_conv(const ChainTail& t, const char* img, int NI, int b0, int B, int slot_rows, int RP) {
-    constexpr int CINB = (C % 64 == 0) ? 64 : 32;
+    constexpr int CINB = (C % 64 == 0) ? 64 : (C % 32 == 0 ? 32 : 16);
     constexpr int NCH = C / CINB, KPT = CINB / 16, KS = NCH * NTAPS * KPT;
     constexpr int PS = 2 * C + 16;
-    constexpr int NPF = (KS % 4 == 0) ? 4 : 2;
+    constexpr int NPF = (KS % 4 == 0) ? 4 : (KS % 2 == 0 ? 2 : 3);
     static_assert(KS % NPF == 0, "tail prefetch ring");
     const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -171,7 +172,12 @@ template <class DT, int C, int WM, int WN, int NT, bool DUAL = false, int NHELD 
 __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_id, char* smem, const unsigned pf = 0) {
     static_assert(!(DUAL && NHELD) && NHELD <= NT, "ping-pong images keep the block input in LDS already");
     constexpr int NTHR = 64 * WM * WN;
-    constexpr int CINB = (C % 64 == 0) ? 64 : 32;      // same k order as rsg_pack_conv_weights_host
+    constexpr int CINB = (C % 64 == 0) ? 64 : (C % 32 == 0 ? 32 : 16);   // same k order as rsg_pack_conv_weights_host
+    // C = 48 (HRNet-W48's first branch): the output channels are padded to two 32-channel tiles (zero weight rows);
+    // the lanes of the padding own no channels of the LDS pixel and write nothing.  Its maps live in buffers with a
+    // pixel stride of their own (ldi / ldo); every other width is dense.
+    constexpr bool PADDED = (C % 32) != 0;
+    static_assert(C % 16 == 0 && 32 * WM >= C && 32 * WM - C < 32, "one wave row per 32 output channels");
     constexpr int NCH = C / CINB, KPT = CINB / 16;
     constexpr int KS = NCH * 9 * KPT;
     constexpr int PS = 2 * C + 16;                       // LDS bytes per pixel
@@ -201,7 +207,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     if (g_chain_stamps && (threadIdx.x & 63) == 0) {         // which XCD (clock domain) and CU this workgroup runs on
         unsigned xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hwid));
-        g_chain_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + 31] = ((unsigned long long)xcc << 32) | hwid;
+        g_chain_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 32 + 31] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
     // ---- zero what staging does not write: the border row above and below every image slot and the border pixel
@@ -259,8 +265,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     const int chunks_per_img = R * W * CPP;
     constexpr int NLD = 14;                              // staging loads in flight per thread (one round for every HRNet-W32 map)
     // sc1 loads (aux 16): served by L2, so a tile written by another workgroup of this launch is read fresh
+    const int ldi2 = PADDED ? p.ldi * 2 : C * 2, ldo2 = PADDED ? p.ldo * 2 : C * 2;     // pixel strides in bytes
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(p.in), 0, p.B * p.H * W * C * 2, 0x00020000);
+        const_cast<char*>(p.in), 0, p.B * p.H * W * ldi2, 0x00020000);
     // The held rows of an image are one contiguous byte range of the input, so chunk k of the window is at
     // start + 16k; only its LDS address needs (row, position in the row).  The row is walked incrementally: a
     // division by the run-time row length per chunk cost more cycles than the loads themselves.
@@ -268,7 +275,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     const int step_q = NTHR / rowc, step_r = NTHR - step_q * rowc;
     for (int i = 0; i < p.NI; ++i) {
         if (b0 + i >= p.B) break;
-        const int gbase = ((b0 + i) * p.H + y_first) * W * C * 2;
+        const int gbase = ((b0 + i) * p.H + y_first) * W * ldi2;
         char* const slot = smem + i * slot_rows * RP;
         int r = tid / rowc, c = tid - r * rowc;
         for (int base = 0; base < chunks_per_img; base += NTHR * NLD) {
@@ -279,7 +286,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
                 lo[j] = -1;
                 if (r < R) {
                     v[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-                        in_rsrc, gbase + (base + j * NTHR + tid) * 16, 0, 16));
+                        in_rsrc, gbase + (PADDED ? (r * W + c / CPP) * ldi2 + (c % CPP) * 16 : (base + j * NTHR + tid) * 16), 0, 16));
                     lo[j] = (r + 1) * RP + PS + (c / CPP) * PS + (c % CPP) * 16;
                 }
                 r += step_q; c += step_r;
@@ -317,7 +324,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 
     // ring depth; must divide KS (18, 36, 72, 144).  C = 128 with six pixel groups per wave has 6 x 128 = 768 cycles of
     // MFMA per k-step: a 6-deep ring covers an L2 miss as well as 9 did with three groups, and frees 12 registers
-    constexpr int NPF = (C == 256) ? 9 : (C == 128 ? (NT >= 6 ? 6 : 9) : (C == 64 ? 4 : RSG_CHAIN_NPF32));
+    constexpr int NPF = (C == 256) ? 9 : (C == 128 ? (NT >= 6 ? 6 : 9) : (C == 64 ? 4 : (C == 32 ? RSG_CHAIN_NPF32 : (C == 48 || C == 96 ? 3 : 6))));
     static_assert(KS % NPF == 0, "prefetch ring must wrap at the layer boundary");
     uint4 aq[NPF];
     // block-input slots of this lane, through a buffer descriptor: uniform base in SGPRs, ONE address VGPR (the
@@ -352,7 +359,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 #ifdef RSG_DBG_LATE_RES
         constexpr int NRE = 0;
 #else
-        constexpr int NRE = NT >= 7 ? 3 : NT;
+        // 768-thread variants (HRNet-W48 widths, 170 registers per lane): everything after the k-loop
+        constexpr int NRE = NTHR > 512 ? 0 : (NT >= 7 ? 3 : NT);
 #endif
         auto fetch_res = [&](int g0, int g1) {
             if (p.debug & 2) {                           // timing experiment only
@@ -407,7 +415,37 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         // cycles per k-step, the two waves of a SIMD serialise).
         constexpr bool DOUBLE_BUF = NT <= 4;
         constexpr int RES_LEAD = 1;                      // k-steps between the block-input fetch and its use
-        if constexpr (DOUBLE_BUF) {
+        if constexpr (DOUBLE_BUF && KS > 144) {
+            // C = 384 (216 k-steps): the same loop in two halves of whole channel blocks -- hipcc gives up unrolling 216
+            // steps and would index the fragment rings at run time (scratch)
+            constexpr int KSO = 2, KSI = KS / KSO;
+            static_assert(NCH % KSO == 0 && KSI % NPF == 0 && KSI % 2 == 0 && NRE == 0, "halves of whole channel blocks");
+            uint4 bq[2][NT];
+#pragma unroll
+            for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(rd + pixoff[g] + boff(0));
+#pragma unroll 1
+            for (int ko = 0; ko < KSO; ++ko) {
+                const char* const rdk = rd + ko * (NCH / KSO) * CINB * 2;
+                const uint4* const apk = ap + ko * KSI * 64;
+                const uint4* const nxt = (ko + 1 < KSO) ? apk + KSI * 64 : apn;
+                const bool more = ko + 1 < KSO;
+#pragma unroll
+                for (int ki = 0; ki < KSI; ++ki) {
+                    const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ki % NPF]);
+                    if (ki + 1 < KSI || more) {
+#pragma unroll
+                        for (int g = 0; g < NT; ++g)
+                            bq[(ki + 1) & 1][g] = *reinterpret_cast<const uint4*>(rdk + pixoff[g] + boff(ki + 1));
+                    }
+                    aq[ki % NPF] = (ki + NPF < KSI) ? apk[(ki + NPF) * 64] : nxt[(ki + NPF - KSI) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < NT; ++g)
+                        acc[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ki & 1][g]), acc[g]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (DOUBLE_BUF) {
             // narrow tiles: two register sets, reads one whole k-step ahead, two scheduling regions per step
             uint4 bq[2][NT];
 #pragma unroll
@@ -501,7 +539,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         }
 #pragma unroll
         for (int g = 0; g < NT; ++g) {
-            if (live[g]) {
+            if (live[g] && (!PADDED || cbase < C)) {
                 *reinterpret_cast<uint4*>(wr + pixoff[g] + wd) = o[g][0];
                 *reinterpret_cast<uint4*>(wr + pixoff[g] + wd + 16) = o[g][1];
             }
@@ -511,16 +549,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     }
 
     // ---- store the TH output rows of every image slot (sc1: written through, see the hand-off above) ----------
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * W * C * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * W * ldo2, 0x00020000);
     const int out_rows = min(p.TH, p.H - tile * p.TH);
     for (int i = 0; i < p.NI; ++i) {
         if (b0 + i >= p.B) break;
-        const int gbase = ((b0 + i) * p.H + tile * p.TH) * W * C * 2;
+        const int gbase = ((b0 + i) * p.H + tile * p.TH) * W * ldo2;
         const char* const slot = smem + (i * slot_rows + tile * p.TH - y_first + 1) * RP + PS;
         int r = tid / rowc, c = tid - r * rowc;
         for (int k = tid; k < out_rows * rowc; k += NTHR) {
             const uint4 v = *reinterpret_cast<const uint4*>(slot + r * RP + (c / CPP) * PS + (c % CPP) * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, gbase + k * 16, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc,
+                                                   gbase + (PADDED ? (r * W + c / CPP) * ldo2 + (c % CPP) * 16 : k * 16), 0, 16);
             r += step_q; c += step_r;
             if (c >= rowc) { c -= rowc; ++r; }
         }
@@ -568,6 +607,7 @@ struct ChainGroupArgs {
 // 188 us, 131 us repeated back to back, 141 us with only the weights warmed; tools/op_in_context.py) and the
 // A-operand ring does not cover an HBM miss.  Dedicated prefetch workgroups did the same for stage 4 but cost
 // stage 3 a CU each (they hold the launch's LDS).
+template <int NTHR = 512>
 static __device__ __forceinline__ unsigned chain_prefetch_weights(const ChainGroupArgs& g) {
     const int nw = min((int)gridDim.x, 256);
     unsigned acc = 0;
@@ -576,7 +616,7 @@ static __device__ __forceinline__ unsigned chain_prefetch_weights(const ChainGro
     for (int i = 0; i < RSG_CHAIN_GROUP_MAX; ++i) {          // static indices: the scalar loads of the table batch up
         const char* w = g.pre_ptr[i];
         const int lines = g.pre_lines[i];                    // 0 for an unused entry
-        for (int k = blockIdx.x * 512 + threadIdx.x; k < lines; k += nw * 512)
+        for (int k = blockIdx.x * NTHR + threadIdx.x; k < lines; k += nw * NTHR)
             acc ^= *reinterpret_cast<const unsigned*>(w + (size_t)k * 128);
     }
     return acc;
@@ -620,11 +660,38 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     }
 }
 
+// The widths of HRNet-W48 (48 / 96 / 192 / 384 channels: 1.5, 3, 6, 12 output-channel tiles) do not divide eight waves:
+// their grouped launch runs TWELVE waves per workgroup (three per SIMD, 170 registers per lane), one wave row per
+// output-channel tile.  At 384x288 only the 12x9x384 map fits LDS whole; the others run in row tiles, so a launch takes
+// one BasicBlock (two layers, halo 2) of every branch.
+#define RSG_CHAIN_WIDE_THREADS 768
+template <class DT>
+__global__ void __launch_bounds__(RSG_CHAIN_WIDE_THREADS) chain_group_wide_kernel(const ChainGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned pf = chain_prefetch_weights<RSG_CHAIN_WIDE_THREADS>(g);
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < RSG_CHAIN_GROUP_MAX; ++j) i += (j < g.n && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
+    const int bid = rsg_xcd_tile(blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);
+    switch (g.c[i]) {
+        case 48: chain_body<DT, 48, 2, 6, 5>(g.a[i], bid, smem, pf); break;
+        case 96: chain_body<DT, 96, 3, 4, 5>(g.a[i], bid, smem, pf); break;
+        case 192: chain_body<DT, 192, 6, 2, 4>(g.a[i], bid, smem, pf); break;
+        case 384:   // NT follows the pixels a workgroup owns (the whole 12x9 map: 4 groups; one of its two row tiles: 3)
+            if (g.a[i].NI * g.a[i].R * g.a[i].W <= 96) chain_body<DT, 384, 12, 1, 3>(g.a[i], bid, smem, pf);
+            else chain_body<DT, 384, 12, 1, 4>(g.a[i], bid, smem, pf);
+            break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct ChainCfg { int C, WM, WN, NT; };
-static const ChainCfg kChainCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3}};
-// widest variants of the grouped launch (512 threads each)
-static const ChainCfg kChainGroupCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 2, 3}, {256, 8, 1, 3}};
+static const ChainCfg kChainCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3},
+                                      {48, 2, 6, 5}, {96, 3, 4, 5}, {192, 6, 2, 4}, {384, 12, 1, 4}};
+// widest variants of the grouped launch (512 threads each; 768 for the HRNet-W48 widths)
+static const ChainCfg kChainGroupCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 2, 3}, {256, 8, 1, 3},
+                                           {48, 2, 6, 5}, {96, 3, 4, 5}, {192, 6, 2, 4}, {384, 12, 1, 4}};
+static bool chain_is_wide(int C) { return C == 48 || C == 96 || C == 192 || C == 384; }
 static const int CHAIN_LDS_LIMIT = 160 * 1024;
 static const int kChainMaxNT = 8;      // workspace slots are sized for the widest variant (standalone or grouped)
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
@@ -633,6 +700,7 @@ static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
 static int g_chain_debug = 0;      // rsg_tune("chain_debug", bits): experiments with WRONG results: 1 = every layer reads layer 0's weights, 2 = no block-input fetch, 4 = hand-off producers never signal (exercises the error word)
 static int g_chain_dual = 1;       // rsg_tune("chain_dual", 0|1): ping-pong LDS images for the whole-image chains that fit twice
 static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
+static int g_chain_split_rows = 0; // rsg_tune("chain_split_rows", 0|1): two row tiles for the 384-channel map at small batch (chain_geometry); measured neutral, off
 static int chain_row_pitch(int C, int W) {
     const int PS = 2 * C + 16;
     return (W + 2) * PS + (g_chain_pitch_pad ? (256 - (2 * PS) % 256) % 256 : 0);
@@ -651,6 +719,7 @@ extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "chain_prefetch")) { g_chain_prefetch = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "chain_debug")) { g_chain_debug = value; return 0; }
     if (key && !strcmp(key, "chain_dual")) { g_chain_dual = value ? 1 : 0; return 0; }
+    if (key && !strcmp(key, "chain_split_rows")) { g_chain_split_rows = value ? 1 : 0; return 0; }
     RSG_FAIL("tune: unknown key or bad value");
 }
 
@@ -669,6 +738,10 @@ static chain_fn chain_lookup(int C, int npix, int dual) {
         case 64: return chain_kernel<DT, 64, 2, 4, 6>;
         case 128: return chain_kernel<DT, 128, 4, 1, 6>;
         case 256: return chain_kernel<DT, 256, 8, 1, 3>;
+        case 48: return chain_kernel<DT, 48, 2, 6, 5>;
+        case 96: return chain_kernel<DT, 96, 3, 4, 5>;
+        case 192: return chain_kernel<DT, 192, 6, 2, 4>;
+        case 384: return npix <= 96 ? chain_kernel<DT, 384, 12, 1, 3> : chain_kernel<DT, 384, 12, 1, 4>;
     }
     return nullptr;
 }
@@ -687,7 +760,14 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     const int RP = chain_row_pitch(C, W);
     a.RP = RP;
     auto bytes = [&](int ni, int R) { return ni * (R + 2) * RP + RSG_CHAIN_MAX_LAYERS * C * 4; };   // image + biases
-    if (H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
+    // 384 channels, one BasicBlock, a small batch: whole images would occupy `batch` compute units for the longest
+    // workgroups of the launch (12x9x384, batch 32: 112 us on 32 of 256 CUs while the other branches need ~90 us of the
+    // rest).  Two row tiles with a 2-row halo do 1.5x the work on twice the CUs and shorten that critical path by a quarter.
+    // Same-visit A/B at batch 32: 5.152 vs 5.153 ms per step -- the launch is bound by the total work at the all-CU clock,
+    // not by this workgroup -- so the switch stays off.
+    const bool split_rows = g_chain_split_rows && C == 384 && nlayers == 2 && H >= 8 && batch * 4 <= 256 &&
+                            (H / 2 + nlayers) * W <= 96;
+    if (!split_rows && H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
         int ni = cap / (H * W);
         while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > ni_want)) --ni;
         a.TH = H; a.R = H; a.halo = 0; a.NI = ni; a.tiles_y = 1;
@@ -770,7 +850,7 @@ extern "C" size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t 
     int lds = 0, nthr = 0;
     if (nlayers < 2 || nlayers > RSG_CHAIN_MAX_LAYERS || (nlayers & 1)) return 0;
     if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr)) return 0;
-    return chain_ws_bytes(c, a, batch, nlayers, 512);
+    return chain_ws_bytes(c, a, batch, nlayers, chain_is_wide(c) ? RSG_CHAIN_WIDE_THREADS : 512);
 }
 
 extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, const float* const* bias,
@@ -790,6 +870,7 @@ extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_p
     if ((long long)batch * h * w * c * 2 >= (1LL << 31))
         RSG_FAIL("basic_chain: map of %lld bytes exceeds the 32-bit buffer offsets", (long long)batch * h * w * c * 2);
     a.in = (const char*)in; a.out = (char*)out; a.nlayers = nlayers; a.B = batch; a.H = h; a.W = w;
+    a.ldi = a.ldo = c;
     a.ws = (uint4*)workspace;
     a.done = nullptr; a.wait = nullptr; a.debug = g_chain_debug;
     for (int l = 0; l < nlayers; ++l) {
@@ -827,6 +908,13 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
             RSG_FAIL("chain_group: item %d: map of %lld bytes exceeds the 32-bit buffer offsets", i,
                      (long long)it.batch * it.h * it.w * it.c * 2);
         a.in = (const char*)it.in; a.out = (char*)it.out; a.nlayers = it.nlayers; a.B = it.batch; a.H = it.h; a.W = it.w;
+        a.ldi = it.in_ld ? it.in_ld : it.c; a.ldo = it.out_ld ? it.out_ld : it.c;
+        if (a.ldi < it.c || a.ldo < it.c || (a.ldi & 7) || (a.ldo & 7) || ((a.ldi != it.c || a.ldo != it.c) && it.c % 32 == 0))
+            RSG_FAIL("chain_group: item %d: pixel strides %d / %d (only the 48-channel chain takes padded buffers)", i, a.ldi, a.ldo);
+        if ((long long)it.batch * it.h * it.w * std::max(a.ldi, a.ldo) * 2 >= (1LL << 31))
+            RSG_FAIL("chain_group: item %d: padded map exceeds the 32-bit buffer offsets", i);
+        if (chain_is_wide(it.c) != chain_is_wide(items[0].c))
+            RSG_FAIL("chain_group: item %d: the 48/96/192/384-channel chains (768 threads) cannot share a launch with the others", i);
         a.ws = (uint4*)it.workspace;
         a.done = (int*)it.done_flags;
         a.wait = (const int*)it.wait_flags;
@@ -862,7 +950,7 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
             a.bias[l] = it.bias[l];
         }
         // prefetch range: the item's layers when the caller packed them back to back (the plan does)
-        const size_t layer_bytes = (size_t)it.c * it.c * 18;
+        const size_t layer_bytes = (size_t)((it.c + 31) / 32 * 32) * it.c * 18;
         bool contiguous = g_chain_prefetch != 0;
         for (int l = 1; l < it.nlayers; ++l)
             contiguous = contiguous && (const char*)it.w_packed[l] == (const char*)it.w_packed[0] + l * layer_bytes;
@@ -881,10 +969,12 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         RSG_FAIL("chain_group: %d workgroups wait on hand-off flags but the device guarantees progress for at most %d "
                  "(compute units - 1): run the dependent chains as a second launch", waiters,
                  rsg_basic_chain_handoff_max_waiters());
-    void (*fn)(const ChainGroupArgs) = dtype == RSG_BF16 ? chain_group_kernel<BF16> : chain_group_kernel<F16>;
+    const bool wide = chain_is_wide(items[0].c);
+    void (*fn)(const ChainGroupArgs) = wide ? (dtype == RSG_BF16 ? chain_group_wide_kernel<BF16> : chain_group_wide_kernel<F16>)
+                                            : (dtype == RSG_BF16 ? chain_group_kernel<BF16> : chain_group_kernel<F16>);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess)
         RSG_FAIL("chain_group: cannot reserve %d B of LDS", lds_max);
-    RSG_LAUNCH(fn, dim3(blocks), dim3(512), lds_max, (hipStream_t)stream, g);
+    RSG_LAUNCH(fn, dim3(blocks), dim3(wide ? RSG_CHAIN_WIDE_THREADS : 512), lds_max, (hipStream_t)stream, g);
     RSG_CHECK_LAUNCH("basic_chain_group");
     return 0;
 }

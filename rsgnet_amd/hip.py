@@ -49,7 +49,7 @@ class ChainItem(C.Structure):
                 ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
                 ("w", C.c_int32), ("c", C.c_int32), ("images_per_workgroup", C.c_int32), ("workspace", C.c_void_p),
                 ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("ntails", C.c_int32), ("reserved", C.c_int32),
-                ("tails", ChainTail * 3)]
+                ("in_ld", C.c_int32), ("out_ld", C.c_int32), ("tails", ChainTail * 3)]
 
 
 class PackItem(C.Structure):
@@ -177,7 +177,8 @@ def lib() -> C.CDLL:
         for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad"),
                          ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit"), ("RSGNET_HIP_CHAIN_PREFETCH", b"chain_prefetch"),
                          ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
-                         ("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug"), ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual")):
+                         ("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug"), ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual"),
+                         ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows")):
             if os.environ.get(env):
                 l.rsg_tune(key, int(os.environ[env]))
         if os.environ.get("RSGNET_HIP_WGRAD_QUAD"):

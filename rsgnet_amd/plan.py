@@ -412,9 +412,10 @@ class Plan:
             n0 = layers[0][0].numel()
             layers = [(allw[k * n0:(k + 1) * n0], b) for k, (_, b) in enumerate(layers)]
             out = self.new(x.H, x.W, x.C, name=name)
+            cc = blocks[0].conv1.in_channels             # 48 of a 64-channel buffer for HRNet-W48's first branch
             # position k of every grouped launch shares one scratch buffer per size; it is named among the op's
             # writes, so every scheduler (lanes, explicit graph) keeps the sharers in order
-            ws = self._chain_workspace(len(subs), x, len(layers))
+            ws = self._chain_workspace(len(subs), x, len(layers), cc)
             # fuse convs computed from the chain's final LDS image (rsg_chain_tail): (conv, bn, relu) each
             tails, touts = [], []
             for conv, bnm, relu in tails_in:
@@ -426,9 +427,9 @@ class Plan:
                 touts.append(tv)
                 self.flops += 2 * self.batch * tv.H * tv.W * O * x.C * k * k
             self._tail_outs.append(touts)
-            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, tails=tails))
+            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, tails=tails, c=cc))
             outs.append(out)
-            self.flops += 2 * self.batch * x.H * x.W * x.C * x.C * 9 * len(layers)
+            self.flops += 2 * self.batch * x.H * x.W * cc * cc * 9 * len(layers)
         self._record(dict(kind="chain_group", subs=subs, name=name),
                      [d["x"] for d in subs if d["after"] is None],
                      outs + [d["ws"] for d in subs] + [t["out"] for d in subs for t in d["tails"]])
@@ -440,6 +441,11 @@ class Plan:
         if not self.use_chain:
             return 0
         info = (C.c_int32 * 4)()
+        if C_ in (48, 96, 192, 384):
+            # HRNet-W48 widths: at 384x288 only the smallest map fits LDS whole, and these maps are MFMA-heavy enough
+            # that a deeper halo costs more than a launch: ONE BasicBlock of every branch per grouped launch
+            return 1 if self.lib.rsg_basic_chain_supported(C_, H, W, 2, self.batch, info) and \
+                os.environ.get("RSGNET_HIP_WIDE_CHAINS", "1") != "0" else 0
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nblocks, self.batch, info) and info[0] == H:
             # whole images stay in LDS.  RSGNET_HIP_CHAIN_SLICES=2 cuts the chain in two launches so that
             # both grouped launches of a module hold a slice of EVERY branch (better balanced grids)
@@ -685,11 +691,11 @@ class Plan:
         # a lone fuse-sum is a group of one (the grouped entry point takes strided operands)
         self._lower_group(dict(subs=[r], name=r["name"]))
 
-    def _chain_workspace(self, slot: Optional[int], x: VT, nlayers: int) -> Optional[torch.Tensor]:
+    def _chain_workspace(self, slot: Optional[int], x: VT, nlayers: int, c: Optional[int] = None) -> Optional[torch.Tensor]:
         """Block-input scratch of a chain.  slot None: a buffer of the op's own.  slot k: the chain in position k of a
         grouped launch; position k of every grouped launch shares one buffer per distinct size (the op names it among
         its writes, so the sharers stay ordered)."""
-        need = int(self.lib.rsg_basic_chain_workspace_bytes(x.C, x.H, x.W, nlayers, self.batch))
+        need = int(self.lib.rsg_basic_chain_workspace_bytes(c or x.C, x.H, x.W, nlayers, self.batch))
         if not need:
             return None
         if slot is None:
@@ -730,16 +736,18 @@ class Plan:
         log = []
         for it, d in zip(items, subs):
             x, out, layers = d["x"], d["out"], d["layers"]
-            if x.ld != x.C or x.coff or out.ld != out.C or out.coff:
-                raise ValueError("chain operands must be dense tensors")
+            cc = d.get("c", x.C)
+            if x.coff or out.coff or ((x.ld != cc or out.ld != cc) and cc != 48):
+                raise ValueError("chain operands must be dense tensors (only the 48-channel chain reads padded buffers)")
             n = len(layers)
             wps = (C.c_void_p * n)(*[w.data_ptr() for w, _ in layers])
             bps = (C.c_void_p * n)(*[b.data_ptr() for _, b in layers])
             self._keep += [wps, bps]
             it.inp, it.out = x.ptr(), out.ptr()
+            it.in_ld, it.out_ld = x.ld, out.ld
             it.w_packed = C.cast(wps, C.POINTER(C.c_void_p))
             it.bias = C.cast(bps, C.POINTER(C.c_void_p))
-            it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, x.C
+            it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, cc
             it.workspace = d["ws"].data_ptr() if d["ws"] is not None else None
             it.ntails = len(d["tails"])
             for k, t in enumerate(d["tails"]):
@@ -748,7 +756,7 @@ class Plan:
                     raise ValueError("tail outputs must be dense tensors")
                 it.tails[k].w_packed, it.tails[k].bias, it.tails[k].out = t["wp"].data_ptr(), t["bias"].data_ptr(), tv.ptr()
                 it.tails[k].cout, it.tails[k].k, it.tails[k].stride, it.tails[k].relu = t["cout"], t["k"], t["stride"], int(t["relu"])
-            log.append((x.C, x.H, x.W, n))
+            log.append((cc, x.H, x.W, n))
         for k, d in enumerate(subs):
             if d.get("after") is not None:
                 prod = items[d["after"]]
@@ -1104,11 +1112,13 @@ class _BackboneMixin:
         # (longest chain first); a branch that needs row tiles contributes its blocks slice by slice
         slices: List[List[Tuple[int, list]]] = []      # slices[k] = [(branch, blocks)] of the k-th launch
         steps = {}
+        chan = {}                                      # channels the branch's convs see (HRNet-W48: 48 of a 64-channel buffer)
         for b, branch in enumerate(mod.branches):
             blocks = list(branch)
             plain = all(not hasattr(blk, "conv3") and blk.downsample is None for blk in blocks)
-            plain = plain and blocks[0].conv1.in_channels == xs[b].C        # no channel padding (W48: 48 in 64)
-            steps[b] = self.chain_mode(xs[b].C, xs[b].H, xs[b].W, len(blocks)) if plain else 0
+            cc = chan[b] = blocks[0].conv1.in_channels
+            plain = plain and (cc == xs[b].C or (cc == 48 and xs[b].C == 64 and xs[b].coff == 0))
+            steps[b] = self.chain_mode(cc, xs[b].H, xs[b].W, len(blocks)) if plain else 0
         # RSGNET_HIP_CHAIN_HANDOFF (default on): ONE launch per module.  Whole-image branches run all their blocks in
         # one chain; a row-tiled branch (halo grows with the chain) runs as two chains that hand over inside the
         # launch, so its second half needs no launch of its own (where half the CUs would idle).
@@ -1116,7 +1126,7 @@ class _BackboneMixin:
 
         def whole(b):
             n = 2 * len(mod.branches[b])
-            return n <= 8 and self.lib.rsg_basic_chain_supported(xs[b].C, xs[b].H, xs[b].W, n, self.batch, info) \
+            return n <= 8 and self.lib.rsg_basic_chain_supported(chan[b], xs[b].H, xs[b].W, n, self.batch, info) \
                 and info[0] == xs[b].H
 
         handoff = self.use_group and len(steps) > 1 and all(steps.values()) and self.allow_handoff and \
@@ -1128,7 +1138,7 @@ class _BackboneMixin:
             waiters = 0
             for b in steps:
                 if not whole(b):
-                    self.lib.rsg_basic_chain_supported(xs[b].C, xs[b].H, xs[b].W, 2 * steps[b], self.batch, info)
+                    self.lib.rsg_basic_chain_supported(chan[b], xs[b].H, xs[b].W, 2 * steps[b], self.batch, info)
                     waiters += info[3]
             handoff = waiters <= self.lib.rsg_basic_chain_handoff_max_waiters()
         pre: Dict[Tuple[int, int], VT] = {}                  # (i, j) -> first conv of fuse path j -> i, done by a chain tail
@@ -1176,6 +1186,27 @@ class _BackboneMixin:
             for b in order:
                 xs[b] = outs[where[b]]
             steps = {}
+        # branches the chains do not cover (HRNet-W48's widths): conv k of EVERY such branch in one grouped launch
+        # (they are independent; alone, a 12x9x384 conv fills a fraction of the 256 CUs and a launch costs ~3 us)
+        loose = [b for b, s in steps.items() if not s]
+        if self.use_group and len(loose) > 1 and os.environ.get("RSGNET_HIP_ZIP_BRANCHES", "1") != "0" and \
+                len({len(mod.branches[b]) for b in loose}) == 1 and \
+                all(not hasattr(blk, "conv3") and blk.downsample is None for b in loose for blk in mod.branches[b]):
+            mid: Dict[int, VT] = {}
+            for k in range(len(mod.branches[loose[0]])):
+                self.begin_group()
+                for b in loose:
+                    blk = mod.branches[b][k]
+                    mid[b] = self._unit(xs[b], blk.conv1, blk.bn1, relu=True, name=f"{name}.branches.{b}.{k}.conv1")
+                self.end_group(f"{name}.branches.{k}.conv1")
+                self.begin_group()
+                for b in loose:
+                    blk = mod.branches[b][k]
+                    xs[b] = self._unit(mid[b], blk.conv2, blk.bn2, relu=True, residual=xs[b],
+                                       name=f"{name}.branches.{b}.{k}.conv2")
+                self.end_group(f"{name}.branches.{k}.conv2")
+            for b in loose:
+                del steps[b]
         for b, step in steps.items():
             blocks = list(mod.branches[b])
             if not step:
@@ -1189,7 +1220,7 @@ class _BackboneMixin:
                 slices[k // step].append((b, blocks[k:k + step]))
         for k, sl in enumerate(slices):
             sl.sort(key=lambda e: (-len(e[1]), -xs[e[0]].C))     # whole-branch chains first, widest first
-            if self.use_group and len(sl) > 1:
+            if self.use_group and (len(sl) > 1 or any(chan[b] != xs[b].C for b, _ in sl)):
                 outs = self.chain_group([(xs[b], blks) for b, blks in sl], f"{name}.chains{k}")
                 for (b, _), o in zip(sl, outs):
                     xs[b] = o

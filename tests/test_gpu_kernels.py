@@ -284,7 +284,10 @@ def test_trp_attention_project_tail_scores_mse():
 
 @pytest.mark.parametrize("Cc,H,W,L", [(128, 16, 12, 8), (256, 8, 6, 8), (64, 32, 24, 8), (32, 64, 48, 2),
                                       (256, 8, 6, 2), (32, 30, 48, 2), (32, 64, 48, 4), (32, 64, 48, 8),
-                                      (32, 61, 48, 4), (64, 32, 24, 4)])
+                                      (32, 61, 48, 4), (64, 32, 24, 4),
+                                      # HRNet-W48 widths (12 waves per workgroup; 48 = 1.5 output-channel tiles)
+                                      (48, 96, 72, 2), (96, 48, 36, 2), (192, 24, 18, 2), (384, 12, 9, 2),
+                                      (384, 12, 9, 8), (96, 21, 36, 4), (48, 64, 48, 2), (192, 16, 12, 4)])
 def test_basic_chain_matches_cpu(Cc, H, W, L):
     """rsg_basic_chain vs a CPU chain that rounds to fp16 where the kernel does (after every conv)."""
     lib = hip.lib()
@@ -301,7 +304,7 @@ def test_basic_chain_matches_cpu(Cc, H, W, L):
     keep, wps, bps = [], [], []
     for l in range(L):
         wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
-        bo = np.zeros(Cc, np.float32)
+        bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
         wn, sn, hn = ws[l].numpy(), scs[l].numpy(), shs[l].numpy()
         hip.check(lib.rsg_pack_conv_weights_host(wn.ctypes.data, sn.ctypes.data, hn.ctypes.data, None, Cc, Cc, 3, 3,
                                                  0, wp.ctypes.data, bo.ctypes.data))
@@ -342,7 +345,7 @@ def _chain_layers(lib, Cc, L, seed):
         sc = ((torch.rand(Cc, generator=g) * 0.4 + 0.1) if l % 2 else (torch.rand(Cc, generator=g) + 0.5)).numpy()
         sh = (torch.randn(Cc, generator=g) * 0.1).numpy()
         wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
-        bo = np.zeros(Cc, np.float32)
+        bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
         hip.check(lib.rsg_pack_conv_weights_host(w.ctypes.data, sc.ctypes.data, sh.ctypes.data, None, Cc, Cc, 3, 3, 0,
                                                  wp.ctypes.data, bo.ctypes.data))
         wd, bd = torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
@@ -410,6 +413,61 @@ def test_chain_group_handoff_inside_one_launch():
     # the consumer must come after its producer
     items[1], items[2] = items[2], items[1]
     assert lib.rsg_basic_chain_group(items, 3, 0, _stream()) != 0
+
+
+def test_chain_group_w48_widths_one_launch():
+    """One BasicBlock of every HRNet-W48 stage-4 branch (48 / 96 / 192 / 384 channels at 96x72 ... 12x9) in ONE grouped
+    launch of the 12-wave kernel gives bit for bit what the separate launches give; the 48-channel map lives in a
+    64-channel buffer (pixel stride 64) whose upper 16 channels the chain neither reads nor writes; the 12-wave and the
+    8-wave widths cannot share a launch."""
+    lib = hip.lib()
+    B, L = 4, 2
+    g = torch.Generator().manual_seed(11)
+    dims = [(48, 96, 72), (96, 48, 36), (192, 24, 18), (384, 12, 9)]
+    xs = [torch.randn(B, H, W, Cc, generator=g).half().to(DEV) for Cc, H, W in dims]
+    lay = [_chain_layers(lib, Cc, L, 20 + k) for k, (Cc, _, _) in enumerate(dims)]
+
+    def ws(Cc, H, W):
+        return torch.empty(lib.rsg_basic_chain_workspace_bytes(Cc, H, W, L, B), dtype=torch.uint8, device=DEV)
+
+    def arr(v):
+        return (C.c_void_p * len(v))(*v)
+
+    refs = []
+    for (Cc, H, W), x, (_k, wp, bp) in zip(dims, xs, lay):
+        r = torch.empty_like(x)
+        hip.check(lib.rsg_basic_chain(x.data_ptr(), r.data_ptr(), arr(wp), arr(bp), L, B, H, W, Cc, 0,
+                                      ws(Cc, H, W).data_ptr(), _stream()), "chain")
+        refs.append(r)
+    torch.cuda.synchronize()
+    # the 48-channel operand in padded buffers: channels 48..63 hold a marker that must survive in the output buffer
+    xpad = torch.full((B, 96, 72, 64), 7.0, dtype=torch.float16, device=DEV)
+    xpad[..., :48] = xs[0]
+    opad = torch.full((B, 96, 72, 64), -3.0, dtype=torch.float16, device=DEV)
+    outs = [opad] + [torch.full_like(x, float("nan")) for x in xs[1:]]
+    ins = [xpad] + xs[1:]
+    items = (hip.ChainItem * 4)()
+    keep = []
+    for it, (Cc, H, W), xin, out, (_k, wp, bp) in zip(items, dims, ins, outs, lay):
+        wa, ba, wsp = arr(wp), arr(bp), ws(Cc, H, W)
+        keep += [wa, ba, wsp]
+        it.inp, it.out = xin.data_ptr(), out.data_ptr()
+        it.w_packed, it.bias = C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p))
+        it.nlayers, it.batch, it.h, it.w, it.c = L, B, H, W, Cc
+        it.workspace = wsp.data_ptr()
+        if Cc == 48:
+            it.in_ld = it.out_ld = 64
+    hip.check(lib.rsg_basic_chain_group(items, 4, 0, _stream()), "chain_group wide")
+    torch.cuda.synchronize()
+    assert torch.equal(opad[..., :48], refs[0]) and bool((opad[..., 48:] == -3.0).all())
+    for o, r in zip(outs[1:], refs[1:]):
+        assert torch.equal(o, r)
+    # padded strides are for the 48-channel chain only; 8-wave widths do not mix with 12-wave ones
+    items[1].in_ld = 128
+    assert lib.rsg_basic_chain_group(items, 4, 0, _stream()) != 0
+    items[1].in_ld = 0
+    items[3].c, items[3].h, items[3].w = 256, 8, 6
+    assert lib.rsg_basic_chain_group(items, 4, 0, _stream()) != 0
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 48, 256), (3, 13, 9, 128), (1, 64, 48, 64)], ids=str)

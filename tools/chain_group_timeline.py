@@ -67,7 +67,7 @@ for k, (Cc, H, W, L, after) in enumerate(branches):
         items[after].done_flags = fl.data_ptr()
         it.wait_flags = fl.data_ptr()
 total = sum(nblk)
-stamps = torch.zeros(total * 8 * 32, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(total * 16 * 32, dtype=torch.int64, device="cuda")
 lib.rsg_chain_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
 for _ in range(3):
     assert lib.rsg_basic_chain_group(items, len(branches), 0, None) == 0, lib.rsg_last_error()
@@ -77,7 +77,7 @@ e0.record()
 lib.rsg_basic_chain_group(items, len(branches), 0, None)
 e1.record()
 torch.cuda.synchronize()
-raw = stamps.cpu().numpy().reshape(total, 8, 32)
+raw = stamps.cpu().numpy().reshape(total, 16, 32)
 sw = raw.astype(np.float64)
 # every XCD has a clock of its own: times are taken from the first start seen on the workgroup's XCD
 xcc = (raw[:, 0, 31] >> 32) & 0xf

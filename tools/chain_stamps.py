@@ -19,16 +19,19 @@ cmd = [B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-shar
 subprocess.check_call(cmd)
 lib = C.CDLL(so)
 lib.rsg_last_error.restype = C.c_char_p
-Bn = 64
-for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8, 6, 4), (64, 32, 24, 8), (32, 64, 48, 8), (128, 16, 12, 8), (256, 8, 6, 8)):
+Bn = int(os.environ.get("CHAIN_STAMP_BATCH", "64"))
+SHAPES = ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8, 6, 4), (64, 32, 24, 8), (32, 64, 48, 8), (128, 16, 12, 8), (256, 8, 6, 8))
+if os.environ.get("CHAIN_STAMP_SHAPES"):          # "C,H,W,L;C,H,W,L": e.g. HRNet-W48's 48,96,72,2;96,48,36,2;192,24,18,2;384,12,9,2
+    SHAPES = tuple(tuple(int(v) for v in sh.split(",")) for sh in os.environ["CHAIN_STAMP_SHAPES"].split(";"))
+for Cc, H, W, L in SHAPES:
     x = (torch.zeros if os.environ.get("STAMP_ZERO") else torch.randn)(Bn, H, W, Cc, device="cuda").half()
     out = torch.empty_like(x)
     keep, wps, bps = [], [], []
     for l in range(L):
         w = (np.random.randn(Cc, Cc, 3, 3) * (2.0 / (Cc * 9)) ** 0.5).astype(np.float32)
-        n = Cc * Cc * 9 * 2
+        n = (Cc + 31) // 32 * 32 * Cc * 9 * 2
         wp = np.zeros(n, np.uint8)
-        bo = np.zeros(Cc, np.float32)
+        bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
         lib.rsg_pack_conv_weights_host(C.c_void_p(w.ctypes.data), None, None, None, Cc, Cc, 3, 3, 0,
                                        C.c_void_p(wp.ctypes.data), C.c_void_p(bo.ctypes.data))
         wd, bd = torch.from_numpy(wp).cuda(), torch.from_numpy(bo).cuda()
@@ -38,7 +41,7 @@ for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8,
     info = (C.c_int32 * 4)()
     lib.rsg_basic_chain_supported(Cc, H, W, L, Bn, info)
     nblk = info[3]
-    stamps = torch.zeros(nblk * 8 * 32, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(nblk * 16 * 32, dtype=torch.int64, device="cuda")
     lib.rsg_chain_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
     lib.rsg_basic_chain_workspace_bytes.restype = C.c_size_t
     wsp = torch.empty(max(lib.rsg_basic_chain_workspace_bytes(Cc, H, W, L, Bn), 16), dtype=torch.uint8, device="cuda")
@@ -53,7 +56,7 @@ for Cc, H, W, L in ((32, 64, 48, 4), (64, 32, 24, 4), (128, 16, 12, 4), (256, 8,
     lib.rsg_basic_chain(*args)
     e1.record()
     torch.cuda.synchronize()
-    sw = stamps.cpu().numpy().reshape(nblk, 8, 32).astype(np.float64)
+    sw = stamps.cpu().numpy().reshape(nblk, 16, 32).astype(np.float64)
     nw = int(np.count_nonzero(sw[nblk // 2, :, 0]))
     blk = nblk // 2
     t0 = sw[blk, 0, 0]
