@@ -18,6 +18,7 @@ writes, later writers add" decisions are taken in execution order.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -70,6 +71,8 @@ class TrainPlan:
         self._sink: Dict[str, Optional[list]] = {"fwd": None, "bwd": None}
         self._region: Optional[Tuple[int, int]] = None
         self._rid = 0
+        self._shared_rids: set = set()
+        self._defer: Optional[list] = None
         self._bn_momentum, self._bn_eps = 0.1, 1e-5
         self._params = [p for p in model.parameters() if p.requires_grad]
         self._sig: Optional[Tuple[int, ...]] = None
@@ -113,8 +116,12 @@ class TrainPlan:
         else:
             self._ops.append(op)
 
-    def _begin_lanes(self, n: int):
+    def _begin_lanes(self, n: int, shared: bool = False):
+        """shared: the lanes read common inputs (the fuse paths of a module all start from the branch outputs), so
+        their gradient contributions meet; the backward pass then adds them after the lanes' launches (_record_backward)."""
         self._rid += 1
+        if shared:
+            self._shared_rids.add(self._rid)
         self._region = (self._rid, 0)
         self._region_ops = [[] for _ in range(n)]
         self._region_fwd = [[] for _ in range(n)]
@@ -400,19 +407,30 @@ class TrainPlan:
             self._end_lanes()
         if mod.fuse_layers is None:
             return xs
+        # the fuse paths (i <- j) are independent of each other: recorded as lanes, so that the k-th conv / BatchNorm of
+        # every path (and, in the backward pass, their weight / data gradients) share grouped launches
+        paths = [(i, j) for i, row in enumerate(mod.fuse_layers) for j in range(len(row)) if j != i]
+        lanes = self.use_lanes and len(paths) > 1 and os.environ.get("RSGNET_HIP_TRAIN_FUSE_LANES", "1") != "0"
+        done: Dict[Tuple[int, int], T] = {}
+        if lanes:
+            self._begin_lanes(len(paths), shared=True)
+        for k, (i, j) in enumerate(paths):
+            if lanes:
+                self._lane(k)
+            fl = mod.fuse_layers[i][j]
+            if j > i:
+                done[(i, j)] = self.unit(xs[j], fl[0], fl[1], False, f"{name}.fuse.{i}.{j}")
+            else:
+                t = xs[j]
+                for q, step in enumerate(fl):
+                    t = self.unit(t, step[0], step[1], q != len(fl) - 1, f"{name}.fuse.{i}.{j}.{q}")
+                done[(i, j)] = t
+        if lanes:
+            self._end_lanes()
         outs = []
         for i, row in enumerate(mod.fuse_layers):
-            same, low = [], []
-            for j, fl in enumerate(row):
-                if j == i:
-                    same.append(xs[j])
-                elif j > i:
-                    low.append((self.unit(xs[j], fl[0], fl[1], False, f"{name}.fuse.{i}.{j}"), j - i))
-                else:
-                    t = xs[j]
-                    for k, step in enumerate(fl):
-                        t = self.unit(t, step[0], step[1], k != len(fl) - 1, f"{name}.fuse.{i}.{j}.{k}")
-                    same.append(t)
+            same = [done[(i, j)] for j in range(i)] + [xs[i]]
+            low = [(done[(i, j)], j - i) for j in range(i + 1, len(row))]
             outs.append(self.fuse_sum(same, low, f"{name}.fuse.{i}"))
         return outs
 
@@ -421,6 +439,9 @@ class TrainPlan:
         """`src` (a gradient of t) joins t.grad: the first one becomes it, later ones are added.  A buffer that several
         maps alias (`shared`) is never written in place."""
         if not t.needs_grad:
+            return
+        if self._defer is not None:              # lanes with common inputs: summed after the lanes' launches
+            self._defer.append((t, src, shared, name))
             return
         if t.grad is None:
             t.grad, t.grad_shared = src, shared
@@ -439,12 +460,25 @@ class TrainPlan:
         bucket: Dict[int, list] = {}             # lane -> backward launches of the lanes' ops at the current position
         cur_key = None
 
+        pending: list = []                        # gradient contributions of lanes with common inputs (see _contribute)
+
+        def rank(rec):
+            # spread (zero insertion), weight gradients, data gradients / BatchNorm, the rest (adds): every lane's own
+            # order is a subsequence of this one, and launches of one kind end up adjacent, where _merge groups them
+            name, gkind = rec[0], rec[2] or ""
+            return 0 if name.endswith(".spread") else 1 if gkind.startswith("wgrad") else \
+                2 if gkind in ("conv", "bn_bwd") or name.endswith(".dgrad") else 3
+
         def flush():
             nonlocal bucket
+            self._sink["bwd"], self._defer = None, None
             if bucket:
-                self._sink["bwd"] = None
-                self.bwd.extend(self._merge(self._zip([bucket[k] for k in sorted(bucket, reverse=True)])))
+                recs = self._zip([bucket[k] for k in sorted(bucket, reverse=True)])
+                self.bwd.extend(self._merge(sorted(recs, key=rank)))
                 bucket = {}
+            for args in pending:
+                self._contribute(*args)
+            pending.clear()
 
         for op in reversed(self._ops):
             kind, name = op["kind"], op["name"]
@@ -454,6 +488,7 @@ class TrainPlan:
                 flush()
                 cur_key = key
             self._sink["bwd"] = bucket.setdefault(reg[1], []) if reg is not None else None
+            self._defer = pending if reg is not None and reg[0] in self._shared_rids else None
             self._bwd_lane = reg[1] if reg is not None else 0
             if kind == "final":
                 x, fl = op["x"], op["m"]
@@ -516,7 +551,7 @@ class TrainPlan:
                 if x.needs_grad:
                     self._dgrad(x, y.grad, m.weight, O, k, stride, y.H, y.W, name)
         flush()
-        self._sink["bwd"] = None
+        self._sink["bwd"], self._defer = None, None
         # Segments of the backward list for the data-parallel overlap: cut where the pass leaves stage 4 and stage 3 (the
         # two stages hold 93 % of the parameters, and the flat gradient buffer keeps parameters in forward order, so
         # what is final after a segment is a tail of that buffer).  After each segment the model's grad_ready_hooks

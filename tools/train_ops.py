@@ -38,6 +38,10 @@ for which, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
             evs.append((rec[0], e0, e1))
         torch.cuda.synchronize()
     rows += [(e0.elapsed_time(e1) * 1e3, which, nm) for nm, e0, e1 in evs]
+if os.environ.get("TRAIN_OPS_JSON"):          # every launch in execution order
+    import json
+    with open(os.environ["TRAIN_OPS_JSON"], "w") as f:
+        json.dump([dict(us=round(us, 2), phase=which, op=nm) for us, which, nm in rows], f)
 rows.sort(reverse=True)
 for us, which, nm in rows[:25]:
     print(f"{us:8.1f} us  {which}  {nm}")
