@@ -15,6 +15,7 @@
 // in a fixed order, the slices' partial tiles go to a workspace and a second kernel sums them in slice order into
 // dW (fp32, nn.Conv2d layout): no atomics, bit-reproducible.
 #include "common.h"
+#include <algorithm>
 
 #define NLD 8            // staging loads in flight per thread
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -379,8 +380,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradRedu
 struct WgradPlan { WgradArgs a; int lds, grid, ntaps; };
 static int g_wgrad_quad = 1;       // RSGNET_HIP_WGRAD_QUAD=0: the one-pair form everywhere (A/B)
 
-static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int out_w, int cout_pad, int kh, int kw, int stride,
-                      int pad, WgradPlan& p, int target_wgs = 512) {
+// Slice policy (rsg_wgrad_tune): every (tile pair, slice) writes a taps x 4 KB partial tile that the reduce kernel
+// reads back, so a slice must own enough pixels to be worth it.  g_wgrad_min_px: lower bound on the pixels per slice
+// (0 = none); g_wgrad_quad_min_wgs: the 2x2 form only where it still gives this many workgroups, else one pair per
+// workgroup (four times the columns, a quarter of the partial bytes per workgroup).
+static int g_wgrad_min_px = 0;
+static int g_wgrad_quad_min_wgs = 0;
+static int g_wgrad_lds_budget = 128 * 1024;  // LDS per workgroup = chunk size.  Same-visit sweep of the training step: 44 KB 16.66 ms,
+                                             // 72 KB (two workgroups per CU) 15.77, 96 KB 15.73, 128 KB 15.41: larger chunks beat more workgroups
+static int g_wgrad_px_cap = 768;             // output pixels of a chunk (128 KB: 512 -> 15.39 ms, 640 15.20, 768 14.66, 896 14.72, 1024 14.79)
+
+static int wgrad_plan_form(int batch, int in_h, int in_w, int cin_pad, int out_h, int out_w, int cout_pad, int kh, int kw, int stride,
+                           int pad, WgradPlan& p, int target_wgs, int quad, bool sizing = false) {
     memset(&p, 0, sizeof(p));
     if (!((kh == 3 && kw == 3 && pad == 1) || (kh == 1 && kw == 1 && pad == 0)) || (stride != 1 && stride != 2)) return 1;
     if (cin_pad % 8 || cout_pad % 8 || batch < 1) return 1;
@@ -391,12 +402,12 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
     a.n_ot = ceil_div(cout_pad, 32); a.n_it = ceil_div(cin_pad, 32);
     a.xcols = in_w + 2 * pad;
     p.ntaps = kh * kw;
-    a.quad = (a.n_ot >= 2 && a.n_it >= 2 && g_wgrad_quad) ? 1 : 0;
+    a.quad = quad;
     const int pitch = a.quad ? 144 : 64;
     const int red_bytes = a.quad ? 0 : 2 * p.ntaps * 16 * 64 * 4;
-    const int budget = 72 * 1024;                           // two workgroups per CU
+    const int budget = g_wgrad_lds_budget;
     int rb = 0;
-    for (int r = max(1, min(out_h, 512 / out_w)); r >= 1; --r) {
+    for (int r = max(1, min(out_h, g_wgrad_px_cap / out_w)); r >= 1; --r) {
         const int p16 = round_up(r * out_w, 16), xr = (r - 1) * stride + kh;
         if (p16 * pitch + xr * a.xcols * pitch + p16 * 4 <= budget) { rb = r; break; }
     }
@@ -405,7 +416,7 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
     a.xrows = (rb - 1) * stride + kh;
     a.nimg = 1;
     if (a.nbands == 1) {                                    // small maps: several whole images per chunk
-        for (int n = min(batch, 512 / max(1, out_h * out_w)); n >= 2; --n) {
+        for (int n = min(batch, g_wgrad_px_cap / max(1, out_h * out_w)); n >= 2; --n) {
             const int p16 = round_up(n * out_h * out_w, 16);
             if (p16 * pitch + n * a.xrows * a.xcols * pitch + p16 * 4 <= budget) { a.nimg = n; break; }
         }
@@ -419,17 +430,43 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
     const int cols = a.quad ? ceil_div(a.n_ot, 2) * ceil_div(a.n_it, 2) : a.n_ot * a.n_it;
     const int chunks = a.nimg > 1 ? ceil_div(batch, a.nimg) : batch * a.nbands;
     a.nslices = max(1, min(chunks, ceil_div(target_wgs, cols)));
+    if (g_wgrad_min_px > 0 && !sizing) a.nslices = max(1, min(a.nslices, (int)((long long)batch * out_h * out_w / g_wgrad_min_px)));
     p.grid = cols * a.nslices;
     return 0;
+}
+
+static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int out_w, int cout_pad, int kh, int kw, int stride,
+                      int pad, WgradPlan& p, int target_wgs = 512) {
+    const bool can_quad = ceil_div(cout_pad, 32) >= 2 && ceil_div(cin_pad, 32) >= 2 && g_wgrad_quad;
+    if (can_quad) {
+        if (!wgrad_plan_form(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p, target_wgs, 1) &&
+            p.grid >= g_wgrad_quad_min_wgs)
+            return 0;
+    }
+    return wgrad_plan_form(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p, target_wgs, 0);
+}
+
+extern "C" void rsg_wgrad_tune(int32_t min_px_per_slice, int32_t quad_min_wgs, int32_t lds_budget, int32_t px_cap) {
+    if (px_cap >= 64 && px_cap <= 4096) g_wgrad_px_cap = px_cap;
+    g_wgrad_min_px = min_px_per_slice > 0 ? min_px_per_slice : 0;
+    g_wgrad_quad_min_wgs = quad_min_wgs > 0 ? quad_min_wgs : 0;
+    if (lds_budget >= 16 * 1024 && lds_budget <= 144 * 1024) g_wgrad_lds_budget = lds_budget;
 }
 
 extern "C" void rsg_wgrad_set_quad(int32_t on) { g_wgrad_quad = on ? 1 : 0; }
 
 extern "C" size_t rsg_conv_wgrad_workspace_bytes(int32_t batch, int32_t in_h, int32_t in_w, int32_t cin_pad, int32_t out_h,
                                                  int32_t out_w, int32_t cout_pad, int32_t kh, int32_t kw, int32_t stride, int32_t pad) {
+    // the larger of the two forms at the single launch's slice count: whatever the policy (rsg_wgrad_tune, the grouped
+    // launch's smaller target) picks later needs no more
     WgradPlan p;
-    if (wgrad_plan(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p)) return 0;
-    return (size_t)p.a.n_ot * p.a.n_it * p.a.nslices * p.ntaps * 1024 * sizeof(float);
+    size_t need = 0;
+    for (int quad = 0; quad < 2; ++quad) {
+        if (quad && !(ceil_div(cout_pad, 32) >= 2 && ceil_div(cin_pad, 32) >= 2)) continue;
+        if (wgrad_plan_form(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p, 512, quad, true)) continue;
+        need = std::max(need, (size_t)p.a.n_ot * p.a.n_it * p.a.nslices * p.ntaps * 1024 * sizeof(float));
+    }
+    return need;
 }
 
 extern "C" int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* workspace, int32_t batch, int32_t in_h, int32_t in_w,
