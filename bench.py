@@ -27,10 +27,13 @@ GFLOP_PER_IMG = {"hrnet_w32_256x192": 15.29, "rsgnet_w32_256x192_coco": 17.80,  
 PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
 
 
-def pmc_traffic(kernel_key):
+def pmc_traffic(kernel_key, workload="hrnet_w32_256x192"):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/*_pmc_summary.json:
-    FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), or None."""
+    FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), or None.  The passes are
+    collected on the headline workload only (tools/gpu_pmc.sh); every other workload reports null."""
     import glob
+    if workload != "hrnet_w32_256x192":
+        return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
         return None
@@ -454,7 +457,7 @@ def main():
             # on the launch stream, per-launch pass after the timed region)
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel"),
+                         "traffic": pmc_traffic("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel", a.workload),
                          "algorithmic_mb_per_launch": dom.get("alg_mb_per_launch"),
                          "kernel": dom_name, "launches": dom["launches"], "kernel_us_per_step": dom["us"],
                          "kernel_gflop_per_step": dom["gflop"],
