@@ -106,11 +106,13 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0, gpu_model=None):
             sd0 = synth_state_dict(m0.state_dict(), 0, regime="init")
             m0.load_state_dict(sd0)
             m0 = m0.eval().to(next(gpu_model.parameters()).device)
+            m0.compute_dtype = gpu_model.compute_dtype
             r0 = po.hrnet_forward(sd0, cfg, x)
             with torch.no_grad():
                 g0 = m0(x.to(next(m0.parameters()).device)).float().cpu()
             out["heatmap_max_abs_err_random_init"] = {"value": float(f"{(g0 - r0).abs().max().item():.3e}"), "bar": 1e-3,
                                                       "ref_abs_max": float(f"{r0.abs().max().item():.3e}"),
+                                                      "dtype": gpu_model.compute_dtype,
                                                       "config": "BASELINE configs[0]: random-init HRNet-W32 256x192, batch 4"}
     return out
 
@@ -323,6 +325,9 @@ def main():
     ap.add_argument("--workload", default="hrnet_w32_256x192", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the metric's 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
+                    help="16-bit storage / MFMA operand type of the inference plan (fp32 accumulation either way).  fp16 is the "
+                         "default because the 1e-3 heat-map bar needs its mantissa (DESIGN.md section 6); bf16 runs the same kernels")
     ap.add_argument("--flip-test", action="store_true",
                     help="a step = flip-tested heatmaps: one forward over [x ; x mirrored] + the fused merge")
     ap.add_argument("--pipeline", action="store_true",
@@ -363,6 +368,7 @@ def main():
     if a.batch:
         batch = a.batch
     model = model.to(dev)
+    model.compute_dtype = a.dtype
     x = synth_input(batch, wh, seed=rank).to(dev)          # resident in HBM before the timed region
 
     joints = WORKLOADS[a.workload][3]
