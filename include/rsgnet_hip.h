@@ -403,8 +403,8 @@ void rsg_wgrad_set_quad(int32_t on);
 /* slice policy of the weight gradient: at least `min_px_per_slice` output pixels per slice (0 = no bound), and the 2x2
  * form only where it still launches `quad_min_wgs` workgroups (else one tile pair per workgroup); lds_budget_bytes: LDS per
  * workgroup (16..144 KB; sets the chunk size and how many workgroups share a compute unit; other values keep the current one); chunk_px_cap: output pixels
- * of a chunk (64..4096, else unchanged) */
-void rsg_wgrad_tune(int32_t min_px_per_slice, int32_t quad_min_wgs, int32_t lds_budget_bytes, int32_t chunk_px_cap);
+ * of a chunk (64..4096, else unchanged); waves: 4 or 8 waves per workgroup of the 2x2 form (else unchanged) */
+void rsg_wgrad_tune(int32_t min_px_per_slice, int32_t quad_min_wgs, int32_t lds_budget_bytes, int32_t chunk_px_cap, int32_t waves);
 
 /* ---- crop producer ---------------------------------------------------------------
  * One person box per entry: `cv2.warpAffine(img, trans, (out_w, out_h), flags=INTER_LINEAR)` (constant border 0)

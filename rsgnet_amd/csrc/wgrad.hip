@@ -185,22 +185,27 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int block, 
 // slices in two workgroups each), every wave walks ALL k-steps of the chunk for its own pair, so there is no cross-wave add
 // through LDS and twice the MFMA work per staged byte.  Pixel pitch 144 B (64 channels + 16): the four rows of a transposed
 // read then start 36 banks apart.
-template <class DT, int NT>
+// NW = 8: two waves per tile pair (two per SIMD), taking alternate k-steps; their tiles are added through LDS in a fixed order
+// (wave w += wave w + 4) before the partial tile is written.  Twice the loads in flight while staging, and a second wave to
+// run MFMAs while the first waits for its transposed LDS reads.
+template <class DT, int NT, int NW = 4>
 __device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int block, char* smem) {
-    constexpr int PSQ = 144;
+    constexpr int PSQ = 144, NTHR = 64 * NW, KPAR = NW / 4;
+    constexpr int NLQ = NW == 8 ? 4 : NLD;                  // staging loads in flight per thread (512 threads: the same bytes in flight)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pw = wave & 3, kpar = wave >> 2;                // tile pair of this wave, its k-step parity
     const int nq_i = (a.n_it + 1) >> 1;
     const int quad = block / a.nslices, slice = block - quad * a.nslices;
     const int oq = quad / nq_i, iq = quad - oq * nq_i;
-    const int ot = oq * 2 + (wave >> 1), it = iq * 2 + (wave & 1);
+    const int ot = oq * 2 + (pw >> 1), it = iq * 2 + (pw & 1);
     const bool active = ot < a.n_ot && it < a.n_it;          // wave-uniform
     char* const sdy = smem;                                   // [P16][144 B]
     char* const sx = smem + a.P16 * PSQ;                      // [xrows * xcols][144 B]
     int* const soff = reinterpret_cast<int*>(sx + a.nimg * a.xrows * a.xcols * PSQ);
     const int grp = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
     const int cb = 16 * (grp & 1), kb = 8 * (grp >> 1);
-    const int col_a = (cb + 4 * pp) * 2 + (wave >> 1) * 64, col_b = (cb + 4 * pp) * 2 + (wave & 1) * 64;
+    const int col_a = (cb + 4 * pp) * 2 + (pw >> 1) * 64, col_b = (cb + 4 * pp) * 2 + (pw & 1) * 64;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -219,17 +224,17 @@ __device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int bl
         __syncthreads();
         {
             const char* src = a.dy + ((size_t)(b * a.Hout + r0) * a.Wout) * a.CoutP * 2 + oq * 128;
-            for (int base = 0; base < a.P16 * 8; base += 256 * NLD) {
-                uint4 v[NLD];
+            for (int base = 0; base < a.P16 * 8; base += NTHR * NLQ) {
+                uint4 v[NLQ];
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) {
-                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                for (int j = 0; j < NLQ; ++j) {
+                    const int i = base + j * NTHR + tid, p = i >> 3, c8 = i & 7;
                     v[j] = make_uint4(0, 0, 0, 0);
                     if (i < a.P16 * 8 && p < P && oq * 64 + c8 * 8 < a.CoutP) v[j] = *reinterpret_cast<const uint4*>(src + (size_t)p * a.CoutP * 2 + c8 * 16);
                 }
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) {
-                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                for (int j = 0; j < NLQ; ++j) {
+                    const int i = base + j * NTHR + tid, p = i >> 3, c8 = i & 7;
                     if (i < a.P16 * 8) *reinterpret_cast<uint4*>(sdy + p * PSQ + c8 * 16) = v[j];
                 }
             }
@@ -237,11 +242,11 @@ __device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int bl
         {
             const int iy0 = r0 * a.stride - a.pad;
             const int npix = nim * xtile;
-            for (int base = 0; base < npix * 8; base += 256 * NLD) {
-                uint4 v[NLD];
+            for (int base = 0; base < npix * 8; base += NTHR * NLQ) {
+                uint4 v[NLQ];
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) {
-                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                for (int j = 0; j < NLQ; ++j) {
+                    const int i = base + j * NTHR + tid, p = i >> 3, c8 = i & 7;
                     const int im = p / xtile, pr = p - im * xtile;
                     const int ry = pr / a.xcols, cx = pr - ry * a.xcols;
                     const int iy = iy0 + ry, ix = cx - a.pad;
@@ -250,13 +255,13 @@ __device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int bl
                         v[j] = *reinterpret_cast<const uint4*>(a.x + ((size_t)((b + im) * a.Hin + iy) * a.Win + ix) * a.CinP * 2 + iq * 128 + c8 * 16);
                 }
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) {
-                    const int i = base + j * 256 + tid, p = i >> 3, c8 = i & 7;
+                for (int j = 0; j < NLQ; ++j) {
+                    const int i = base + j * NTHR + tid, p = i >> 3, c8 = i & 7;
                     if (i < npix * 8) *reinterpret_cast<uint4*>(sx + p * PSQ + c8 * 16) = v[j];
                 }
             }
         }
-        for (int p = tid; p < a.P16; p += 256) {
+        for (int p = tid; p < a.P16; p += NTHR) {
             int o = 0;
             if (p < P) {
                 const int im = a.nimg > 1 ? p / opix : 0, pr = p - im * opix;
@@ -268,7 +273,7 @@ __device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int bl
         __syncthreads();
         const int ksteps = (P + 15) >> 4;
         if (active) {
-            for (int ks = 0; ks < ksteps; ++ks) {
+            for (int ks = kpar; ks < ksteps; ks += KPAR) {
                 const int pix0 = ks * 16 + kb + q, pix1 = pix0 + 4;
                 const s16x4 a0 = tr_read(sdy, pix0 * PSQ + col_a), a1 = tr_read(sdy, pix1 * PSQ + col_a);
                 const s16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -284,6 +289,31 @@ __device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int bl
             }
         }
     }
+    if constexpr (NW == 8) {
+        // wave w += wave w + 4, a few taps at a time (4 waves x TB taps x 4 KB of LDS)
+        constexpr int TB = NT >= 5 ? 5 : NT;
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += TB) {
+            __syncthreads();                                  // staging tiles (first round) / the previous round are done with
+            if (kpar == 1) {
+#pragma unroll
+                for (int t = 0; t < TB; ++t)
+                    if (t0 + t < NT)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[((pw * TB + t) * 16 + r) * 64 + lane] = acc[t0 + t < NT ? t0 + t : 0][r];
+            }
+            __syncthreads();
+            if (kpar == 0) {
+#pragma unroll
+                for (int t = 0; t < TB; ++t)
+                    if (t0 + t < NT)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t0 + t < NT ? t0 + t : 0][r] += red[((pw * TB + t) * 16 + r) * 64 + lane];
+            }
+        }
+        if (kpar == 1) return;
+    }
     if (!active) return;
     float* dst = a.part + ((size_t)(ot * a.n_it + it) * a.nslices + slice) * NT * 1024;
     const int col = lane & 31, hh = lane >> 5;
@@ -293,11 +323,14 @@ __device__ __forceinline__ void wgrad_quad_body(const WgradArgs& a, const int bl
         for (int r = 0; r < 16; ++r) dst[t * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + col] = acc[t][r];
 }
 
-template <class DT, int NT>
-__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
+template <class DT, int NT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (a.quad) wgrad_quad_body<DT, NT>(a, blockIdx.x, smem);
-    else wgrad_body<DT, NT>(a, blockIdx.x, smem);
+    if (a.quad) wgrad_quad_body<DT, NT, NW>(a, blockIdx.x, smem);
+    else {
+        if (NW == 8 && threadIdx.x >= 256) return;       // the one-pair form runs four waves
+        wgrad_body<DT, NT>(a, blockIdx.x, smem);
+    }
 }
 
 // Up to 4 independent weight gradients (the same conv position of a HighResolutionModule's branches) in one launch
@@ -307,8 +340,8 @@ struct WgradGroupArgs {
     int first[RSG_WGRAD_GROUP_MAX + 1];
     WgradArgs a[RSG_WGRAD_GROUP_MAX];
 };
-template <class DT, int NT>
-__global__ void __launch_bounds__(256) wgrad_group_kernel(const WgradGroupArgs g) {
+template <class DT, int NT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) wgrad_group_kernel(const WgradGroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int idx = 0;
 #pragma unroll
@@ -318,8 +351,11 @@ __global__ void __launch_bounds__(256) wgrad_group_kernel(const WgradGroupArgs g
 #pragma unroll
     for (int k = 0; k < RSG_WGRAD_GROUP_MAX; ++k)
         if (k == idx) { a = g.a[k]; block = (int)blockIdx.x - g.first[k]; }
-    if (a.quad) wgrad_quad_body<DT, NT>(a, block, smem);
-    else wgrad_body<DT, NT>(a, block, smem);
+    if (a.quad) wgrad_quad_body<DT, NT, NW>(a, block, smem);
+    else {
+        if (NW == 8 && threadIdx.x >= 256) return;
+        wgrad_body<DT, NT>(a, block, smem);
+    }
 }
 
 // dW[o][i][t] = sum over slices of part[(ot, it)][slice][t][o % 32][i % 32], in a fixed order: a workgroup owns a
@@ -388,6 +424,7 @@ static int g_wgrad_min_px = 0;
 static int g_wgrad_quad_min_wgs = 0;
 static int g_wgrad_lds_budget = 128 * 1024;  // LDS per workgroup = chunk size.  Same-visit sweep of the training step: 44 KB 16.66 ms,
                                              // 72 KB (two workgroups per CU) 15.77, 96 KB 15.73, 128 KB 15.41: larger chunks beat more workgroups
+static int g_wgrad_waves = 8;                // waves per workgroup of the 2x2 form (rsg_wgrad_tune): 4, or 8 = two per tile pair
 static int g_wgrad_px_cap = 768;             // output pixels of a chunk (128 KB: 512 -> 15.39 ms, 640 15.20, 768 14.66, 896 14.72, 1024 14.79)
 
 static int wgrad_plan_form(int batch, int in_h, int in_w, int cin_pad, int out_h, int out_w, int cout_pad, int kh, int kw, int stride,
@@ -422,7 +459,8 @@ static int wgrad_plan_form(int batch, int in_h, int in_w, int cin_pad, int out_h
         }
     }
     a.P16 = round_up(a.nimg * rb * out_w, 16);
-    p.lds = max(a.P16 * pitch + a.nimg * a.xrows * a.xcols * pitch + a.P16 * 4, red_bytes);
+    const int red8 = (a.quad && g_wgrad_waves == 8) ? 4 * (p.ntaps >= 5 ? 5 : p.ntaps) * 4096 : 0;   // wgrad_quad_body<.., 8>
+    p.lds = max(max(a.P16 * pitch + a.nimg * a.xrows * a.xcols * pitch + a.P16 * 4, red_bytes), red8);
     // pixel slices per workgroup column (a tile pair, or a 2x2 block of pairs): enough workgroups to fill the chip (2 per
     // CU), but every slice pays a fixed price (a taps x 4 KB partial tile per pair written and read back; the one-pair form
     // also its cross-wave add through LDS), so a slice should own several chunks when the columns alone already give
@@ -446,7 +484,8 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
     return wgrad_plan_form(batch, in_h, in_w, cin_pad, out_h, out_w, cout_pad, kh, kw, stride, pad, p, target_wgs, 0);
 }
 
-extern "C" void rsg_wgrad_tune(int32_t min_px_per_slice, int32_t quad_min_wgs, int32_t lds_budget, int32_t px_cap) {
+extern "C" void rsg_wgrad_tune(int32_t min_px_per_slice, int32_t quad_min_wgs, int32_t lds_budget, int32_t px_cap, int32_t waves) {
+    if (waves == 4 || waves == 8) g_wgrad_waves = waves;
     if (px_cap >= 64 && px_cap <= 4096) g_wgrad_px_cap = px_cap;
     g_wgrad_min_px = min_px_per_slice > 0 ? min_px_per_slice : 0;
     g_wgrad_quad_min_wgs = quad_min_wgs > 0 ? quad_min_wgs : 0;
@@ -483,11 +522,12 @@ extern "C" int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
     p.a.x = (const char*)x; p.a.dy = (const char*)dy; p.a.part = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
     void (*fn)(const WgradArgs) = nullptr;
-    if (dtype == RSG_BF16) fn = p.ntaps == 9 ? wgrad_kernel<BF16, 9> : wgrad_kernel<BF16, 1>;
-    else fn = p.ntaps == 9 ? wgrad_kernel<F16, 9> : wgrad_kernel<F16, 1>;
+    const bool w8 = g_wgrad_waves == 8;
+    if (dtype == RSG_BF16) fn = p.ntaps == 9 ? (w8 ? wgrad_kernel<BF16, 9, 8> : wgrad_kernel<BF16, 9>) : (w8 ? wgrad_kernel<BF16, 1, 8> : wgrad_kernel<BF16, 1>);
+    else fn = p.ntaps == 9 ? (w8 ? wgrad_kernel<F16, 9, 8> : wgrad_kernel<F16, 9>) : (w8 ? wgrad_kernel<F16, 1, 8> : wgrad_kernel<F16, 1>);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds) != hipSuccess)
         RSG_FAIL("conv_wgrad: cannot reserve %d B of LDS", p.lds);
-    RSG_LAUNCH(fn, dim3(p.grid), dim3(256), p.lds, s, p.a);
+    RSG_LAUNCH(fn, dim3(p.grid), dim3(w8 ? 512 : 256), p.lds, s, p.a);
     RSG_LAUNCH(wgrad_reduce_kernel, dim3(p.a.n_ot * p.a.n_it * p.ntaps * 4), dim3(256), 0, s, (const float*)workspace, dw, cout, cin,
                p.ntaps, p.a.n_it, p.a.nslices);
     RSG_CHECK_LAUNCH("conv_wgrad");
@@ -529,11 +569,12 @@ extern "C" int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int3
     g.first[n] = blocks; r.first[n] = rblocks; r.ntaps = ntaps;
     hipStream_t s = (hipStream_t)stream;
     void (*fn)(const WgradGroupArgs) = nullptr;
-    if (dtype == RSG_BF16) fn = ntaps == 9 ? wgrad_group_kernel<BF16, 9> : wgrad_group_kernel<BF16, 1>;
-    else fn = ntaps == 9 ? wgrad_group_kernel<F16, 9> : wgrad_group_kernel<F16, 1>;
+    const bool w8 = g_wgrad_waves == 8;
+    if (dtype == RSG_BF16) fn = ntaps == 9 ? (w8 ? wgrad_group_kernel<BF16, 9, 8> : wgrad_group_kernel<BF16, 9>) : (w8 ? wgrad_group_kernel<BF16, 1, 8> : wgrad_group_kernel<BF16, 1>);
+    else fn = ntaps == 9 ? (w8 ? wgrad_group_kernel<F16, 9, 8> : wgrad_group_kernel<F16, 9>) : (w8 ? wgrad_group_kernel<F16, 1, 8> : wgrad_group_kernel<F16, 1>);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         RSG_FAIL("conv_wgrad_group: cannot reserve %d B of LDS", lds);
-    RSG_LAUNCH(fn, dim3(blocks), dim3(256), lds, s, g);
+    RSG_LAUNCH(fn, dim3(blocks), dim3(w8 ? 512 : 256), lds, s, g);
     RSG_LAUNCH(wgrad_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, r);
     RSG_CHECK_LAUNCH("conv_wgrad_group");
     return 0;

@@ -148,7 +148,7 @@ SYMBOLS = {
     "rsg_conv_wgrad": (C.c_int, [_vp, _vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "rsg_conv_wgrad_group": (C.c_int, [C.POINTER(WgradItem), _i, _i, _vp]),
     "rsg_wgrad_set_quad": (None, [_i]),
-    "rsg_wgrad_tune": (None, [_i, _i, _i, _i]),
+    "rsg_wgrad_tune": (None, [_i, _i, _i, _i, _i]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
@@ -182,9 +182,10 @@ def lib() -> C.CDLL:
                          ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows")):
             if os.environ.get(env):
                 l.rsg_tune(key, int(os.environ[env]))
-        if any(os.environ.get("RSGNET_HIP_WGRAD_" + k) for k in ("MIN_PX", "QUAD_MIN_WGS", "LDS", "PX_CAP")):
+        if any(os.environ.get("RSGNET_HIP_WGRAD_" + k) for k in ("MIN_PX", "QUAD_MIN_WGS", "LDS", "PX_CAP", "WAVES")):
             l.rsg_wgrad_tune(int(os.environ.get("RSGNET_HIP_WGRAD_MIN_PX", "0")), int(os.environ.get("RSGNET_HIP_WGRAD_QUAD_MIN_WGS", "0")),
-                             int(os.environ.get("RSGNET_HIP_WGRAD_LDS", "0")), int(os.environ.get("RSGNET_HIP_WGRAD_PX_CAP", "0")))
+                             int(os.environ.get("RSGNET_HIP_WGRAD_LDS", "0")), int(os.environ.get("RSGNET_HIP_WGRAD_PX_CAP", "0")),
+                             int(os.environ.get("RSGNET_HIP_WGRAD_WAVES", "0")))
         if os.environ.get("RSGNET_HIP_WGRAD_QUAD"):
             l.rsg_wgrad_set_quad(int(os.environ["RSGNET_HIP_WGRAD_QUAD"]))
         _lib = l
