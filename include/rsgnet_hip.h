@@ -398,6 +398,12 @@ typedef struct rsg_wgrad_item {
     int32_t batch, in_h, in_w, cin, cin_pad, out_h, out_w, cout, cout_pad, kh, kw, stride, pad, reserved;
 } rsg_wgrad_item;
 int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int32_t dtype, void* stream);
+/* Pipelined form: one launch = the main kernel of `items` + (in its first workgroups) the partial-tile reduction of `prev`,
+ * a group whose main kernel ran in an earlier call on this stream with defer_reduce = 1.  defer_reduce = 0 appends this
+ * group's own reduction as a second launch (= rsg_conv_wgrad_group); n = 0 runs only prev's reduction.  The workspaces of
+ * `items` and `prev` must be disjoint (they are in use at the same time). */
+int rsg_conv_wgrad_group_ex(const rsg_wgrad_item* items, int32_t n, const rsg_wgrad_item* prev, int32_t n_prev,
+                            int32_t defer_reduce, int32_t dtype, void* stream);
 /* experiment switch (process-wide): 0 = every weight gradient in the one-tile-pair-per-workgroup form */
 void rsg_wgrad_set_quad(int32_t on);
 /* slice policy of the weight gradient: at least `min_px_per_slice` output pixels per slice (0 = no bound), and the 2x2

@@ -340,24 +340,6 @@ struct WgradGroupArgs {
     int first[RSG_WGRAD_GROUP_MAX + 1];
     WgradArgs a[RSG_WGRAD_GROUP_MAX];
 };
-template <class DT, int NT, int NW = 4>
-__global__ void __launch_bounds__(64 * NW) wgrad_group_kernel(const WgradGroupArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int idx = 0;
-#pragma unroll
-    for (int k = 1; k < RSG_WGRAD_GROUP_MAX; ++k) idx += (k < g.n && (int)blockIdx.x >= g.first[k]) ? 1 : 0;
-    WgradArgs a;
-    int block = 0;
-#pragma unroll
-    for (int k = 0; k < RSG_WGRAD_GROUP_MAX; ++k)
-        if (k == idx) { a = g.a[k]; block = (int)blockIdx.x - g.first[k]; }
-    if (a.quad) wgrad_quad_body<DT, NT, NW>(a, block, smem);
-    else {
-        if (NW == 8 && threadIdx.x >= 256) return;
-        wgrad_body<DT, NT>(a, block, smem);
-    }
-}
-
 // dW[o][i][t] = sum over slices of part[(ot, it)][slice][t][o % 32][i % 32], in a fixed order: a workgroup owns a
 // quarter (256 elements) of one (pair, tap) tile; lane l of slice group sg (4 groups) adds the float4 l of slices
 // sg, sg+4, ... and the four group sums are added in group order through LDS.  Every read is a coalesced 1 KB row.
@@ -401,16 +383,51 @@ struct WgradReduceGroupArgs {
     float* dw[RSG_WGRAD_GROUP_MAX];
     int cout[RSG_WGRAD_GROUP_MAX], cin[RSG_WGRAD_GROUP_MAX], n_it[RSG_WGRAD_GROUP_MAX], nslices[RSG_WGRAD_GROUP_MAX];
 };
-__global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradReduceGroupArgs g) {
+__device__ __forceinline__ void wgrad_reduce_group_body(const WgradReduceGroupArgs& g, const int blk) {
     int idx = 0;
 #pragma unroll
-    for (int k = 1; k < RSG_WGRAD_GROUP_MAX; ++k) idx += (k < g.n && (int)blockIdx.x >= g.first[k]) ? 1 : 0;
+    for (int k = 1; k < RSG_WGRAD_GROUP_MAX; ++k) idx += (k < g.n && blk >= g.first[k]) ? 1 : 0;
     const float* part = nullptr; float* dw = nullptr;
     int cout = 0, cin = 0, n_it = 0, nslices = 0, block = 0;
 #pragma unroll
     for (int k = 0; k < RSG_WGRAD_GROUP_MAX; ++k)
-        if (k == idx) { part = g.part[k]; dw = g.dw[k]; cout = g.cout[k]; cin = g.cin[k]; n_it = g.n_it[k]; nslices = g.nslices[k]; block = (int)blockIdx.x - g.first[k]; }
+        if (k == idx) { part = g.part[k]; dw = g.dw[k]; cout = g.cout[k]; cin = g.cin[k]; n_it = g.n_it[k]; nslices = g.nslices[k]; block = blk - g.first[k]; }
     wgrad_reduce_body(part, dw, cout, cin, g.ntaps, n_it, nslices, block);
+}
+__global__ void __launch_bounds__(256) wgrad_reduce_group_kernel(const WgradReduceGroupArgs g) {
+    wgrad_reduce_group_body(g, (int)blockIdx.x);
+}
+
+// The main kernel of one group may carry the REDUCTION of the previous group (pipelined form, rsg_conv_wgrad_group_ex): the
+// first r.first[r.n] workgroups sum the previous launch's partial tiles (bandwidth work, no LDS) while the others stage
+// and multiply (latency-bound, one per CU for its LDS) -- the reduction rides along instead of holding the stream.
+template <class DT, int NT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) wgrad_group_kernel(const WgradGroupArgs g, const WgradReduceGroupArgs r) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // grid order: the first `lead` main workgroups (one per CU: they take the LDS), then the reduction blocks (no LDS: they
+    // fit beside them), then the other main workgroups.  The dispatcher works in order: with the reduction in front the main
+    // workgroups would wait for it to be dispatched, behind them it would wait for LDS to come free.
+    const int nred = r.n ? r.first[r.n] : 0, lead = min(g.first[g.n], 256);
+    int bid = (int)blockIdx.x;
+    if (bid >= lead && bid < lead + nred) {
+        if (threadIdx.x >= 256) return;
+        wgrad_reduce_group_body(r, bid - lead);
+        return;
+    }
+    if (bid >= lead) bid -= nred;
+    int idx = 0;
+#pragma unroll
+    for (int k = 1; k < RSG_WGRAD_GROUP_MAX; ++k) idx += (k < g.n && bid >= g.first[k]) ? 1 : 0;
+    WgradArgs a;
+    int block = 0;
+#pragma unroll
+    for (int k = 0; k < RSG_WGRAD_GROUP_MAX; ++k)
+        if (k == idx) { a = g.a[k]; block = bid - g.first[k]; }
+    if (a.quad) wgrad_quad_body<DT, NT, NW>(a, block, smem);
+    else {
+        if (NW == 8 && threadIdx.x >= 256) return;
+        wgrad_body<DT, NT>(a, block, smem);
+    }
 }
 
 struct WgradPlan { WgradArgs a; int lds, grid, ntaps; };
@@ -424,6 +441,7 @@ static int g_wgrad_min_px = 0;
 static int g_wgrad_quad_min_wgs = 0;
 static int g_wgrad_lds_budget = 128 * 1024;  // LDS per workgroup = chunk size.  Same-visit sweep of the training step: 44 KB 16.66 ms,
                                              // 72 KB (two workgroups per CU) 15.77, 96 KB 15.73, 128 KB 15.41: larger chunks beat more workgroups
+static int g_wgrad_group_wgs = 0;            // workgroups a grouped launch aims at in total; 0 = as many as fit one round (rsg_wgrad_tune: min_px slot < 0 sets -value)
 static int g_wgrad_waves = 8;                // waves per workgroup of the 2x2 form (rsg_wgrad_tune): 4, or 8 = two per tile pair
 static int g_wgrad_px_cap = 768;             // output pixels of a chunk (128 KB: 512 -> 15.39 ms, 640 15.20, 768 14.66, 896 14.72, 1024 14.79)
 
@@ -487,6 +505,7 @@ static int wgrad_plan(int batch, int in_h, int in_w, int cin_pad, int out_h, int
 extern "C" void rsg_wgrad_tune(int32_t min_px_per_slice, int32_t quad_min_wgs, int32_t lds_budget, int32_t px_cap, int32_t waves) {
     if (waves == 4 || waves == 8) g_wgrad_waves = waves;
     if (px_cap >= 64 && px_cap <= 4096) g_wgrad_px_cap = px_cap;
+    if (min_px_per_slice < 0) { g_wgrad_group_wgs = -min_px_per_slice; min_px_per_slice = 0; }      // experiment: total workgroups of a grouped launch
     g_wgrad_min_px = min_px_per_slice > 0 ? min_px_per_slice : 0;
     g_wgrad_quad_min_wgs = quad_min_wgs > 0 ? quad_min_wgs : 0;
     if (lds_budget >= 16 * 1024 && lds_budget <= 144 * 1024) g_wgrad_lds_budget = lds_budget;
@@ -535,47 +554,120 @@ extern "C" int rsg_conv_wgrad(const void* x, const void* dy, float* dw, void* wo
 }
 
 
-extern "C" int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int32_t dtype, void* stream) {
-    if (!items || n < 1 || n > RSG_WGRAD_GROUP_MAX) RSG_FAIL("conv_wgrad_group: 1..%d items", RSG_WGRAD_GROUP_MAX);
-    WgradGroupArgs g;
-    WgradReduceGroupArgs r;
-    memset(&g, 0, sizeof(g));
-    memset(&r, 0, sizeof(r));
-    g.n = r.n = n;
-    int lds = 0, blocks = 0, rblocks = 0, ntaps = 0;
+// Compute units of the current device (cached per device id); 256 when the query fails.
+static int wgrad_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int v = 0;
+        cus[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return cus[dev];
+}
+
+// Fills the main-kernel table (g) and the reduction table (r) of one group of weight gradients.
+static int wgrad_group_tables(const rsg_wgrad_item* items, int n, const char* what, WgradGroupArgs* g, WgradReduceGroupArgs& r,
+                              int& lds, int& blocks, int& rblocks, int& ntaps, bool pipelined) {
+    if (!items || n < 1 || n > RSG_WGRAD_GROUP_MAX) RSG_FAIL("%s: 1..%d items", what, RSG_WGRAD_GROUP_MAX);
     for (int k = 0; k < n; ++k) {
         const rsg_wgrad_item& it = items[k];
-        if (!it.x || !it.dy || !it.dw || !it.workspace) RSG_FAIL("conv_wgrad_group: item %d: null pointer", k);
-        if (((uintptr_t)it.x | (uintptr_t)it.dy | (uintptr_t)it.workspace) & 15) RSG_FAIL("conv_wgrad_group: item %d: alignment", k);
-        if (it.cin < 1 || it.cin > it.cin_pad || it.cout < 1 || it.cout > it.cout_pad) RSG_FAIL("conv_wgrad_group: item %d: channels", k);
-        WgradPlan p;
-        // the group fills the chip together: fewer, longer slices per item (a quarter of the partial tiles to write,
-        // read back and add; the workspace of rsg_conv_wgrad_workspace_bytes is sized for the single launch's 512)
-        if (wgrad_plan(it.batch, it.in_h, it.in_w, it.cin_pad, it.out_h, it.out_w, it.cout_pad, it.kh, it.kw, it.stride, it.pad, p,
-                       max(128, 768 / n)))
-            RSG_FAIL("conv_wgrad_group: item %d: unsupported geometry", k);
+        if (!it.x || !it.dy || !it.dw || !it.workspace) RSG_FAIL("%s: item %d: null pointer", what, k);
+        if (((uintptr_t)it.x | (uintptr_t)it.dy | (uintptr_t)it.workspace) & 15) RSG_FAIL("%s: item %d: alignment", what, k);
+        if (it.cin < 1 || it.cin > it.cin_pad || it.cout < 1 || it.cout > it.cout_pad) RSG_FAIL("%s: item %d: channels", what, k);
         if ((long long)it.batch * it.in_h * it.in_w * it.cin_pad * 2 >= (1LL << 31) || (long long)it.batch * it.out_h * it.out_w * it.cout_pad * 2 >= (1LL << 31))
-            RSG_FAIL("conv_wgrad_group: item %d: map too large for 32-bit offsets", k);
-        if (k && p.ntaps != ntaps) RSG_FAIL("conv_wgrad_group: every item must have the same kernel size");
+            RSG_FAIL("%s: item %d: map too large for 32-bit offsets", what, k);
+    }
+    // Slices per item.  A workgroup holds a whole CU (128 KB of LDS), so a launch runs in rounds of one workgroup per CU
+    // and a round that is not full costs as much as a full one: the largest per-item target (never above the 512 the
+    // workspaces are sized for) whose workgroups still fit ONE round -- three quarters of a round when the launch also
+    // carries the previous group's reduction (pipelined form), whose blocks then find free CUs from the start.  Same-visit
+    // sweeps of the training step by total workgroups of a 4-item launch, pipelined: 768 (the first policy) 13.72 ms,
+    // 320 13.63, 288 13.75, 256 13.25-13.37, 224 13.19, 192 13.03-13.07, 160 13.50; not pipelined: 256 13.40, 192 13.75.
+    auto total_for = [&](int target) {
+        int tot = 0;
+        for (int k = 0; k < n; ++k) {
+            const rsg_wgrad_item& it = items[k];
+            WgradPlan p;
+            if (wgrad_plan(it.batch, it.in_h, it.in_w, it.cin_pad, it.out_h, it.out_w, it.cout_pad, it.kh, it.kw, it.stride, it.pad, p, target)) return -1;
+            tot += p.grid;
+        }
+        return tot;
+    };
+    int target = min(512, max(16, g_wgrad_group_wgs / n));
+    if (g_wgrad_group_wgs == 0) {                            // default: fit one round
+        const int cus = pipelined ? wgrad_device_cus() * 3 / 4 : wgrad_device_cus();
+        int lo = 1, hi = 512;                                // total_for is monotonic in the target
+        if (total_for(lo) < 0) RSG_FAIL("%s: unsupported geometry", what);
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (total_for(mid) <= cus) lo = mid; else hi = mid - 1;
+        }
+        target = lo;
+    }
+    if (g) memset(g, 0, sizeof(*g));
+    memset(&r, 0, sizeof(r));
+    if (g) g->n = n;
+    r.n = n;
+    lds = 0; blocks = 0; rblocks = 0; ntaps = 0;
+    for (int k = 0; k < n; ++k) {
+        const rsg_wgrad_item& it = items[k];
+        WgradPlan p;
+        if (wgrad_plan(it.batch, it.in_h, it.in_w, it.cin_pad, it.out_h, it.out_w, it.cout_pad, it.kh, it.kw, it.stride, it.pad, p, target))
+            RSG_FAIL("%s: item %d: unsupported geometry", what, k);
+        if (k && p.ntaps != ntaps) RSG_FAIL("%s: every item must have the same kernel size", what);
         ntaps = p.ntaps;
         p.a.x = (const char*)it.x; p.a.dy = (const char*)it.dy; p.a.part = (float*)it.workspace;
-        g.a[k] = p.a;
-        g.first[k] = blocks; blocks += p.grid;
+        if (g) { g->a[k] = p.a; g->first[k] = blocks; }
+        blocks += p.grid;
         lds = max(lds, p.lds);
         r.part[k] = (const float*)it.workspace; r.dw[k] = it.dw; r.cout[k] = it.cout; r.cin[k] = it.cin;
         r.n_it[k] = p.a.n_it; r.nslices[k] = p.a.nslices;
         r.first[k] = rblocks; rblocks += p.a.n_ot * p.a.n_it * p.ntaps * 4;
     }
-    g.first[n] = blocks; r.first[n] = rblocks; r.ntaps = ntaps;
+    if (g) g->first[n] = blocks;
+    r.first[n] = rblocks; r.ntaps = ntaps;
+    return 0;
+}
+
+// Pipelined form: ONE launch runs the main kernel of `items` and, in its first workgroups, the reduction of `prev`
+// (a group whose main kernel ran in an EARLIER launch on this stream with defer_reduce set).  defer_reduce = 1 leaves
+// this group's partial tiles in its workspaces for the next call; 0 appends its reduction as a second launch, as
+// rsg_conv_wgrad_group does.  items == NULL (n = 0): only prev's reduction.  prev's workspaces must not be workspaces
+// of `items` (the two run concurrently).
+extern "C" int rsg_conv_wgrad_group_ex(const rsg_wgrad_item* items, int32_t n, const rsg_wgrad_item* prev, int32_t n_prev,
+                                       int32_t defer_reduce, int32_t dtype, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    void (*fn)(const WgradGroupArgs) = nullptr;
+    WgradReduceGroupArgs rp;
+    memset(&rp, 0, sizeof(rp));
+    int plds = 0, pblocks = 0, prb = 0, ptaps = 0;
+    // a group that deferred its reduction was planned as pipelined (below): the same plan again
+    if (n_prev > 0 && wgrad_group_tables(prev, n_prev, "conv_wgrad_group_ex(prev)", nullptr, rp, plds, pblocks, prb, ptaps, true)) return 1;
+    if (n <= 0 || !items) {
+        if (n_prev > 0) RSG_LAUNCH(wgrad_reduce_group_kernel, dim3(prb), dim3(256), 0, s, rp);
+        RSG_CHECK_LAUNCH("conv_wgrad_group_ex");
+        return 0;
+    }
+    WgradGroupArgs g;
+    WgradReduceGroupArgs r;
+    int lds = 0, blocks = 0, rblocks = 0, ntaps = 0;
+    if (wgrad_group_tables(items, n, "conv_wgrad_group", &g, r, lds, blocks, rblocks, ntaps, defer_reduce || n_prev > 0)) return 1;
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n_prev; ++j)
+            if (items[k].workspace == prev[j].workspace) RSG_FAIL("conv_wgrad_group_ex: item %d shares its workspace with the group being reduced", k);
+    void (*fn)(const WgradGroupArgs, const WgradReduceGroupArgs) = nullptr;
     const bool w8 = g_wgrad_waves == 8;
     if (dtype == RSG_BF16) fn = ntaps == 9 ? (w8 ? wgrad_group_kernel<BF16, 9, 8> : wgrad_group_kernel<BF16, 9>) : (w8 ? wgrad_group_kernel<BF16, 1, 8> : wgrad_group_kernel<BF16, 1>);
     else fn = ntaps == 9 ? (w8 ? wgrad_group_kernel<F16, 9, 8> : wgrad_group_kernel<F16, 9>) : (w8 ? wgrad_group_kernel<F16, 1, 8> : wgrad_group_kernel<F16, 1>);
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
         RSG_FAIL("conv_wgrad_group: cannot reserve %d B of LDS", lds);
-    RSG_LAUNCH(fn, dim3(blocks), dim3(w8 ? 512 : 256), lds, s, g);
-    RSG_LAUNCH(wgrad_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, r);
+    RSG_LAUNCH(fn, dim3(blocks + prb), dim3(w8 ? 512 : 256), lds, s, g, rp);
+    if (!defer_reduce) RSG_LAUNCH(wgrad_reduce_group_kernel, dim3(rblocks), dim3(256), 0, s, r);
     RSG_CHECK_LAUNCH("conv_wgrad_group");
     return 0;
+}
+
+extern "C" int rsg_conv_wgrad_group(const rsg_wgrad_item* items, int32_t n, int32_t dtype, void* stream) {
+    if (!items || n < 1) RSG_FAIL("conv_wgrad_group: 1..%d items", RSG_WGRAD_GROUP_MAX);
+    return rsg_conv_wgrad_group_ex(items, n, nullptr, 0, 0, dtype, stream);
 }

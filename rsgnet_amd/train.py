@@ -50,6 +50,35 @@ class T:
         return self.data.shape[0] * self.H * self.W
 
 
+class _WgradLaunch:
+    """One grouped weight-gradient launch (rsg_conv_wgrad_group_ex).  Linked in execution order by TrainPlan._link_wgrads:
+    a launch defers the reduction of its partial tiles to the NEXT weight-gradient launch, which runs it in its first
+    workgroups next to its own main kernel (workspaces alternate between two sets, `par`); the last one of a backward
+    segment reduces its own."""
+
+    def __init__(self, plan: "TrainPlan", makers: list):
+        self.plan, self.makers, self.n = plan, makers, len(makers)
+        self.items = (hip.WgradItem * self.n)()
+        self.prev: Optional["_WgradLaunch"] = None
+        self.prev_items = None
+        self.par, self.defer = 0, False
+
+    def link(self, prev: "_WgradLaunch"):
+        self.prev, prev.defer = prev, True
+        self.prev_items = (hip.WgradItem * prev.n)()
+
+    def __call__(self, s: int):
+        for k, mk in enumerate(self.makers):     # addresses are read at launch time (a re-seated parameter re-captures)
+            mk(self.items[k], self.par)
+        n_prev = 0
+        if self.prev is not None:
+            for k, mk in enumerate(self.prev.makers):
+                mk(self.prev_items[k], self.prev.par)
+            n_prev = self.prev.n
+        self.plan._chk(self.plan.lib.rsg_conv_wgrad_group_ex(self.items, self.n, self.prev_items, n_prev, int(self.defer), BF16, s),
+                       "conv_wgrad_group")
+
+
 class TrainPlan:
     """Forward and backward launch lists of pose_hrnet in training mode for one (batch, device)."""
 
@@ -89,7 +118,9 @@ class TrainPlan:
         self.dheat = torch.zeros_like(self.heat)
         self._record(model)
         self._record_backward()
-        self._wgrad_lane_ws = {k: torch.empty(max(v, 16), dtype=torch.uint8, device=device) for k, v in self._wgrad_lane_need.items()}
+        self._wgrad_lane_ws = {(par, k): torch.empty(max(v, 16), dtype=torch.uint8, device=device)
+                               for k, v in self._wgrad_lane_need.items() for par in (0, 1)}
+        self._link_wgrads()
         self._build_pack_table()
         self._bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
         self._nbt = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
@@ -162,6 +193,8 @@ class TrainPlan:
             if j - i >= 2:
                 out.append((f"{name}(+{j - i - 1})", self._group_launch(gkind, [r[3] for r in recs[i:j]]), None, None,
                             tuple(q for r in recs[i:j] for q in r[4])))
+            elif gkind is not None and gkind.startswith("wgrad"):
+                out.append((name, _WgradLaunch(self, [item]), None, None, recs[i][4]))
             else:
                 out.append(recs[i])
                 j = i + 1
@@ -181,14 +214,7 @@ class TrainPlan:
             tptr, blocks, lds = table.ctypes.data, launch2[0], launch2[1]
             return lambda s: self._chk(lib.rsg_conv_fuse_group_run(tptr, blocks, lds, BF16, s), "conv group")
         if gkind.startswith("wgrad"):
-            warr = (hip.WgradItem * n)()
-            self._keep.append(warr)
-
-            def wlaunch(s):
-                for k, mk in enumerate(makers):
-                    mk(warr[k])
-                self._chk(lib.rsg_conv_wgrad_group(warr, n, BF16, s), "conv_wgrad_group")
-            return wlaunch
+            return _WgradLaunch(self, makers)
         arr = (hip.BnItem * n)()
         self._keep.append(arr)
 
@@ -572,6 +598,22 @@ class TrainPlan:
                 done.update(id(q) for q in rec[4])
             self._pending_after.append([q for q in self._params if id(q) not in done])
 
+    def _link_wgrads(self):
+        """Chain the weight-gradient launches of every backward segment: each defers its partial-tile reduction to the next
+        one (which runs it beside its own main kernel), the last of a segment reduces its own -- gradients are final where
+        the segment ends, which is where grad_ready_hooks and the optimizer look."""
+        # Alone it is neutral (13.40 vs 13.37 ms: the two kernels compete for the same memory system); it pays together
+        # with main kernels that leave a quarter of the CUs to the reduction blocks (csrc/wgrad.hip, wgrad_group_tables):
+        # 13.40 -> 13.07 ms per step
+        if os.environ.get("RSGNET_HIP_TRAIN_WGRAD_PIPE", "1") == "0":
+            return
+        for lo, hi in self._bwd_segments:
+            chain = [rec[1] for rec in self.bwd[lo:hi] if isinstance(rec[1], _WgradLaunch)]
+            for k, wl in enumerate(chain):
+                wl.par = k & 1
+                if k:
+                    wl.link(chain[k - 1])
+
     def _wgrad(self, x: torch.Tensor, dy: torch.Tensor, w: torch.nn.Parameter, H, W, cin, cin_pad, Ho, Wo, cout, cout_pad, k, stride, name):
         lib, B, pad = self.lib, self.batch, (k - 1) // 2
         need = int(lib.rsg_conv_wgrad_workspace_bytes(B, H, W, cin_pad, Ho, Wo, cout_pad, k, k, stride, pad))
@@ -581,15 +623,12 @@ class TrainPlan:
         lane = self._bwd_lane                    # grouped launches run several weight gradients at once: a workspace per lane
         self._wgrad_lane_need[lane] = max(self._wgrad_lane_need.get(lane, 0), need)
 
-        def item(it):
-            it.x, it.dy, it.dw, it.workspace = x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_lane_ws[lane].data_ptr()
+        def item(it, par=0):
+            it.x, it.dy, it.dw, it.workspace = x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_lane_ws[(par, lane)].data_ptr()
             it.batch, it.in_h, it.in_w, it.cin, it.cin_pad = B, H, W, cin, cin_pad
             it.out_h, it.out_w, it.cout, it.cout_pad, it.kh, it.kw, it.stride, it.pad = Ho, Wo, cout, cout_pad, k, k, stride, pad
 
-        def launch(s):
-            self._chk(lib.rsg_conv_wgrad(x.data_ptr(), dy.data_ptr(), self._grad_of(w).data_ptr(), self._wgrad_lane_ws[lane].data_ptr(), B, H, W,
-                                         cin, cin_pad, Ho, Wo, cout, cout_pad, k, k, stride, pad, BF16, s), name + ".wgrad")
-
+        launch = _WgradLaunch(self, [item])      # replaced by a grouped launch where _merge finds neighbours of its kind
         self._emit("bwd", name + ".wgrad", launch, f"wgrad{k}", item, params=(w,))
 
     def _dgrad(self, x: T, dy: torch.Tensor, w: torch.nn.Parameter, dy_c: int, k: int, stride: int, Ho: int, Wo: int, name: str):

@@ -332,3 +332,30 @@ def test_grouped_batchnorm_and_wgrad_equal_the_single_launches():
     hip.check(lib.rsg_conv_wgrad_group(wi, n, BF, _stream()), "wgrad_group")
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(again, dws[0]))          # ... and reproducible bit for bit
+    # pipelined form: group A defers its reduction, the next launch (group B, other workspaces) carries it in its first
+    # workgroups; a launch without items flushes B.  Same gradients (another slice count), the same bits every time.
+    wss2 = [torch.empty_like(w) for w in wss]
+    dws2 = [torch.full_like(d, float("nan")) for d in dws[0]]
+    wj = (hip.WgradItem * n)()
+    for k in range(n):
+        for f, _t in hip.WgradItem._fields_:
+            setattr(wj[k], f, getattr(wi[k], f))
+        wj[k].dw, wj[k].workspace = dws2[k].data_ptr(), wss2[k].data_ptr()
+    outs = []
+    for rep in range(2):
+        for d in dws[0] + dws2:
+            d.fill_(float("nan"))
+        hip.check(lib.rsg_conv_wgrad_group_ex(wi, n, None, 0, 1, BF, _stream()), "wgrad_group_ex A")
+        torch.cuda.synchronize()
+        assert all(torch.isnan(d).all() for d in dws[0])                 # nothing reduced yet
+        hip.check(lib.rsg_conv_wgrad_group_ex(wj, n, wi, n, 1, BF, _stream()), "wgrad_group_ex B + reduce A")
+        hip.check(lib.rsg_conv_wgrad_group_ex(None, 0, wj, n, 0, BF, _stream()), "wgrad_group_ex flush B")
+        torch.cuda.synchronize()
+        for k in range(n):
+            ref = dws[1][k]
+            assert (dws[0][k] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), k
+            assert torch.equal(dws[0][k], dws2[k]), k                     # A and B: the same inputs through the same plan
+        outs.append([d.clone() for d in dws[0]])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # the group being reduced must not share workspaces with the one being computed
+    assert lib.rsg_conv_wgrad_group_ex(wi, n, wi, n, 1, BF, _stream()) != 0
