@@ -152,6 +152,12 @@ int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, cons
                     int32_t nlayers, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t dtype,
                     void* workspace, void* stream);
 size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch);
+/* c = 48 runs on the 16x16x32 MFMA (exactly 48 channels, csrc/chain48.h): ONE BasicBlock per launch (nlayers == 2), no
+ * hand-off flags or tail convs, and its layers are packed by rsg_pack_chain48_weights_host (w fp32 [48][48][3][3], BatchNorm
+ * scale / shift or NULL; rsg_chain48_packed_bytes() bytes of weights, 48 floats of bias) instead of
+ * rsg_pack_conv_weights_host. */
+size_t rsg_chain48_packed_bytes(void);
+int rsg_pack_chain48_weights_host(const float* w, const float* scale, const float* shift, int32_t dtype, void* wp_out, float* bias_out);
 int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
                               int32_t* info4);
 /* Up to 6 chains (the branches of one HighResolutionModule, pose_hrnet.py:254-255) in ONE launch; the

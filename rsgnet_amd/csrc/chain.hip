@@ -581,6 +581,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     RSG_STAMP(30);
 }
 
+#include "chain48.h"
+
+template <class DT>
+__global__ void __launch_bounds__(768) chain48_kernel(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    chain48_body<DT>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), smem);
+}
+
 template <class DT, int C, int WM, int WN, int NT, bool DUAL = false>
 __global__ void __launch_bounds__(64 * WM * WN) chain_kernel(const ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -674,7 +682,7 @@ __global__ void __launch_bounds__(RSG_CHAIN_WIDE_THREADS) chain_group_wide_kerne
     for (int j = 1; j < RSG_CHAIN_GROUP_MAX; ++j) i += (j < g.n && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
     const int bid = rsg_xcd_tile(blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);
     switch (g.c[i]) {
-        case 48: chain_body<DT, 48, 2, 6, 5>(g.a[i], bid, smem, pf); break;
+        case 48: chain48_body<DT>(g.a[i], bid, smem, pf); break;     // 16x16x32 MFMA, exactly 48 channels (chain48.h)
         case 96: chain_body<DT, 96, 3, 4, 5>(g.a[i], bid, smem, pf); break;
         case 192: chain_body<DT, 192, 6, 2, 4>(g.a[i], bid, smem, pf); break;
         case 384:   // NT follows the pixels a workgroup owns (the whole 12x9 map: 4 groups; one of its two row tiles: 3)
@@ -687,10 +695,10 @@ __global__ void __launch_bounds__(RSG_CHAIN_WIDE_THREADS) chain_group_wide_kerne
 // ------------------------------------------------------------------------------------------------
 struct ChainCfg { int C, WM, WN, NT; };
 static const ChainCfg kChainCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 1, 6}, {256, 8, 1, 3},
-                                      {48, 2, 6, 5}, {96, 3, 4, 5}, {192, 6, 2, 4}, {384, 12, 1, 4}};
+                                      {48, 2, 6, 6}, {96, 3, 4, 5}, {192, 6, 2, 4}, {384, 12, 1, 4}};
 // widest variants of the grouped launch (512 threads each; 768 for the HRNet-W48 widths)
 static const ChainCfg kChainGroupCfgs[] = {{32, 1, 8, 7}, {64, 2, 4, 6}, {128, 4, 2, 3}, {256, 8, 1, 3},
-                                           {48, 2, 6, 5}, {96, 3, 4, 5}, {192, 6, 2, 4}, {384, 12, 1, 4}};
+                                           {48, 2, 6, 6}, {96, 3, 4, 5}, {192, 6, 2, 4}, {384, 12, 1, 4}};
 static bool chain_is_wide(int C) { return C == 48 || C == 96 || C == 192 || C == 384; }
 static const int CHAIN_LDS_LIMIT = 160 * 1024;
 static const int kChainMaxNT = 8;      // workspace slots are sized for the widest variant (standalone or grouped)
@@ -738,7 +746,7 @@ static chain_fn chain_lookup(int C, int npix, int dual) {
         case 64: return chain_kernel<DT, 64, 2, 4, 6>;
         case 128: return chain_kernel<DT, 128, 4, 1, 6>;
         case 256: return chain_kernel<DT, 256, 8, 1, 3>;
-        case 48: return chain_kernel<DT, 48, 2, 6, 5>;
+        case 48: return chain48_kernel<DT>;
         case 96: return chain_kernel<DT, 96, 3, 4, 5>;
         case 192: return chain_kernel<DT, 192, 6, 2, 4>;
         case 384: return npix <= 96 ? chain_kernel<DT, 384, 12, 1, 3> : chain_kernel<DT, 384, 12, 1, 4>;
@@ -754,6 +762,7 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     for (const ChainCfg& c : (grouped ? kChainGroupCfgs : kChainCfgs)) if (c.C == C) cfg = &c;
     if (ni_want < 1) ni_want = g_chain_max_ni;
     if (!cfg) return 1;
+    if (C == 48 && nlayers != 2) return 1;               // chain48_body: one BasicBlock, the residual is the launch's own input
     const int cap = 32 * cfg->NT * cfg->WN;              // pixels a workgroup can own
     const int PS = 2 * C + 16;
     nthr = 64 * cfg->WM * cfg->WN;
@@ -950,7 +959,8 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
             a.bias[l] = it.bias[l];
         }
         // prefetch range: the item's layers when the caller packed them back to back (the plan does)
-        const size_t layer_bytes = (size_t)((it.c + 31) / 32 * 32) * it.c * 18;
+        const size_t layer_bytes = it.c == 48 ? (size_t)RSG_CHAIN48_KS * 3 * 64 * 16 : (size_t)it.c * it.c * 18;
+        if (it.c == 48 && (it.wait_flags || it.done_flags || it.ntails)) RSG_FAIL("chain_group: item %d: the 48-channel chain takes no hand-off flags or tail convs", i);
         bool contiguous = g_chain_prefetch != 0;
         for (int l = 1; l < it.nlayers; ++l)
             contiguous = contiguous && (const char*)it.w_packed[l] == (const char*)it.w_packed[0] + l * layer_bytes;
@@ -986,3 +996,29 @@ extern "C" int rsg_chain_set_stamp_buffer(void* dev_ptr) {
     return 0;
 }
 #endif
+
+// Weights of one layer of the 48-channel chain (chain48.h): w fp32 [48][48][3][3], BatchNorm folded like
+// rsg_pack_conv_weights_host (scale into the weights, shift into the bias; either may be NULL).
+// wp_out: 14 * 3 * 64 * 16 = 43008 bytes; bias_out: 48 floats.
+extern "C" size_t rsg_chain48_packed_bytes(void) { return (size_t)RSG_CHAIN48_KS * 3 * 64 * 16; }
+extern "C" int rsg_pack_chain48_weights_host(const float* w, const float* scale, const float* shift, int32_t dtype, void* wp_out, float* bias_out) {
+    if (!w || !wp_out || !bias_out) RSG_FAIL("pack_chain48: null pointer");
+    unsigned short* dst = (unsigned short*)wp_out;
+    for (int s = 0; s < RSG_CHAIN48_KS; ++s)
+        for (int m = 0; m < 3; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = 16 * m + (lane & 15), f = 32 * s + 8 * (lane >> 4) + j;
+                    float v = 0.f;
+                    if (f < 432) {
+                        const int tap = f / 48, ci = f % 48;
+                        v = w[((size_t)co * 48 + ci) * 9 + tap] * (scale ? scale[co] : 1.f);
+                    }
+                    unsigned short bits;
+                    if (dtype == RSG_BF16) { const BF16::elem e = BF16::from_f32(v); memcpy(&bits, &e, 2); }
+                    else { const F16::elem e = F16::from_f32(v); memcpy(&bits, &e, 2); }
+                    dst[(((size_t)s * 3 + m) * 64 + lane) * 8 + j] = bits;
+                }
+    for (int co = 0; co < 48; ++co) bias_out[co] = shift ? shift[co] : 0.f;
+    return 0;
+}

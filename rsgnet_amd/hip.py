@@ -149,6 +149,8 @@ SYMBOLS = {
     "rsg_conv_wgrad_group": (C.c_int, [C.POINTER(WgradItem), _i, _i, _vp]),
     "rsg_conv_wgrad_group_ex": (C.c_int, [C.POINTER(WgradItem), _i, C.POINTER(WgradItem), _i, _i, _i, _vp]),
     "rsg_wgrad_set_quad": (None, [_i]),
+    "rsg_chain48_packed_bytes": (C.c_size_t, []),
+    "rsg_pack_chain48_weights_host": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp]),
     "rsg_wgrad_tune": (None, [_i, _i, _i, _i, _i]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),

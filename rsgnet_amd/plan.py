@@ -226,6 +226,20 @@ class Plan:
         self._tmp = []
         return self._dev(wp), self._dev(bo), I, O
 
+    def pack_chain48(self, w: torch.Tensor, scale, shift) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One layer of the 48-channel chain (csrc/chain48.h): w fp32 [48,48,3,3] -> (weights, bias) on the device."""
+        w = w.detach().to("cpu", torch.float32).contiguous().numpy()
+        if w.shape != (48, 48, 3, 3):
+            raise ValueError(f"pack_chain48: weight of shape {w.shape}")
+        wp = np.empty(self.lib.rsg_chain48_packed_bytes(), dtype=np.uint8)
+        bo = np.empty(48, dtype=np.float32)
+        sc = None if scale is None else np.ascontiguousarray(scale.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(scale) else scale, dtype=np.float32)
+        sh = None if shift is None else np.ascontiguousarray(shift.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(shift) else shift, dtype=np.float32)
+        hip.check(self.lib.rsg_pack_chain48_weights_host(w.ctypes.data, sc.ctypes.data if sc is not None else None,
+                                                         sh.ctypes.data if sh is not None else None, self.dtype,
+                                                         wp.ctypes.data, bo.ctypes.data), "pack_chain48")
+        return self._dev(wp), self._dev(bo)
+
     @staticmethod
     def bn_fold(bn: Optional[nn.Module]):
         """eval-mode BatchNorm as (scale, shift) in fp64->fp32."""
@@ -404,7 +418,10 @@ class Plan:
             for blk in blocks:
                 for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
                     scale, shift = self.bn_fold(bn)
-                    wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
+                    if conv.in_channels == 48:           # the 48-channel chain (16x16x32 MFMA) has a pack of its own
+                        wp, bo = self.pack_chain48(conv.weight, scale, shift)
+                    else:
+                        wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
                     layers.append((wp, bo))
             # the layers of one chain back to back in memory: the grouped launch prefetches them as one range
             allw = torch.cat([w for w, _ in layers])

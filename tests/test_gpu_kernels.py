@@ -282,6 +282,20 @@ def test_trp_attention_project_tail_scores_mse():
     assert float((mse.cpu().double() - mref).abs().max()) < 1e-5
 
 
+def _pack_chain_layer(lib, w, scale, shift, Cc):
+    """One 3x3 Cc->Cc layer in the order its chain kernel reads (the 48-channel chain has a pack of its own)."""
+    if Cc == 48:
+        wp = np.zeros(lib.rsg_chain48_packed_bytes(), np.uint8)
+        bo = np.zeros(48, np.float32)
+        hip.check(lib.rsg_pack_chain48_weights_host(w.ctypes.data, scale.ctypes.data, shift.ctypes.data, 0, wp.ctypes.data, bo.ctypes.data))
+        return wp, bo
+    wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
+    bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
+    hip.check(lib.rsg_pack_conv_weights_host(w.ctypes.data, scale.ctypes.data, shift.ctypes.data, None, Cc, Cc, 3, 3, 0,
+                                             wp.ctypes.data, bo.ctypes.data))
+    return wp, bo
+
+
 @pytest.mark.parametrize("Cc,H,W,L", [(128, 16, 12, 8), (256, 8, 6, 8), (64, 32, 24, 8), (32, 64, 48, 2),
                                       (256, 8, 6, 2), (32, 30, 48, 2), (32, 64, 48, 4), (32, 64, 48, 8),
                                       (32, 61, 48, 4), (64, 32, 24, 4),
@@ -303,11 +317,8 @@ def test_basic_chain_matches_cpu(Cc, H, W, L):
     assert lib.rsg_basic_chain_supported(Cc, H, W, L, B, info) == 1
     keep, wps, bps = [], [], []
     for l in range(L):
-        wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
-        bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
         wn, sn, hn = ws[l].numpy(), scs[l].numpy(), shs[l].numpy()
-        hip.check(lib.rsg_pack_conv_weights_host(wn.ctypes.data, sn.ctypes.data, hn.ctypes.data, None, Cc, Cc, 3, 3,
-                                                 0, wp.ctypes.data, bo.ctypes.data))
+        wp, bo = _pack_chain_layer(lib, wn, sn, hn, Cc)
         wd, bd = torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
         keep += [wd, bd]
         wps.append(wd.data_ptr())
@@ -344,10 +355,7 @@ def _chain_layers(lib, Cc, L, seed):
         w = (torch.randn(Cc, Cc, 3, 3, generator=g) * (2.0 / (Cc * 9)) ** 0.5).numpy()
         sc = ((torch.rand(Cc, generator=g) * 0.4 + 0.1) if l % 2 else (torch.rand(Cc, generator=g) + 0.5)).numpy()
         sh = (torch.randn(Cc, generator=g) * 0.1).numpy()
-        wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
-        bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
-        hip.check(lib.rsg_pack_conv_weights_host(w.ctypes.data, sc.ctypes.data, sh.ctypes.data, None, Cc, Cc, 3, 3, 0,
-                                                 wp.ctypes.data, bo.ctypes.data))
+        wp, bo = _pack_chain_layer(lib, w, sc, sh, Cc)
         wd, bd = torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
         keep += [wd, bd]
         wps.append(wd.data_ptr())
