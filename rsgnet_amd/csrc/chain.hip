@@ -708,7 +708,7 @@ static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
 static int g_chain_debug = 0;      // rsg_tune("chain_debug", bits): experiments with WRONG results: 1 = every layer reads layer 0's weights, 2 = no block-input fetch, 4 = hand-off producers never signal (exercises the error word)
 static int g_chain_dual = 1;       // rsg_tune("chain_dual", 0|1): ping-pong LDS images for the whole-image chains that fit twice
 static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
-static int g_chain_split_rows = 0; // rsg_tune("chain_split_rows", 0|1): two row tiles for the 384-channel map at small batch (chain_geometry); measured neutral, off
+static int g_chain_split_rows = 1; // rsg_tune("chain_split_rows", 0|1): two row tiles for the 384-channel map at small batch (chain_geometry)
 static int chain_row_pitch(int C, int W) {
     const int PS = 2 * C + 16;
     return (W + 2) * PS + (g_chain_pitch_pad ? (256 - (2 * PS) % 256) % 256 : 0);
@@ -772,8 +772,9 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     // 384 channels, one BasicBlock, a small batch: whole images would occupy `batch` compute units for the longest
     // workgroups of the launch (12x9x384, batch 32: 112 us on 32 of 256 CUs while the other branches need ~90 us of the
     // rest).  Two row tiles with a 2-row halo do 1.5x the work on twice the CUs and shorten that critical path by a quarter.
-    // Same-visit A/B at batch 32: 5.152 vs 5.153 ms per step -- the launch is bound by the total work at the all-CU clock,
-    // not by this workgroup -- so the switch stays off.
+    // Same-visit A/B at batch 32: neutral (5.152 vs 5.153 ms per step) while the 48-channel chain made a stage-4 launch
+    // work-bound; with that branch on the 16x16x32 MFMA (chain48.h) the 384-channel workgroups are the critical path again
+    // and the split pays: 4.545 -> 4.449 ms.
     const bool split_rows = g_chain_split_rows && C == 384 && nlayers == 2 && H >= 8 && batch * 4 <= 256 &&
                             (H / 2 + nlayers) * W <= 96;
     if (!split_rows && H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
