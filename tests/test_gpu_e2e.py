@@ -95,13 +95,14 @@ def test_batch_sharding_is_invariant():
     assert torch.equal(full, halves)
 
 
-@pytest.mark.parametrize("name", ["hrnet_w32_256x192", "rsgnet_w32_256x192_coco"])
+@pytest.mark.parametrize("name", ["hrnet_w32_256x192", "rsgnet_w32_256x192_coco", "hrnet_w48_384x288"])
 def test_ragged_batches_agree_with_each_other(name):
     """Batches of 1, 3 and 7 crops (fewer workgroups than XCDs, odd tile counts, the last workgroup of a two-image
-    chain half empty) give, crop by crop, the bits a batch of 11 gives."""
+    chain half empty; HRNet-W48: the 12-wave chains, the 48-channel branch in padded buffers, row tiles whose count
+    depends on the batch) give, crop by crop, the bits a batch of 11 gives."""
     cfg, model, sd, x, gold = load_case(name)
     from rsgnet_amd.weights import synth_input
-    x11 = synth_input(11, (192, 256), 4).cuda()
+    x11 = synth_input(11, TAGS[name][2], 4).cuda()
     model = model.cuda()
     pick = (lambda o: o) if name.startswith("hrnet") else (lambda o: o[1])
     with torch.no_grad():
