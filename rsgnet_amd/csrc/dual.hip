@@ -1,0 +1,187 @@
+// transition1 of HRNet (pose_hrnet.py:336-375, forward :437-443): the two 3x3 convs that start branches 0 and 1 of stage 2
+// read the SAME 256-channel map (100 MB at batch 64) -- conv A at stride 1 (256 -> 32), conv B at stride 2 (256 -> 64).
+// As two rsg_conv_igemm launches that map is staged twice (52 + 34 us, both bound by the read).  Here one workgroup stages
+// a 16x16 tile (+ halo) per 64-channel block once and runs both contractions on it: conv A's 256 output pixels are two
+// pixel groups per wave, conv B's 8x8 outputs x 64 channels are four (pixel group, channel tile) jobs, one per wave, so
+// every wave issues the same number of MFMAs.  Conv B reads its B fragments at a two-pixel stride from the plain image
+// (a 2-way bank conflict on a third of the LDS reads; conv_igemm's stride-2 kernel de-interleaves the columns instead).
+// Same k order, same accumulation, same epilogue as rsg_conv_igemm: the results are bit-identical to the two launches.
+#include "conv_args.h"
+
+struct DualArgs {
+    const char* in;
+    const uint4* wA; const float* bA; char* outA;
+    const uint4* wB; const float* bB; char* outB;
+    int B, H, W, ldi;
+    int ldoA, storeA, ldoB;
+    int nchunks, tiles_x, tiles_y, RP;
+    int reluA, reluB;
+};
+
+template <class DT>
+__global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TH = 16, TW = 16, TIH = 18, TIW = 18, CINB = 64, PS = 2 * CINB + 16, CPP = CINB / 8, KPT = 4, KSB = 36, NT = 2;
+    constexpr int NLD = 8, NPF = 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hh = lane >> 5;
+    int bx = rsg_xcd_tile(blockIdx.x, gridDim.x);
+    const int tix = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int tiy = bx % p.tiles_y, b = bx / p.tiles_y;
+    const int y0 = tiy * TH, x0 = tix * TW;
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+
+    int pixA[NT], opixA[NT];
+#pragma unroll
+    for (int g = 0; g < NT; ++g) {
+        const int q = (wave * NT + g) * 32 + n, py = q / TW, px = q - py * TW;
+        pixA[g] = py * p.RP + px * PS + hh * 16;
+        opixA[g] = (y0 + py < p.H && x0 + px < p.W) ? (b * p.H + y0 + py) * p.W + x0 + px : -1;
+    }
+    // conv B: wave w owns channel tile w & 1 of the pixel group w >> 1 (8x8 stride-2 outputs of this tile)
+    const int ctB = wave & 1;
+    int pixB, opixB;
+    {
+        const int q = (wave >> 1) * 32 + n, py = q / (TW / 2), px = q - py * (TW / 2);
+        pixB = (2 * py) * p.RP + (2 * px) * PS + hh * 16;
+        opixB = (y0 / 2 + py < H2 && x0 / 2 + px < W2) ? (b * H2 + y0 / 2 + py) * W2 + x0 / 2 + px : -1;
+    }
+    auto bias16 = [&](const float* bp, f32x16& acc) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(bp + r4 * 4);
+            acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
+        }
+    };
+    f32x16 accA[NT], accB;
+    bias16(p.bA + hh * 16, accA[0]);
+    accA[1] = accA[0];
+    bias16(p.bB + ctB * 32 + hh * 16, accB);
+
+    const int KS = p.nchunks * KSB;
+    const uint4* apA = p.wA + lane;
+    const uint4* apB = p.wB + (size_t)ctB * KS * 64 + lane;
+    const int total = TIH * TIW * CPP;
+    const int iy0 = y0 - 1, ix0 = x0 - 1;
+    const size_t img = (size_t)b * p.H * p.W;
+    auto boff = [&](int ks) {
+        const int t = ks / KPT, c = ks % KPT;
+        return (t / 3) * p.RP + (t % 3) * PS + c * 32;
+    };
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const uint4* aA = apA + (size_t)ch * KSB * 64;
+        const uint4* aB = apB + (size_t)ch * KSB * 64;
+        uint4 aq[NPF];
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) aq[k] = aA[k * 64];
+        // ---- stage 64 channels of the input tile (+halo), zero outside the picture
+        for (int base = 0; base < total; base += 256 * NLD) {
+            uint4 r[NLD];
+            int lo[NLD];
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
+                const int id = base + j * 256 + tid;
+                r[j] = make_uint4(0, 0, 0, 0);
+                lo[j] = -1;
+                if (id < total) {
+                    const int pix = id / CPP, cg = id - pix * CPP;
+                    const int ty = pix / TIW, tx = pix - ty * TIW;
+                    const int iy = iy0 + ty, ix = ix0 + tx;
+                    lo[j] = ty * p.RP + tx * PS + cg * 16;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                        r[j] = *reinterpret_cast<const uint4*>(p.in + ((img + (size_t)iy * p.W + ix) * p.ldi + ch * CINB + cg * 8) * 2);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NLD; ++j)
+                if (lo[j] >= 0) *reinterpret_cast<uint4*>(smem + lo[j]) = r[j];
+        }
+        __syncthreads();
+        // ---- conv A: one scheduling region per k-step, A loads NPF steps ahead, LDS reads one step ahead
+        {
+            uint4 bq[2][NT];
+#pragma unroll
+            for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixA[g] + boff(0));
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+                if (ks + 1 < KSB) {
+#pragma unroll
+                    for (int g = 0; g < NT; ++g) bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixA[g] + boff(ks + 1));
+                }
+                // the ring runs on into conv B's fragments of the same channel block
+                aq[ks % NPF] = (ks + NPF < KSB) ? aA[(ks + NPF) * 64] : aB[(ks + NPF - KSB) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NT; ++g) accA[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), accA[g]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- conv B on the same staged tile
+        {
+            uint4 bq[2];
+            bq[0] = *reinterpret_cast<const uint4*>(smem + pixB + boff(0));
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+                if (ks + 1 < KSB) bq[(ks + 1) & 1] = *reinterpret_cast<const uint4*>(smem + pixB + boff(ks + 1));
+                if (ks + NPF < KSB) aq[ks % NPF] = aB[(ks + NPF) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+                accB = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1]), accB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ch + 1 < p.nchunks) __syncthreads();
+    }
+    // ---- epilogues: ReLU -> 16-bit NHWC
+    auto store = [&](const f32x16& acc, char* out, int opix, int ldo, int cbase, int nstore, int relu) {
+        if (opix < 0) return;
+        char* op = out + ((size_t)opix * ldo + cbase) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = relu ? fmaxf(acc[k * 8 + e], 0.f) : acc[k * 8 + e];
+            const typename DT::vec8 o = __builtin_convertvector(f, typename DT::vec8);
+            if (cbase + k * 8 < nstore) *reinterpret_cast<uint4*>(op + k * 16) = __builtin_bit_cast(uint4, o);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < NT; ++g) store(accA[g], p.outA, opixA[g], p.ldoA, hh * 16, p.storeA, p.reluA);
+    store(accB, p.outB, opixB, p.ldoB, ctB * 32 + hh * 16, 64, p.reluB);
+}
+
+// a: the stride-1 conv (3x3, pad 1, cin a multiple of 64, cout <= 32, 16-bit NHWC output, no residual); the stride-2 conv
+// reads the same input: wB/biasB packed for (cin, 64, 3x3), outB [batch, h/2, w/2, out_ld_b] (h, w even).
+extern "C" int rsg_conv_dual(const rsg_conv_desc* a, const void* wB_packed, const float* biasB, void* outB16, int32_t out_ld_b,
+                             int32_t relu_b, void* stream) {
+    if (!a || !a->in || !a->w_packed || !a->bias || !a->out16 || !wB_packed || !biasB || !outB16) RSG_FAIL("conv_dual: null pointer");
+    if (a->kh != 3 || a->kw != 3 || a->stride != 1 || a->pad_y != 1 || a->pad_x != 1 || a->in_c < 64 || a->in_c % 64 || a->out_c < 1 ||
+        a->out_c > 32 || a->residual || a->out_nchw_f32 || a->up != 1 || a->out_h != a->in_h || a->out_w != a->in_w)
+        RSG_FAIL("conv_dual: conv A must be 3x3 stride 1 pad 1 with cin a multiple of 64 and at most 32 output channels");
+    if ((a->in_h | a->in_w) & 1) RSG_FAIL("conv_dual: the map must have even height and width");
+    const int store = a->out_c_store ? a->out_c_store : 32;
+    if (a->in_ld < a->in_c || (a->in_ld & 7) || a->out_ld < store || (a->out_ld & 7) || store % 8 || store > 32 || out_ld_b < 64 || (out_ld_b & 7))
+        RSG_FAIL("conv_dual: strides");
+    if (((uintptr_t)a->in | (uintptr_t)a->w_packed | (uintptr_t)a->bias | (uintptr_t)a->out16 | (uintptr_t)wB_packed | (uintptr_t)biasB | (uintptr_t)outB16) & 15)
+        RSG_FAIL("conv_dual: pointers must be 16-byte aligned");
+    if ((long long)a->batch * a->in_h * a->in_w * a->in_ld * 2 >= (1LL << 31)) RSG_FAIL("conv_dual: map too large for 32-bit offsets");
+    DualArgs p;
+    p.in = (const char*)a->in; p.wA = (const uint4*)a->w_packed; p.bA = a->bias; p.outA = (char*)a->out16;
+    p.wB = (const uint4*)wB_packed; p.bB = biasB; p.outB = (char*)outB16;
+    p.B = a->batch; p.H = a->in_h; p.W = a->in_w; p.ldi = a->in_ld;
+    p.ldoA = a->out_ld; p.storeA = store; p.ldoB = out_ld_b;
+    p.nchunks = a->in_c / 64;
+    p.tiles_x = ceil_div(a->in_w, 16); p.tiles_y = ceil_div(a->in_h, 16);
+    const int PS = 144, base = 18 * PS;
+    p.RP = base + ((0 - base) % 256 + 256) % 256;          // == 16 * PS (mod 256): see conv_igemm.hip, tile_geometry
+    p.reluA = a->relu ? 1 : 0; p.reluB = relu_b ? 1 : 0;
+    const int lds = 18 * p.RP;
+    const dim3 grid(a->batch * p.tiles_x * p.tiles_y);
+    if (a->dtype == RSG_BF16) RSG_LAUNCH(conv_dual_kernel<BF16>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    else RSG_LAUNCH(conv_dual_kernel<F16>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    RSG_CHECK_LAUNCH("conv_dual");
+    return 0;
+}

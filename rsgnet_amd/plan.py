@@ -1088,6 +1088,49 @@ class _BackboneMixin:
         self.conv_log.append(dict(name="stem(conv1+conv2)", flops=float(fl)))
         return out
 
+    def _transition1_dual(self: Plan, ys: List[VT], trans) -> bool:
+        """transition1 as ONE launch (rsg_conv_dual): both new branches start with a 3x3 conv of the same 256-channel map."""
+        if os.environ.get("RSGNET_HIP_TRANS_DUAL", "1") == "0" or len(ys) != 1 or len(trans) != 2 or trans[0] is None or \
+                trans[1] is None or len(trans[1]) != 1:
+            return False
+        ca, cb, x = trans[0][0], trans[1][0][0], ys[0]
+        return ca.kernel_size == (3, 3) and ca.stride == (1, 1) and cb.kernel_size == (3, 3) and cb.stride == (2, 2) and \
+            ca.in_channels == cb.in_channels == x.C and x.C % 64 == 0 and ca.out_channels <= 32 and cb.out_channels == 64 and \
+            ca.bias is None and cb.bias is None and x.coff == 0 and x.H % 2 == 0 and x.W % 2 == 0
+
+    def conv_dual(self: Plan, x: VT, seq_a, seq_b, name: str) -> List[VT]:
+        """Record transition1 (pose_hrnet.py:437-443): conv-BN-ReLU at stride 1 and at stride 2 from the same map."""
+        ca, cb = seq_a[0], seq_b[0]
+        sa, ha = self.bn_fold(seq_a[1])
+        sb, hb = self.bn_fold(seq_b[1])
+        wa, ba, _i, Oa = self.pack_conv(ca.weight, sa, ha, None)
+        wb, bb, _i, Ob = self.pack_conv(cb.weight, sb, hb, None)
+        oa = self.new(x.H, x.W, _round_up(Oa, 32), name=name + ".a")
+        ob = self.new(x.H // 2, x.W // 2, Ob, name=name + ".b")
+        lib, B, dt = self.lib, self.batch, self.dtype
+
+        def make():
+            d = hip.ConvDesc()
+            d.inp, d.w_packed, d.bias, d.out16 = x.ptr(), wa.data_ptr(), ba.data_ptr(), oa.ptr()
+            d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, x.H, x.W, x.C, x.ld
+            d.out_h, d.out_w, d.out_c, d.out_ld = x.H, x.W, Oa, oa.ld
+            d.kh = d.kw = 3
+            d.stride, d.pad_y, d.pad_x = 1, 1, 1
+            d.up, d.phys_h, d.phys_w, d.relu, d.dtype = 1, x.H, x.W, 1, dt
+            self._keep.append(d)
+            ref, pb, pbb, pob, ldb = C.byref(d), wb.data_ptr(), bb.data_ptr(), ob.ptr(), ob.ld
+
+            def launch(stream):
+                rc = lib.rsg_conv_dual(ref, pb, pbb, pob, ldb, 1, stream)
+                if rc:
+                    hip.check(rc, name)
+            return launch
+        self.custom(name, [x], [oa, ob], make)
+        fl = 2 * B * x.C * 9 * (x.H * x.W * Oa + (x.H // 2) * (x.W // 2) * Ob)
+        self.flops += fl
+        self.conv_log.append(dict(name=name, flops=float(fl)))
+        return [oa, ob]
+
     def _unit(self: Plan, x: VT, conv: nn.Conv2d, bn, **kw) -> VT:
         return self.conv(x, conv.weight, bn, conv.bias, stride=conv.stride[0], **kw)
 
@@ -1395,6 +1438,9 @@ class _BackboneMixin:
         for s in (2, 3, 4):
             trans = getattr(m, f"transition{s - 1}")
             xs = []
+            if s == 2 and self._transition1_dual(ys, trans):
+                xs = self.conv_dual(ys[0], trans[0], trans[1][0], "transition1.0+1.0")
+                trans = []
             for i, tr in enumerate(trans):
                 if i < len(ys):
                     xs.append(ys[i] if tr is None else self._unit(ys[i], tr[0], tr[1], relu=True,
