@@ -137,12 +137,12 @@ int rsg_graph_launch(void* graph, void* stream);
 int rsg_graph_destroy(void* graph);
 
 /* transition1 of HRNet (pose_hrnet.py:336-375, :437-443) in one launch: `a` describes the stride-1 3x3 conv (pad 1, cin a
- * multiple of 64, at most 32 output channels, 16-bit NHWC output, BatchNorm folded, ReLU per a->relu, no residual); the
- * stride-2 3x3 conv of the second new branch reads the SAME input: wB_packed / biasB from rsg_pack_conv_weights_host
- * (cin, 64, 3x3), outB16 [batch, h/2, w/2, out_ld_b] (h, w even).  The input tile is staged once for both; results are
- * bit-identical to two rsg_conv_igemm launches. */
+ * multiple of 64, 16-bit NHWC output, BatchNorm folded, ReLU per a->relu, no residual); the stride-2 3x3 conv of the second
+ * new branch reads the SAME input: wB_packed / biasB from rsg_pack_conv_weights_host (cin, cout_b, 3x3), outB16
+ * [batch, h/2, w/2, out_ld_b] (h, w even).  Built for (a->out_c <= 32, cout_b = 64: HRNet-W32) and (a->out_c <= 64,
+ * cout_b = 96: HRNet-W48).  The input tile is staged once for both; results are bit-identical to two rsg_conv_igemm launches. */
 int rsg_conv_dual(const rsg_conv_desc* a, const void* wB_packed, const float* biasB, void* outB16, int32_t out_ld_b,
-                  int32_t relu_b, void* stream);
+                  int32_t cout_b, int32_t relu_b, void* stream);
 
 /* ---- fused BasicBlock chain -----------------------------------------------------------------
  * x = branches[i](x) of a HighResolutionModule (pose_hrnet.py:254-255): nlayers = 2*nblocks 3x3 convs

@@ -18,11 +18,14 @@ struct DualArgs {
     int reluA, reluB;
 };
 
-template <class DT>
+// CTA / CTB: 32-channel output tiles of conv A / conv B -- (1, 2) for HRNet-W32 (256 -> 32 and 256 -> 64), (2, 3) for
+// HRNet-W48 (256 -> 48 padded to 64, and 256 -> 96).  Conv A: a wave owns two pixel groups and all CTA tiles of them (one B
+// fragment feeds CTA MFMAs); conv B: 2 x CTB (pixel group, tile) jobs dealt to the four waves, job j = wave + 4 k.
+template <class DT, int CTA, int CTB>
 __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TH = 16, TW = 16, TIH = 18, TIW = 18, CINB = 64, PS = 2 * CINB + 16, CPP = CINB / 8, KPT = 4, KSB = 36, NT = 2;
-    constexpr int NLD = 8, NPF = 6;
+    constexpr int NLD = 8, NPF = 6, NJB = (2 * CTB + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hh = lane >> 5;
@@ -40,13 +43,14 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
         pixA[g] = py * p.RP + px * PS + hh * 16;
         opixA[g] = (y0 + py < p.H && x0 + px < p.W) ? (b * p.H + y0 + py) * p.W + x0 + px : -1;
     }
-    // conv B: wave w owns channel tile w & 1 of the pixel group w >> 1 (8x8 stride-2 outputs of this tile)
-    const int ctB = wave & 1;
-    int pixB, opixB;
-    {
-        const int q = (wave >> 1) * 32 + n, py = q / (TW / 2), px = q - py * (TW / 2);
-        pixB = (2 * py) * p.RP + (2 * px) * PS + hh * 16;
-        opixB = (y0 / 2 + py < H2 && x0 / 2 + px < W2) ? (b * H2 + y0 / 2 + py) * W2 + x0 / 2 + px : -1;
+    int pixB[NJB], opixB[NJB], ctB[NJB];
+#pragma unroll
+    for (int k = 0; k < NJB; ++k) {
+        const int j = wave + 4 * k;                           // wave-uniform
+        ctB[k] = j < 2 * CTB ? j % CTB : -1;
+        const int q = (j < 2 * CTB ? j / CTB : 0) * 32 + n, py = q / (TW / 2), px = q - py * (TW / 2);
+        pixB[k] = (2 * py) * p.RP + (2 * px) * PS + hh * 16;
+        opixB[k] = (j < 2 * CTB && y0 / 2 + py < H2 && x0 / 2 + px < W2) ? (b * H2 + y0 / 2 + py) * W2 + x0 / 2 + px : -1;
     }
     auto bias16 = [&](const float* bp, f32x16& acc) {
 #pragma unroll
@@ -55,14 +59,16 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
             acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
         }
     };
-    f32x16 accA[NT], accB;
-    bias16(p.bA + hh * 16, accA[0]);
-    accA[1] = accA[0];
-    bias16(p.bB + ctB * 32 + hh * 16, accB);
+    f32x16 accA[NT][CTA], accB[NJB];
+#pragma unroll
+    for (int c = 0; c < CTA; ++c) {
+        bias16(p.bA + c * 32 + hh * 16, accA[0][c]);
+        accA[1][c] = accA[0][c];
+    }
+#pragma unroll
+    for (int k = 0; k < NJB; ++k) bias16(p.bB + (ctB[k] < 0 ? 0 : ctB[k]) * 32 + hh * 16, accB[k]);
 
     const int KS = p.nchunks * KSB;
-    const uint4* apA = p.wA + lane;
-    const uint4* apB = p.wB + (size_t)ctB * KS * 64 + lane;
     const int total = TIH * TIW * CPP;
     const int iy0 = y0 - 1, ix0 = x0 - 1;
     const size_t img = (size_t)b * p.H * p.W;
@@ -71,11 +77,11 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
         return (t / 3) * p.RP + (t % 3) * PS + c * 32;
     };
     for (int ch = 0; ch < p.nchunks; ++ch) {
-        const uint4* aA = apA + (size_t)ch * KSB * 64;
-        const uint4* aB = apB + (size_t)ch * KSB * 64;
+        // conv A's fragments in (k-step, tile) order: flattened step f = ks * CTA + c
+        auto fragA = [&](int f) { return p.wA[((size_t)(f % CTA) * KS + (size_t)ch * KSB + f / CTA) * 64 + lane]; };
         uint4 aq[NPF];
 #pragma unroll
-        for (int k = 0; k < NPF; ++k) aq[k] = aA[k * 64];
+        for (int f = 0; f < NPF; ++f) aq[f] = fragA(f);
         // ---- stage 64 channels of the input tile (+halo), zero outside the picture
         for (int base = 0; base < total; base += 256 * NLD) {
             uint4 r[NLD];
@@ -106,30 +112,41 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
             for (int g = 0; g < NT; ++g) bq[0][g] = *reinterpret_cast<const uint4*>(smem + pixA[g] + boff(0));
 #pragma unroll
             for (int ks = 0; ks < KSB; ++ks) {
-                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+                typename DT::vec8 a[CTA];
+#pragma unroll
+                for (int c = 0; c < CTA; ++c) a[c] = __builtin_bit_cast(typename DT::vec8, aq[(ks * CTA + c) % NPF]);
                 if (ks + 1 < KSB) {
 #pragma unroll
                     for (int g = 0; g < NT; ++g) bq[(ks + 1) & 1][g] = *reinterpret_cast<const uint4*>(smem + pixA[g] + boff(ks + 1));
                 }
-                // the ring runs on into conv B's fragments of the same channel block
-                aq[ks % NPF] = (ks + NPF < KSB) ? aA[(ks + NPF) * 64] : aB[(ks + NPF - KSB) * 64];
+#pragma unroll
+                for (int c = 0; c < CTA; ++c)
+                    if (ks * CTA + c + NPF < KSB * CTA) aq[(ks * CTA + c) % NPF] = fragA(ks * CTA + c + NPF);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int g = 0; g < NT; ++g) accA[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), accA[g]);
+                for (int g = 0; g < NT; ++g)
+#pragma unroll
+                    for (int c = 0; c < CTA; ++c)
+                        accA[g][c] = DT::mfma(a[c], __builtin_bit_cast(typename DT::vec8, bq[ks & 1][g]), accA[g][c]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- conv B on the same staged tile
-        {
+        // ---- conv B on the same staged tile, job by job
+#pragma unroll
+        for (int k = 0; k < NJB; ++k) {
+            if (ctB[k] < 0) continue;                         // wave-uniform
+            const uint4* aB = p.wB + ((size_t)ctB[k] * KS + (size_t)ch * KSB) * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < NPF; ++f) aq[f] = aB[f * 64];
             uint4 bq[2];
-            bq[0] = *reinterpret_cast<const uint4*>(smem + pixB + boff(0));
+            bq[0] = *reinterpret_cast<const uint4*>(smem + pixB[k] + boff(0));
 #pragma unroll
             for (int ks = 0; ks < KSB; ++ks) {
                 const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
-                if (ks + 1 < KSB) bq[(ks + 1) & 1] = *reinterpret_cast<const uint4*>(smem + pixB + boff(ks + 1));
+                if (ks + 1 < KSB) bq[(ks + 1) & 1] = *reinterpret_cast<const uint4*>(smem + pixB[k] + boff(ks + 1));
                 if (ks + NPF < KSB) aq[ks % NPF] = aB[(ks + NPF) * 64];
                 __builtin_amdgcn_sched_barrier(0);
-                accB = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1]), accB);
+                accB[k] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1]), accB[k]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -149,21 +166,29 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
         }
     };
 #pragma unroll
-    for (int g = 0; g < NT; ++g) store(accA[g], p.outA, opixA[g], p.ldoA, hh * 16, p.storeA, p.reluA);
-    store(accB, p.outB, opixB, p.ldoB, ctB * 32 + hh * 16, 64, p.reluB);
+    for (int g = 0; g < NT; ++g)
+#pragma unroll
+        for (int c = 0; c < CTA; ++c) store(accA[g][c], p.outA, opixA[g], p.ldoA, c * 32 + hh * 16, p.storeA, p.reluA);
+#pragma unroll
+    for (int k = 0; k < NJB; ++k)
+        if (ctB[k] >= 0) store(accB[k], p.outB, opixB[k], p.ldoB, ctB[k] * 32 + hh * 16, 32 * CTB, p.reluB);
 }
 
-// a: the stride-1 conv (3x3, pad 1, cin a multiple of 64, cout <= 32, 16-bit NHWC output, no residual); the stride-2 conv
-// reads the same input: wB/biasB packed for (cin, 64, 3x3), outB [batch, h/2, w/2, out_ld_b] (h, w even).
+// a: the stride-1 conv (3x3, pad 1, cin a multiple of 64, 16-bit NHWC output, no residual); the stride-2 conv reads the same
+// input: wB/biasB packed for (cin, cout_b, 3x3), outB [batch, h/2, w/2, out_ld_b] (h, w even).  (cout_a <= 32, cout_b = 64)
+// or (cout_a <= 64, cout_b = 96).
 extern "C" int rsg_conv_dual(const rsg_conv_desc* a, const void* wB_packed, const float* biasB, void* outB16, int32_t out_ld_b,
-                             int32_t relu_b, void* stream) {
+                             int32_t cout_b, int32_t relu_b, void* stream) {
     if (!a || !a->in || !a->w_packed || !a->bias || !a->out16 || !wB_packed || !biasB || !outB16) RSG_FAIL("conv_dual: null pointer");
     if (a->kh != 3 || a->kw != 3 || a->stride != 1 || a->pad_y != 1 || a->pad_x != 1 || a->in_c < 64 || a->in_c % 64 || a->out_c < 1 ||
-        a->out_c > 32 || a->residual || a->out_nchw_f32 || a->up != 1 || a->out_h != a->in_h || a->out_w != a->in_w)
-        RSG_FAIL("conv_dual: conv A must be 3x3 stride 1 pad 1 with cin a multiple of 64 and at most 32 output channels");
+        a->residual || a->out_nchw_f32 || a->up != 1 || a->out_h != a->in_h || a->out_w != a->in_w)
+        RSG_FAIL("conv_dual: conv A must be 3x3 stride 1 pad 1 with cin a multiple of 64");
+    const int cta = ceil_div(a->out_c, 32);
+    if (!((cta == 1 && cout_b == 64) || (cta == 2 && cout_b == 96)))
+        RSG_FAIL("conv_dual: output channels %d / %d (built: <= 32 with 64, <= 64 with 96)", a->out_c, cout_b);
     if ((a->in_h | a->in_w) & 1) RSG_FAIL("conv_dual: the map must have even height and width");
-    const int store = a->out_c_store ? a->out_c_store : 32;
-    if (a->in_ld < a->in_c || (a->in_ld & 7) || a->out_ld < store || (a->out_ld & 7) || store % 8 || store > 32 || out_ld_b < 64 || (out_ld_b & 7))
+    const int store = a->out_c_store ? a->out_c_store : 32 * cta;
+    if (a->in_ld < a->in_c || (a->in_ld & 7) || a->out_ld < store || (a->out_ld & 7) || store % 8 || store > 32 * cta || out_ld_b < cout_b || (out_ld_b & 7))
         RSG_FAIL("conv_dual: strides");
     if (((uintptr_t)a->in | (uintptr_t)a->w_packed | (uintptr_t)a->bias | (uintptr_t)a->out16 | (uintptr_t)wB_packed | (uintptr_t)biasB | (uintptr_t)outB16) & 15)
         RSG_FAIL("conv_dual: pointers must be 16-byte aligned");
@@ -180,8 +205,14 @@ extern "C" int rsg_conv_dual(const rsg_conv_desc* a, const void* wB_packed, cons
     p.reluA = a->relu ? 1 : 0; p.reluB = relu_b ? 1 : 0;
     const int lds = 18 * p.RP;
     const dim3 grid(a->batch * p.tiles_x * p.tiles_y);
-    if (a->dtype == RSG_BF16) RSG_LAUNCH(conv_dual_kernel<BF16>, grid, dim3(256), lds, (hipStream_t)stream, p);
-    else RSG_LAUNCH(conv_dual_kernel<F16>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    hipStream_t s = (hipStream_t)stream;
+    if (cta == 1) {
+        if (a->dtype == RSG_BF16) RSG_LAUNCH((conv_dual_kernel<BF16, 1, 2>), grid, dim3(256), lds, s, p);
+        else RSG_LAUNCH((conv_dual_kernel<F16, 1, 2>), grid, dim3(256), lds, s, p);
+    } else {
+        if (a->dtype == RSG_BF16) RSG_LAUNCH((conv_dual_kernel<BF16, 2, 3>), grid, dim3(256), lds, s, p);
+        else RSG_LAUNCH((conv_dual_kernel<F16, 2, 3>), grid, dim3(256), lds, s, p);
+    }
     RSG_CHECK_LAUNCH("conv_dual");
     return 0;
 }

@@ -1095,7 +1095,8 @@ class _BackboneMixin:
             return False
         ca, cb, x = trans[0][0], trans[1][0][0], ys[0]
         return ca.kernel_size == (3, 3) and ca.stride == (1, 1) and cb.kernel_size == (3, 3) and cb.stride == (2, 2) and \
-            ca.in_channels == cb.in_channels == x.C and x.C % 64 == 0 and ca.out_channels <= 32 and cb.out_channels == 64 and \
+            ca.in_channels == cb.in_channels == x.C and x.C % 64 == 0 and \
+            ((ca.out_channels <= 32 and cb.out_channels == 64) or (32 < ca.out_channels <= 64 and cb.out_channels == 96)) and \
             ca.bias is None and cb.bias is None and x.coff == 0 and x.H % 2 == 0 and x.W % 2 == 0
 
     def conv_dual(self: Plan, x: VT, seq_a, seq_b, name: str) -> List[VT]:
@@ -1121,7 +1122,7 @@ class _BackboneMixin:
             ref, pb, pbb, pob, ldb = C.byref(d), wb.data_ptr(), bb.data_ptr(), ob.ptr(), ob.ld
 
             def launch(stream):
-                rc = lib.rsg_conv_dual(ref, pb, pbb, pob, ldb, 1, stream)
+                rc = lib.rsg_conv_dual(ref, pb, pbb, pob, ldb, Ob, 1, stream)
                 if rc:
                     hip.check(rc, name)
             return launch

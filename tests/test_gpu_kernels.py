@@ -478,18 +478,20 @@ def test_chain_group_w48_widths_one_launch():
     assert lib.rsg_basic_chain_group(items, 4, 0, _stream()) != 0
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 48, 256, 32), (2, 40, 24, 256, 32), (1, 18, 14, 64, 24)], ids=str)
+@pytest.mark.parametrize("shape", [(3, 64, 48, 256, 32, 64), (2, 40, 24, 256, 32, 64), (1, 18, 14, 64, 24, 64),
+                                   (2, 96, 72, 256, 48, 96), (1, 22, 18, 128, 64, 96)], ids=str)
 def test_conv_dual_equals_two_convs(shape):
     """rsg_conv_dual (transition1: the stride-1 and the stride-2 3x3 conv of the same map from ONE staged tile) gives bit for
     bit what two rsg_conv_igemm launches give -- whole tiles, tiles that hang over the map's edge, a narrow first conv."""
-    B, H, W, Cin, Oa = shape
+    B, H, W, Cin, Oa, Ob = shape
     lib = hip.lib()
     g = torch.Generator().manual_seed(H * W + Cin)
     x = torch.randn(B, Cin, H, W, generator=g)
     wa = torch.randn(Oa, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
-    wb = torch.randn(64, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    wb = torch.randn(Ob, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
     sa, ha = torch.rand(Oa, generator=g) + 0.5, torch.randn(Oa, generator=g) * 0.1
-    sb, hb = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    sb, hb = torch.rand(Ob, generator=g) + 0.5, torch.randn(Ob, generator=g) * 0.1
+    PA = (Oa + 31) // 32 * 32
     ref_a, _ = run_conv(x, wa, sa, ha, relu=True)
     ref_b, _ = run_conv(x, wb, sb, hb, stride=2, relu=True)
 
@@ -504,21 +506,21 @@ def test_conv_dual_equals_two_convs(shape):
     wpa, boa = pack(wa, sa, ha)
     wpb, bob = pack(wb, sb, hb)
     xin = x.permute(0, 2, 3, 1).contiguous().half().to(DEV)
-    oa = torch.full((B, H, W, 32), float("nan"), dtype=torch.float16, device=DEV)
-    ob = torch.full((B, H // 2, W // 2, 64), float("nan"), dtype=torch.float16, device=DEV)
+    oa = torch.full((B, H, W, PA), float("nan"), dtype=torch.float16, device=DEV)
+    ob = torch.full((B, H // 2, W // 2, Ob), float("nan"), dtype=torch.float16, device=DEV)
     d = hip.ConvDesc()
     d.inp, d.w_packed, d.bias, d.out16 = xin.data_ptr(), wpa.data_ptr(), boa.data_ptr(), oa.data_ptr()
     d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, H, W, Cin, Cin
-    d.out_h, d.out_w, d.out_c, d.out_ld = H, W, Oa, 32
+    d.out_h, d.out_w, d.out_c, d.out_ld = H, W, Oa, PA
     d.kh = d.kw = 3
     d.stride, d.pad_y, d.pad_x = 1, 1, 1
     d.up, d.phys_h, d.phys_w, d.relu, d.dtype = 1, H, W, 1, 0
-    hip.check(lib.rsg_conv_dual(C.byref(d), wpb.data_ptr(), bob.data_ptr(), ob.data_ptr(), 64, 1, _stream()), "conv_dual")
+    hip.check(lib.rsg_conv_dual(C.byref(d), wpb.data_ptr(), bob.data_ptr(), ob.data_ptr(), Ob, Ob, 1, _stream()), "conv_dual")
     torch.cuda.synchronize()
     assert torch.equal(oa.float().cpu().permute(0, 3, 1, 2), ref_a)
     assert torch.equal(ob.float().cpu().permute(0, 3, 1, 2), ref_b)
     d.stride = 2
-    assert lib.rsg_conv_dual(C.byref(d), wpb.data_ptr(), bob.data_ptr(), ob.data_ptr(), 64, 1, _stream()) != 0
+    assert lib.rsg_conv_dual(C.byref(d), wpb.data_ptr(), bob.data_ptr(), ob.data_ptr(), Ob, Ob, 1, _stream()) != 0
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 48, 256), (3, 13, 9, 128), (1, 64, 48, 64)], ids=str)
