@@ -23,7 +23,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 GFLOP_PER_IMG = {"hrnet_w32_256x192": 15.29, "rsgnet_w32_256x192_coco": 17.80,
-                 "rsgnet_w32_256x192_crowdpose": 17.78, "hrnet_w48_384x288": 70.6}
+                 "rsgnet_w32_256x192_crowdpose": 17.78, "hrnet_w48_384x288": 70.6, "rsgnet_w48_384x288_coco": 89.9}
 PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
 
 
@@ -49,6 +49,7 @@ WORKLOADS = {
     "rsgnet_w32_256x192_coco": ("pose_rsgnet", 32, (192, 256), 17, 64),
     "rsgnet_w32_256x192_crowdpose": ("pose_rsgnet", 32, (192, 256), 14, 64),     # BASELINE configs[4]
     "hrnet_w48_384x288": ("pose_hrnet", 48, (288, 384), 17, 32),                 # BASELINE configs[2]
+    "rsgnet_w48_384x288_coco": ("pose_rsgnet", 48, (288, 384), 17, 32),          # ... with the TRP / SGM head (S = 6912)
 }
 FLIP_PAIRS = {17: [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]],   # coco.py:92
               14: [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9], [10, 11]]}                        # crowdpose.py:988
