@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_igemm_kernel(const ConvArgs
 static int pick_cinb(int cin) {
     if (cin % 64 == 0) return 64;
     if (cin % 32 == 0) return 32;
+    if (cin == 48) return 48;       // HRNet-W48's first branch: one staging round and 27 k-steps instead of three rounds of nine
     if (cin % 16 == 0) return 16;
     return 0;
 }
@@ -163,13 +164,16 @@ static conv_fn lookup(int cinb, int taps, int wm, int nt) {
     RSG_CASE(C, TH_, TW_, 2, 2, 1) \
     RSG_CASE(C, TH_, TW_, 4, 1, 2)
     RSG_CFGS(16, 3, 3)
+    RSG_CFGS(48, 3, 3)
     RSG_CFGS(32, 3, 3)
     RSG_CFGS(64, 3, 3)
     RSG_CFGS(16, 1, 1)
+    RSG_CFGS(48, 1, 1)
     RSG_CFGS(32, 1, 1)
     RSG_CFGS(64, 1, 1)
     RSG_CFGS(256, 1, 1)
     RSG_CFGS(16, 2, 2)
+    RSG_CFGS(48, 2, 2)
     RSG_CFGS(32, 2, 2)
 #undef RSG_CFGS
 #undef RSG_CASE
@@ -484,7 +488,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const rsg_pack_item* 
     const int wcin = it.cin, wcout = it.cout, ntaps = it.kh * it.kw;   // the weight tensor is [wcout][wcin][kh][kw]
     const int cin = it.transpose ? wcout : wcin, cout = it.transpose ? wcin : wcout;   // the packed conv's own cin/cout
     const int cin_pad = cin <= 16 ? 16 : (cin % 16 == 0 ? cin : (cin + 31) / 32 * 32);
-    const int cinb = cin_pad % 64 == 0 ? 64 : (cin_pad % 32 == 0 ? 32 : 16);
+    const int cinb = cin_pad % 64 == 0 ? 64 : (cin_pad % 32 == 0 ? 32 : (cin_pad == 48 ? 48 : 16));
     const int kpt = cinb / 16, nchunks = cin_pad / cinb, KSB = ntaps * kpt, KS = nchunks * KSB;
     const int local = (int)blockIdx.x - it.first_block;
     const int ct = local / nchunks, ch = local - ct * nchunks;

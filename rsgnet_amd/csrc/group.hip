@@ -20,10 +20,10 @@ struct GroupArgs {
     FuseArgs fuse[RSG_GROUP_MAX_FUSES];
 };
 
-// variant id = ((cinb_idx * 3 + taps_idx) * 5 + cfg_idx); cinb in {32,64,16}, taps in {1x1,3x3,2x2 (cinb 32 only)},
-// cfg in {(1,4,3),(1,4,1),(2,2,3),(2,2,1),(4,1,2)} = (WM,WN,NT).  cinb 16: the 48-channel maps of HRNet-W48.
+// variant id = ((cinb_idx * 3 + taps_idx) * 5 + cfg_idx); cinb in {32,64,48}, taps in {1x1,3x3,2x2 (cinb 32 only)},
+// cfg in {(1,4,3),(1,4,1),(2,2,3),(2,2,1),(4,1,2)} = (WM,WN,NT).  cinb 48: the 48-channel maps of HRNet-W48.
 static int variant_id(int cinb, int taps, int wm, int nt) {
-    const int ci = cinb == 32 ? 0 : (cinb == 64 ? 1 : (cinb == 16 ? 2 : -1));
+    const int ci = cinb == 32 ? 0 : (cinb == 64 ? 1 : (cinb == 48 ? 2 : -1));
     const int ti = taps == 1 ? 0 : (taps == 9 ? 1 : (taps == 4 && cinb == 32 ? 2 : -1));
     int cf = -1;
     if (wm == 1 && nt == 3) cf = 0;
@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(256, 3) conv_group_kernel(const GroupArgs g) {
         RSG_V5(10, 32, 2, 2)
         RSG_V5(15, 64, 1, 1)
         RSG_V5(20, 64, 3, 3)
-        RSG_V5(30, 16, 1, 1)
-        RSG_V5(35, 16, 3, 3)
+        RSG_V5(30, 48, 1, 1)
+        RSG_V5(35, 48, 3, 3)
     }
 #undef RSG_V5
 #undef RSG_V
