@@ -38,7 +38,7 @@ def test_packer_matches_kernel_mfma_convention(cin, cout, k):
     cb = rs.standard_normal(cout).astype(np.float32)
     wp, bo = _pack(w, scale, shift, cb)
     cin_pad = lib.rsg_conv_padded_cin(cin)
-    cinb = 64 if cin_pad % 64 == 0 else (32 if cin_pad % 32 == 0 else 16)
+    cinb = 64 if cin_pad % 64 == 0 else (32 if cin_pad % 32 == 0 else (48 if cin_pad == 48 else 16))   # csrc/conv_igemm.hip, pick_cinb
     ntaps, kpt, nch = k * k, cinb // 16, cin_pad // cinb
     KS = nch * ntaps * kpt
     ntile = (cout + 31) // 32
