@@ -112,6 +112,28 @@ def test_ragged_batches_agree_with_each_other(name):
     assert torch.equal(full, parts)
 
 
+@pytest.mark.parametrize("width,wh,batch", [(48, (192, 256), 3), (32, (288, 384), 2), (48, (160, 224), 1)], ids=str)
+def test_other_input_sizes_against_the_oracle(width, wh, batch):
+    """The networks at input sizes the goldens do not cover (other chain geometries: HRNet-W48 at 256x192 has whole-image
+    192/384-channel maps and four row tiles of its 48-channel map; HRNet-W32 at 384x288 needs three row tiles; 224x160 has
+    maps that are no multiple of a tile): HIP forward against the CPU oracle on the same weights."""
+    from rsgnet_amd import make_cfg, models
+    from rsgnet_amd.weights import synth_input, synth_state_dict
+    cfg = make_cfg("pose_hrnet", width, wh)
+    model = models.pose_hrnet.get_pose_net(cfg, is_train=False)
+    tag = "hrnet_w32_256x192" if width == 32 else "hrnet_w48_384x288"
+    bn = dict(np.load(os.path.join(ROOT, "tests", "golden", f"bnstats_{tag}.npz")))      # per-channel: any input size
+    sd = synth_state_dict(model.state_dict(), 0, bn)
+    model.load_state_dict(sd)
+    model = model.eval().cuda()
+    x = synth_input(batch, wh, 13)
+    with torch.no_grad():
+        y = model(x.cuda()).cpu()
+    ref = po.hrnet_forward(sd, cfg, x)
+    e = _stats(f"W{width} {wh[1]}x{wh[0]} heatmaps vs oracle", y, ref.numpy())
+    assert torch.isfinite(y).all() and e < REL_TOL * float(ref.std())
+
+
 @pytest.mark.parametrize("tag", ["rsgnet_w32_256x192_coco", "rsgnet_w32_256x192_crowdpose",
                                  "rsgnet_w48_384x288_coco"])
 def test_rsgnet_w32_golden(tag):
