@@ -358,6 +358,7 @@ def rsgnet_forward(sd, cfg, x, relation_target=None, want_scores=True, **kw):
         wl = kt_machine(ctx, ctx.p("final_layer.weight"))                         # :1004
         ctx.taps["limb_weights"] = wl
         limbs = F.conv2d(lf, wl.to(ctx.emu).to(ctx.dtype) if ctx.emu is not None else wl)  # :1005
+        ctx.taps["limbs_logits"] = limbs                                          # before x2 upsampling and sigmoid
         if model["UP_SCALE"] > 1:                                                 # :1008-1012
             multi = F.interpolate(multi, scale_factor=2, mode="bilinear", align_corners=True)
             limbs = F.interpolate(limbs, scale_factor=2, mode="bilinear", align_corners=True)

@@ -41,6 +41,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+    if os.environ.get("RSGNET_HIP_DEBUG_BUILD") == "1":     # diagnostic library: timing switches that give WRONG results
+        flags.append("-DRSG_DEBUG")
     # MFMA accumulators in VGPRs (gfx950 has one unified register file): the default AGPR form costs
     # v_accvgpr moves wherever VALU code touches an accumulator (64 per tile in trp.hip's sigmoid loop,
     # 16 per tile in every conv epilogue).  Measured in one visit: TRP loop -18 registers; HRNet step -1.8 %.

@@ -98,7 +98,7 @@ struct ChainArgs {
     ChainTail tail[RSG_CHAIN_MAX_TAILS];
     int dual;     // 1: two LDS images (ping-pong): a layer reads one and writes the other, the block input stays in LDS
     int ldi, ldo; // pixel stride (elements) of in / out; == C except for the 48-channel maps of HRNet-W48 (kept in 64-channel buffers)
-    int debug;    // experiments (rsg_tune("chain_debug")): bit 2 = no block-input fetch (WRONG results), bit 4 = producers never signal
+    int debug;    // rsg_tune("chain_debug"): bit 4 = fault injection, producers never signal (the error word's test); -DRSG_DEBUG builds only: bit 2 = no block-input fetch (timing experiment, WRONG results)
 };
 
 // One tail conv over the LDS image `img` (slot layout of chain_body: slot_rows rows of RP bytes per image, pixel
@@ -363,11 +363,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
         constexpr int NRE = NTHR > 512 ? 0 : (NT >= 7 ? 3 : NT);
 #endif
         auto fetch_res = [&](int g0, int g1) {
-            if (p.debug & 2) {                           // timing experiment only
+#ifdef RSG_DEBUG
+            if (p.debug & 2) {                           // timing experiment only (diagnostic build)
 #pragma unroll
                 for (int g = g0; g < g1; ++g) res[g][0] = res[g][1] = make_uint4(0, 0, 0, 0);
                 return;
             }
+#endif
             if (dual) {
 #pragma unroll
                 for (int g = g0; g < g1; ++g) {
@@ -705,7 +707,16 @@ static const int kChainMaxNT = 8;      // workspace slots are sized for the wide
 // measured (8x6x256 branch, batch 64): 1 image per workgroup (64 workgroups, shorter critical path) beats 2
 static int g_chain_max_ni = 1;
 static int g_chain_pitch_pad = 1;   // rsg_tune("chain_pitch_pad", 0|1)
-static int g_chain_debug = 0;      // rsg_tune("chain_debug", bits): experiments with WRONG results: 1 = every layer reads layer 0's weights, 2 = no block-input fetch, 4 = hand-off producers never signal (exercises the error word)
+// rsg_tune("chain_debug", bits).  Production library: only bit 4, a fault injection whose effect is DETECTED (hand-off
+// producers never signal: every consumer poll gives up, the error word counts it, the plan raises HandoffTimeout).
+// The timing experiments that silently give WRONG results exist only in a -DRSG_DEBUG build (RSGNET_HIP_DEBUG_BUILD=1
+// for rsgnet_amd.build): 1 = every layer reads layer 0's weights, 2 = no block-input fetch.
+static int g_chain_debug = 0;
+#ifdef RSG_DEBUG
+#define RSG_CHAIN_DEBUG_MASK 7
+#else
+#define RSG_CHAIN_DEBUG_MASK 4
+#endif
 static int g_chain_dual = 1;       // rsg_tune("chain_dual", 0|1): ping-pong LDS images for the whole-image chains that fit twice
 static int g_chain_prefetch = 1;   // rsg_tune("chain_prefetch", 0|1): weight prefetch at the start of a grouped launch
 static int g_chain_split_rows = 1; // rsg_tune("chain_split_rows", 0|1): two row tiles for the 384-channel map at small batch (chain_geometry)
@@ -716,16 +727,24 @@ static int chain_row_pitch(int C, int W) {
 extern int g_conv_lds_limit;
 extern int g_conv_full_k;
 extern int g_bottleneck_head;
+#ifdef RSG_DEBUG
 extern int g_bottleneck_debug;
+#endif
 extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "bottleneck_head") && (value == 1 || value == 2)) { g_bottleneck_head = value; return 0; }
+#ifdef RSG_DEBUG
     if (key && !strcmp(key, "bottleneck_debug")) { g_bottleneck_debug = value; return 0; }
+#endif
     if (key && !strcmp(key, "conv_full_k")) { g_conv_full_k = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "conv_lds_limit") && value >= 8192 && value <= 64 * 1024) { g_conv_lds_limit = value; return 0; }
     if (key && !strcmp(key, "chain_max_ni") && value >= 1) { g_chain_max_ni = value; return 0; }
     if (key && !strcmp(key, "chain_pitch_pad")) { g_chain_pitch_pad = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "chain_prefetch")) { g_chain_prefetch = value ? 1 : 0; return 0; }
-    if (key && !strcmp(key, "chain_debug")) { g_chain_debug = value; return 0; }
+    if (key && !strcmp(key, "chain_debug")) {
+        if (value & ~RSG_CHAIN_DEBUG_MASK) RSG_FAIL("tune: chain_debug bits 0x%x exist only in a -DRSG_DEBUG build of the library", value & ~RSG_CHAIN_DEBUG_MASK);
+        g_chain_debug = value;
+        return 0;
+    }
     if (key && !strcmp(key, "chain_dual")) { g_chain_dual = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "chain_split_rows")) { g_chain_split_rows = value ? 1 : 0; return 0; }
     RSG_FAIL("tune: unknown key or bad value");

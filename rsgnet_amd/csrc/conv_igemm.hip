@@ -255,7 +255,9 @@ __global__ void __launch_bounds__(256) bottleneck_kernel(const ConvArgs p) {
     conv_body<DT, 64, 3, 3, 2, 2, 3, true, HEAD>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 int g_bottleneck_head = 2;     // rsg_tune("bottleneck_head", 1|2): 2 = two pixel groups in flight
-int g_bottleneck_debug = 0;    // rsg_tune("bottleneck_debug", 1): timing experiment, no residual read (WRONG results)
+#ifdef RSG_DEBUG
+int g_bottleneck_debug = 0;    // rsg_tune("bottleneck_debug", 1): timing experiment, no residual read (WRONG results; diagnostic build only)
+#endif
 
 // 3x3 stride-1 conv (C1 = 64 outputs, BatchNorm folded, ReLU) followed by a 1x1 conv (+BN, +residual, ReLU) in one
 // launch: `inner` describes the 3x3 conv (its out16/residual are ignored), the other arguments the 1x1 tail.
@@ -329,7 +331,9 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
     }
     if (head_x) {
         a.in0 = (const char*)head_x; a.ldi0 = head_ld; a.wpk0 = (const uint4*)head_w; a.bias0 = head_bias;
+#ifdef RSG_DEBUG
         if (g_bottleneck_debug & 1) a.res = nullptr;
+#endif
         if (g_bottleneck_head == 1) {
             if (inner->dtype == RSG_BF16) RSG_LAUNCH((bottleneck_kernel<BF16, 1>), dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);
             else RSG_LAUNCH((bottleneck_kernel<F16, 1>), dim3(grid.x), dim3(256), t.lds, (hipStream_t)stream, a);

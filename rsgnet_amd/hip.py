@@ -182,10 +182,18 @@ def lib() -> C.CDLL:
         for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad"),
                          ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit"), ("RSGNET_HIP_CHAIN_PREFETCH", b"chain_prefetch"),
                          ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
-                         ("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug"), ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual"),
+                         ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual"),
                          ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows")):
             if os.environ.get(env):
                 l.rsg_tune(key, int(os.environ[env]))
+        # the wrong-result timing switches (chain_debug bits 1|2, bottleneck_debug) exist only in a -DRSG_DEBUG build
+        # (RSGNET_HIP_DEBUG_BUILD=1 python -m rsgnet_amd.build --force) and are never set from the environment of a
+        # production process; tools/ call rsg_tune themselves and fail loudly on a production library
+        for env, key in (("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug")):
+            if os.environ.get(env) and os.environ.get("RSGNET_HIP_DEBUG_BUILD") == "1":
+                check_rc = l.rsg_tune(key, int(os.environ[env]))
+                if check_rc:
+                    raise RuntimeError(f"{env}: {l.rsg_last_error().decode(errors='replace')}")
         if any(os.environ.get("RSGNET_HIP_WGRAD_" + k) for k in ("MIN_PX", "QUAD_MIN_WGS", "LDS", "PX_CAP", "WAVES")):
             l.rsg_wgrad_tune(int(os.environ.get("RSGNET_HIP_WGRAD_MIN_PX", "0")), int(os.environ.get("RSGNET_HIP_WGRAD_QUAD_MIN_WGS", "0")),
                              int(os.environ.get("RSGNET_HIP_WGRAD_LDS", "0")), int(os.environ.get("RSGNET_HIP_WGRAD_PX_CAP", "0")),

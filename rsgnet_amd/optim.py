@@ -156,11 +156,12 @@ class FusedAdam(torch.optim.Optimizer):
             if k in flat_of:
                 where[pid] = flat_of[k]
         hyper = {k: v for k, v in groups[0].items() if k != "params"}
-        for k in ("lr", "betas", "eps"):
-            if k in hyper:
-                self.param_groups[0][k] = hyper[k]
         if hyper.get("weight_decay", 0) or hyper.get("amsgrad", False) or hyper.get("maximize", False):
             raise ValueError("FusedAdam implements Adam without weight decay / amsgrad (lib/utils/utils.py:70-74)")
+        # every key of the saved group comes back, as torch.optim.Optimizer.load_state_dict does it: a scheduler's
+        # `initial_lr` must survive a resume (tools/cp_train.py:184-193 builds MultiStepLR(last_epoch=checkpoint epoch)
+        # right after optimizer.load_state_dict, and torch raises KeyError without it)
+        self.param_groups[0].update(hyper)
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
         self._steps = [0] * len(self._params)

@@ -124,7 +124,10 @@ class Plan:
         self._ho_pinned: Optional[torch.Tensor] = None
         self._ho_pending: Optional[torch.cuda.Event] = None
         self._runs = 0
-        self.handoff_poll_every = 32                   # forwards between two asynchronous reads of the error word
+        # forwards between two asynchronous reads of the error word: every forward enqueues the 4-byte copy behind its
+        # launches and looks at the previous forward's copy first, so at most ONE batch of outputs can leave a plan
+        # whose hand-off gave up before HandoffTimeout is raised (advisor, round 2: was 32)
+        self.handoff_poll_every = max(1, int(os.environ.get("RSGNET_HIP_HANDOFF_POLL_EVERY", "1")))
 
     class _LaneCtx:
         def __init__(self, plan, lane):
@@ -510,8 +513,11 @@ class Plan:
                 free.setdefault(v.nbytes(B) // 2, []).append(v.storage)
         self.arena_bytes = total
         self._derive_dependencies()
+        self._op_writes: List[List[VT]] = []          # per lowered op: the 16-bit maps it writes (run_with_taps)
         for r in self._rec:
+            n0 = len(self.ops)
             getattr(self, "_lower_" + r["kind"])(r)
+            self._op_writes += [[v for v in r["writes"] if isinstance(v, VT)]] * (len(self.ops) - n0)
         self._rec = []
 
     def _derive_dependencies(self):
@@ -856,6 +862,25 @@ class Plan:
                 keep.append(ev)
                 ev.record(st)
                 main.wait_event(ev)
+
+    def run_with_taps(self, x: torch.Tensor, names: Sequence[str]) -> Dict[str, torch.Tensor]:
+        """Tests / triage: one eager pass over the launch list; after the op that writes a 16-bit map whose recorded
+        name is in `names`, that map is cloned as [B,H,W,C] (buffers are reused by later ops, so it has to be taken
+        on the spot).  Returns {name: tensor}; the plan's fp32 outputs hold this pass's results afterwards."""
+        if self.graph_mode == "dag":
+            raise RuntimeError("run_with_taps needs RSGNET_HIP_GRAPH != dag")
+        want, got = set(names), {}
+        self._bind_input(x)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for (_, op), writes in zip(self.ops, self._op_writes):
+            op(st)
+            for v in writes:
+                if v.name in want:
+                    got[v.name] = v.tensor(self.batch).clone()
+        missing = want - set(got)
+        if missing:
+            raise KeyError(f"no op of this plan writes {sorted(missing)}; maps: {sorted({v.name for w in self._op_writes for v in w})[:60]}")
+        return got
 
     def _build_hip_graph(self):
         """One kernel node per op, edges = the data dependencies (librsgnet_hip's explicit graph API)."""

@@ -688,6 +688,10 @@ class TrainPlan:
         if tuple(x.shape) != tuple(self.x_f32.shape):
             raise ValueError(f"input {tuple(x.shape)} != plan {tuple(self.x_f32.shape)}")
         self._prepare()
+        # ONE static activation/gradient arena per plan: this forward overwrites what an earlier, not yet
+        # back-propagated forward left there.  The generation number lets backward() refuse a stale node.
+        self.generation = getattr(self, "generation", 0) + 1
+        self._backward_done = False
         self.x_f32.copy_(x)
         if self.use_graph and self._graphs is None and self._warm >= 1:
             torch.cuda.synchronize(self.device)
@@ -713,7 +717,20 @@ class TrainPlan:
             self._run_forward()
         return self.heat.clone()
 
-    def backward(self, dheat: torch.Tensor) -> None:
+    def backward(self, dheat: torch.Tensor, generation: Optional[int] = None) -> None:
+        """Parameter gradients are OVERWRITTEN (the state after `optimizer.zero_grad()`, which the reference's loop
+        calls before every backward, lib/core/function.py:60-62), not accumulated into."""
+        if generation is not None and generation != self.generation:
+            raise RuntimeError(
+                "backward of a training-mode forward whose activations are gone: the model ran another training-mode "
+                f"forward (generation {self.generation}) on the same (batch, device) before this one (generation "
+                f"{generation}) was back-propagated. The HIP training plan keeps ONE activation arena per batch size; "
+                "back-propagate each forward before the next one (micro-batches: loss.backward() per micro-batch and "
+                "accumulate outside, or use different batch sizes).")
+        if self._backward_done:
+            raise RuntimeError("second backward through the same training-mode forward: its buffers were reused "
+                               "(run the forward again; retain_graph is not supported by the HIP training plan)")
+        self._backward_done = True
         self.dheat.copy_(dheat)
         hooks = getattr(self.model, "grad_ready_hooks", ())
         for k in range(len(self._bwd_segments)):
@@ -737,13 +754,15 @@ class _TrainFn(torch.autograd.Function):
     def forward(ctx, hook: torch.Tensor, plan: TrainPlan, x: torch.Tensor):
         ctx.plan = plan
         with torch.cuda.device(x.device):
-            return plan.forward(x)
+            out = plan.forward(x)
+        ctx.generation = plan.generation
+        return out
 
     @staticmethod
     def backward(ctx, dheat: torch.Tensor):
         plan: TrainPlan = ctx.plan
         with torch.cuda.device(dheat.device):
-            plan.backward(dheat.contiguous().float())
+            plan.backward(dheat.contiguous().float(), ctx.generation)
         return None, None, None
 
 

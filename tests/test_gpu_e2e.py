@@ -19,6 +19,21 @@ pytestmark = pytest.mark.gpu
 # (BASELINE configs[0]) below.
 REL_TOL = 0.05          # x std(reference map): ~1.5x the fp16 emulation's own deviation
 ABS_TOL = 1e-3
+# The SHARP end-to-end check: HIP against the oracle that rounds where the kernels round (emulate='fp16').  Both sides
+# round the same values at the same points; what is left is fp32 summation order inside a conv (MFMA k-order vs ATen's)
+# flipping an fp16 rounding now and then.  Bars = 2x the values measured on MI355X (round 3, gpurun_out/parity.txt,
+# quoted next to each bar), as a fraction of the reference map's std.
+EMU_BARS = {
+    "hrnet_w32_256x192": {"heatmaps": 0.012},
+    "rsgnet_w32_256x192_coco": {"multi": 0.012, "kpt": 0.012, "limbs_logits": 0.012},
+    "rsgnet_w32_256x192_crowdpose": {"multi": 0.012, "kpt": 0.012, "limbs_logits": 0.012},
+}
+TAP_REL_TOL = 0.05      # x std of the tap: intermediate maps against the reference-captured goldens
+
+
+def _tap_nchw(t):
+    """[B,H,W,C] 16-bit plan map -> crop 0 as fp32 [C,H,W]."""
+    return t[0].permute(2, 0, 1).float().cpu()
 
 
 def _stats(name, got, ref):
@@ -46,11 +61,29 @@ def test_hrnet_w32_golden():
     assert maxabs(y[1, :, ::4, ::4], gold["heatmaps_crop1_sub"]) < REL_TOL * float(ref.std())
     # kernel correctness proper: agree with the oracle that rounds where the kernels round
     emu = po.hrnet_forward(sd, cfg, x, emulate="fp16")
-    e2 = _stats("vs fp16-emulating oracle", y, emu.numpy())
-    assert e2 < 0.5 * REL_TOL * float(ref.std())
-    # intermediate taps exist for triage
+    e2 = _stats("hrnet heatmaps vs fp16-emulating oracle", y, emu.numpy())
+    assert e2 < EMU_BARS["hrnet_w32_256x192"]["heatmaps"] * float(ref.std()), e2 / float(ref.std())
+    # intermediate maps against the reference-captured taps: a failure above is localised here
     plan = model.plan_for(x.cuda())
     assert plan.arena_bytes > 0 and len(plan.ops) > 30
+    _check_backbone_taps(plan, x, gold)
+
+
+def _check_backbone_taps(plan, x, gold):
+    """layer1 / stage2 / stage3 / stage4 outputs of crop 0 against the module-hook taps of the reference forward
+    (oracle/make_goldens.py): the 16-bit maps of the plan, taken right after the op that writes them."""
+    names = {"layer1": "layer1.3.conv2+conv3", "stage2": "stage2.0.fuse.0", "stage3": "stage3.3.fuse.0",
+             "stage4": "stage4.2.fuse.0"}
+    with torch.no_grad():
+        taps = plan.run_with_taps(x.cuda(), list(names.values()))
+    torch.cuda.synchronize()
+    l1 = _tap_nchw(taps[names["layer1"]])[::8, ::2, ::2]
+    ref = gold["layer1_crop0_sub"]
+    assert _stats("tap layer1", l1, ref) < TAP_REL_TOL * float(ref.std())
+    for s in (2, 3, 4):
+        ref = gold[f"stage{s}_br0_crop0"]
+        got = _tap_nchw(taps[names[f"stage{s}"]])[:ref.shape[0]]
+        assert _stats(f"tap stage{s} branch 0", got, ref) < TAP_REL_TOL * float(ref.std()), s
 
 
 def test_hrnet_w32_random_init_regime_meets_1e3():
@@ -70,8 +103,8 @@ def test_hrnet_w32_random_init_regime_meets_1e3():
 
 
 def test_hrnet_w48_384x288_golden():
-    """BASELINE configs[2] backbone (channels 48/96/192/384, maps 96x72 ... 12x9): the per-conv kernels
-    (CINB=16 path, 48-channel maps in 64-channel buffers); the LDS-resident chains cover W32 widths only."""
+    """BASELINE configs[2] backbone (channels 48/96/192/384, maps 96x72 ... 12x9): the 12-wave LDS-resident chains
+    (csrc/chain.hip, the 48-channel branch on csrc/chain48.h), 48-channel maps in 64-channel buffers."""
     cfg, model, sd, x, gold = load_case("hrnet_w48_384x288")
     model = model.cuda()
     with torch.no_grad():
@@ -147,19 +180,34 @@ def test_rsgnet_w32_golden(tag):
     W_, H_ = TAGS[tag][2]
     S = (H_ // 4) * (W_ // 4)
     assert multi.shape == (2, J, H_ // 2, W_ // 2) and kpt.shape == multi.shape and limbs.shape == (2, L, H_ // 2, W_ // 2)
-    for name, t in (("multi_kpt_scores", multi), ("kpt_scores", kpt), ("limbs_scores", limbs)):
+    for name, t in (("multi_kpt_scores", multi), ("kpt_scores", kpt)):
         ref = gold[name + "_crop0"]
         e = _stats(tag.split("_")[1] + " " + name, like_gold(t[0], ref), ref)
-        # limb maps: sigmoids of x2-upsampled logits (std ~0.1, peaks ~0.93); the steep part of the sigmoid passes the
-        # backbone's 16-bit rounding noise, the rounding-aware oracle below is itself ~1e-2 from the fp32 goldens: bar 0.02
-        scale = float(ref.std()) if name != "limbs_scores" else 0.4
-        assert e < REL_TOL * scale, name
+        assert e < REL_TOL * float(ref.std()), name
+    # limb maps are sigmoids of x2-upsampled logits: the bar is on the LOGITS (the linear quantity the kernels compute),
+    # at the same fraction of the map's std as every other output; the probabilities follow (|d sigma| <= |d logit| / 4)
+    ref_p = np.clip(gold["limbs_scores_crop0"].astype(np.float64), 1e-7, 1 - 1e-7)
+    got_p = np.clip(like_gold(limbs[0], ref_p).double().numpy(), 1e-7, 1 - 1e-7)
+    ref_l, got_l = np.log(ref_p / (1 - ref_p)), np.log(got_p / (1 - got_p))
+    e = _stats(tag.split("_")[1] + " limb logits (x2 up-sampled)", got_l, ref_l)
+    assert e < REL_TOL * float(ref_l.std()), e / float(ref_l.std())
+    assert maxabs(like_gold(limbs[0], ref_p), gold["limbs_scores_crop0"]) < 0.25 * REL_TOL * float(ref_l.std())
     # TRP: the lazy handle materialises R = sigmoid(x x^T) on demand
     assert rel.shape == (2, S, S)
     R = rel.materialize()
     idx = sample_index(S)
-    e = _stats("relation_scores samples", R[:, idx[:, 0], idx[:, 1]].cpu(), gold["relation_scores_samples"])
-    assert e < 2e-2
+    want = gold["relation_scores_samples"].astype(np.float64)
+    got = R[:, idx[:, 0], idx[:, 1]].cpu().double().numpy()
+    _stats("relation_scores samples", got, want)
+    # R = sigmoid(affinity) sits in [0.5, 1): compare the AFFINITIES (the Gram product the kernel computes) where the
+    # sigmoid has not saturated, relative to their spread; saturated entries (R > 1 - 1e-4) are compared as they are
+    open_ = want < 1 - 1e-4
+    aff = lambda r: np.log(r / (1 - r))
+    wa, ga = aff(want[open_]), aff(np.clip(got[open_], 1e-7, 1 - 1e-7))
+    e = _stats("relation affinities (unsaturated samples)", ga, wa)
+    assert open_.sum() > 50 and e < REL_TOL * float(wa.std()), (int(open_.sum()), e, float(wa.std()))
+    if (~open_).any():
+        assert np.abs(got[~open_] - want[~open_]).max() < 1e-3
     rs = gold["relation_scores_rowsum"]                       # sums of 3072 correlated terms
     assert maxabs(R.sum(dim=2).cpu(), rs) < 1e-2 * float(np.abs(rs).max())
     # training tail with the factored target
@@ -170,9 +218,29 @@ def test_rsgnet_w32_golden(tag):
     # against the rounding-aware oracle (kernel correctness)
     if S > 4000:
         return                                       # the CPU emulation of the 384x288 net is slow; goldens suffice
-    emu = po.rsgnet_forward(sd, cfg, x, want_scores=False, emulate="fp16")
-    for name, t, r in (("multi", multi, emu[0]), ("kpt", kpt, emu[1]), ("limbs", limbs, emu[2])):
-        _stats(name + " vs fp16-emulating oracle", t.cpu(), r.numpy())
+    ctx = po.Ctx(sd, emulate="fp16")
+    emu = po.rsgnet_forward(sd, cfg, x, want_scores=False, ctx=ctx)
+    plan = model.plan_for(xc)
+    bars = EMU_BARS[tag]
+    for name, t, r, g in (("multi", multi, emu[0], "multi_kpt_scores"), ("kpt", kpt, emu[1], "kpt_scores")):
+        e = _stats(f"{tag.split('_')[-1]} {name} vs fp16-emulating oracle", t.cpu(), r.numpy())
+        sig = float(gold[g + "_crop0"].std())
+        assert e < bars[name] * sig, (name, e / sig)
+    _stats(f"{tag.split('_')[-1]} limbs vs fp16-emulating oracle", limbs.cpu(), emu[2].numpy())
+    lo = ctx.taps["limbs_logits"]
+    e = _stats(f"{tag.split('_')[-1]} limb logits (low res) vs fp16-emulating oracle", plan.limbs_lo.cpu(), lo.numpy())
+    assert e < bars["limbs_logits"] * float(lo.std()), e / float(lo.std())
+    # intermediate maps against the reference-captured taps (crop 0): backbone stages, the contact clue, TRP output
+    _check_backbone_taps(plan, x, gold)
+    with torch.no_grad():
+        model(xc)                                     # fvis / TRP output are pinned buffers: valid after a run
+    torch.cuda.synchronize()
+    fv = _tap_nchw(plan.fvis.tensor(2))
+    ref = gold["final_vis_crop0"]
+    assert _stats("tap final_vis", fv, ref) < TAP_REL_TOL * float(ref.std())
+    rf = _tap_nchw(plan.fvis.base.tensor(2)[..., :plan.C0])
+    ref = gold["relation_feats_crop0"]
+    assert _stats("tap relation_feats", rf, ref) < TAP_REL_TOL * float(ref.std())
 
 
 CROWDPOSE_FLIP_PAIRS = [[0, 1], [2, 3], [4, 5], [6, 7], [8, 9], [10, 11]]      # lib/dataset/crowdpose.py:988-989
@@ -236,8 +304,10 @@ def test_hrnet_w32_bf16_path_runs_and_is_coarser(tag):
     with torch.no_grad():
         y = model(x.cuda()).cpu()
     ref = gold["heatmaps_crop0"]
-    e = _stats("bf16 heatmaps", y[0], ref)
-    assert torch.isfinite(y).all() and e < 0.6 * float(ref.std())
+    e = _stats(f"{tag} bf16 heatmaps", y[0], ref)
+    # the bf16-emulating ORACLE is itself 4.7e-2 = 0.16 sigma from the fp32 golden on HRNet-W32 (VERDICT round 2,
+    # re-derived on the CPU): the bar is twice that floor (was 0.6 sigma)
+    assert torch.isfinite(y).all() and e < 0.32 * float(ref.std()), e / float(ref.std())
 
 
 @pytest.mark.parametrize("tag", ["hrnet_w32_256x192", "hrnet_w48_384x288"])
@@ -354,3 +424,47 @@ def test_chain_tails_change_no_bits(monkeypatch):
     assert ntails >= 8 * 3 and sum(e.get("tails", 0) for e in plan0.conv_log) == 0
     assert torch.equal(y1, y0)
     assert n1 <= len(plan0.ops)
+
+
+def test_flip_test_forward_rsgnet_crowdpose():
+    """BASELINE configs[4]: the CrowdPose RSGNet (14 joints, cp_kpt_word_embs) under the flip test -- one 2B forward and
+    the fused merge (rsgnet_amd/flip.py) against the reference's procedure restated on the oracle: two forwards, host
+    flip_back with CrowdPose's pairs, one-pixel shift, average (lib/core/function.py:400-427 applies it to output[1],
+    the joints-of-target heat maps)."""
+    from rsgnet_amd.flip import forward_flip_test
+    tag = "rsgnet_w32_256x192_crowdpose"
+    cfg, model, sd, x, gold = load_case(tag)
+    model = model.cuda()
+    with torch.no_grad():
+        got = forward_flip_test(model, x.cuda(), CROWDPOSE_FLIP_PAIRS).cpu()
+    a = po.rsgnet_forward(sd, cfg, x, want_scores=False)[1]
+    b = po.rsgnet_forward(sd, cfg, x.flip(3), want_scores=False)[1]
+    want = po.flip_test_merge(a, b, CROWDPOSE_FLIP_PAIRS)
+    assert got.shape == want.shape == (2, 14, 128, 96)
+    e = _stats("crowdpose flip-test kpt heat maps", got, want.numpy())
+    assert e < REL_TOL * float(want.std())
+    ea = po.rsgnet_forward(sd, cfg, x, want_scores=False, emulate="fp16")[1]
+    eb = po.rsgnet_forward(sd, cfg, x.flip(3), want_scores=False, emulate="fp16")[1]
+    e2 = _stats("crowdpose flip-test vs fp16-emulating oracle", got, po.flip_test_merge(ea, eb, CROWDPOSE_FLIP_PAIRS).numpy())
+    assert e2 < EMU_BARS[tag]["kpt"] * float(want.std())
+
+
+def test_dataparallel_wrap_and_module_state_dict():
+    """the reference wraps the model in nn.DataParallel (tools/cp_test.py:99, cp_train.py:115) and saves
+    model.module.state_dict() (cp_train.py:221,238).  One visible device here: the wrap must forward through the HIP
+    plan unchanged, and the wrapped module's state_dict must be the reference's key set."""
+    from tests.util import manifest
+    for tag in ("hrnet_w32_256x192", "rsgnet_w32_256x192_crowdpose"):
+        cfg, model, sd, x, gold = load_case(tag)
+        dp = torch.nn.DataParallel(model, device_ids=[0]).cuda()
+        with torch.no_grad():
+            y = dp(x.cuda())
+            y0 = model(x.cuda())
+        if tag.startswith("hrnet"):
+            assert torch.equal(y, y0)
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(y[:3], y0[:3]))
+        msd = dp.module.state_dict()
+        assert list(msd.keys()) == list(manifest(tag)["state_dict"].keys())
+        assert all(torch.equal(msd[k].cpu(), sd[k]) for k in sd)
+        assert all(k.startswith("module.") for k in dp.state_dict())

@@ -780,3 +780,117 @@ def test_bottleneck_fused_through_the_plan():
     scale = float(outs["0"].std())
     # two fp16 evaluation orders of layer1 seen through 30 more layers: the fp16 noise floor of the whole network
     assert float((outs["0"] - outs["1"]).abs().max()) < 3e-2 * scale
+
+
+def _pack(w, scale, shift, dtype="fp16"):
+    lib = hip.lib()
+    O, I, kh, kw = w.shape
+    wp = np.zeros(lib.rsg_conv_packed_bytes(I, O, kh, kw), np.uint8)
+    bo = np.zeros((O + 31) // 32 * 32, np.float32)
+    wn, sn, hn = (np.ascontiguousarray(t.numpy()) for t in (w, scale, shift))
+    hip.check(lib.rsg_pack_conv_weights_host(wn.ctypes.data, sn.ctypes.data, hn.ctypes.data, None, I, O, kh, kw,
+                                             hip.DTYPES[dtype], wp.ctypes.data, bo.ctypes.data))
+    return torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+
+
+@pytest.mark.parametrize("batch", [3, 8])
+def test_conv_fuse_group_matches_cpu(batch):
+    """The PRODUCTION fuse launches of a HighResolutionModule (rsg_conv_fuse_group_plan / _run, csrc/group.hip; what
+    plan.py records for pose_hrnet.py:190-268) on a three-branch module, against fp64 on the CPU with 16-bit rounding
+    where the launches store 16 bits: level 0 = every 1x1 "up" conv, the first strided conv of every "down" path;
+    level 1 = the second strided conv of path 2<-0 with the module's last sum folded into its epilogue (three residual
+    operands), plus the fuse-sums of outputs 0 and 1 (same-resolution and nearest-up-sampled operands)."""
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(40 + batch)
+    B, H, W = batch, 16, 12
+    chans = [32, 64, 128]
+    xs = [torch.randn(B, c, H >> i, W >> i, generator=g).relu() for i, c in enumerate(chans)]
+    h16 = lambda t: t.to(torch.float16)
+
+    def dev(t):     # NCHW fp32 -> NHWC fp16 on the device
+        return h16(t.permute(0, 2, 3, 1)).contiguous().to(DEV)
+
+    xd = [dev(t) for t in xs]
+    convs = {}      # name -> (src index or name, cout, k, stride, relu)
+    spec = [("u01", 1, 32, 1, 1, False), ("u02", 2, 32, 1, 1, False), ("u12", 2, 64, 1, 1, False),
+            ("d10", 0, 64, 3, 2, False), ("d20a", 0, 32, 3, 2, True), ("d21", 1, 128, 3, 2, False)]
+    params = {}
+    for name, src, cout, k, s, relu in spec + [("d20b", "d20a", 128, 3, 2, True)]:
+        cin = chans[src] if isinstance(src, int) else 32
+        w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        params[name] = (w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, src, k, s, relu)
+    keep = []
+
+    def desc(name, inp, in_hw, out, res=()):
+        w, sc, sh, src, k, s, relu = params[name]
+        wp, bo = _pack(w, sc, sh)
+        keep.extend([wp, bo])
+        d = hip.ConvDesc()
+        d.inp, d.w_packed, d.bias, d.out16 = inp.data_ptr(), wp.data_ptr(), bo.data_ptr(), out.data_ptr()
+        cin, cout = w.shape[1], w.shape[0]
+        pad = (k - 1) // 2
+        ho, wo = (in_hw[0] + 2 * pad - k) // s + 1, (in_hw[1] + 2 * pad - k) // s + 1
+        d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, in_hw[0], in_hw[1], cin, cin
+        d.out_h, d.out_w, d.out_c, d.out_ld = ho, wo, cout, cout
+        d.kh = d.kw = k
+        d.stride, d.pad_y, d.pad_x = s, pad, pad
+        d.up, d.phys_h, d.phys_w, d.relu, d.dtype = 1, ho, wo, int(relu), hip.RSG_F16
+        if res:
+            d.residual, d.res_ld = res[0].data_ptr(), cout
+            if len(res) > 1:
+                d.residual2, d.res2_ld = res[1].data_ptr(), cout
+            if len(res) > 2:
+                d.residual3, d.res3_ld = res[2].data_ptr(), cout
+        return d
+
+    nan16 = lambda c, h, w: torch.full((B, h, w, c), float("nan"), dtype=torch.float16, device=DEV)
+    o = {"u01": nan16(32, 8, 6), "u02": nan16(32, 4, 3), "u12": nan16(64, 4, 3), "d10": nan16(64, 8, 6),
+         "d20a": nan16(32, 8, 6), "d21": nan16(128, 4, 3), "out2": nan16(128, 4, 3), "out0": nan16(32, 16, 12),
+         "out1": nan16(64, 8, 6)}
+
+    def run(descs, fuses):
+        cd = (hip.ConvDesc * max(len(descs), 1))(*descs)
+        fi = (hip.FuseItem * max(len(fuses), 1))(*fuses)
+        table = np.zeros(lib.rsg_group_table_bytes(), np.uint8)
+        l2 = (C.c_int32 * 2)()
+        hip.check(lib.rsg_conv_fuse_group_plan(cd, len(descs), fi, len(fuses), hip.RSG_F16, table.ctypes.data, l2), "plan")
+        hip.check(lib.rsg_conv_fuse_group_run(table.ctypes.data, l2[0], l2[1], hip.RSG_F16, _stream()), "run")
+        torch.cuda.synchronize()
+
+    run([desc(n, xd[params[n][3]], (H >> params[n][3], W >> params[n][3]), o[n]) for n, *_ in spec], [])
+
+    def fuse_item(same, low, out, h, w, c):
+        it = hip.FuseItem()
+        for k, t in enumerate(same):
+            it.same[k], it.same_ld[k] = t.data_ptr(), c
+        for k, (t, sh) in enumerate(low):
+            it.low[k], it.low_shift[k], it.low_ld[k] = t.data_ptr(), sh, c
+        it.n_same, it.n_low, it.out, it.batch, it.h, it.w, it.c = len(same), len(low), out.data_ptr(), B, h, w, c
+        return it
+
+    run([desc("d20b", o["d20a"], (8, 6), o["out2"], res=(xd[2], o["d21"]))],
+        [fuse_item([xd[0]], [(o["u01"], 1), (o["u02"], 2)], o["out0"], 16, 12, 32),
+         fuse_item([o["d10"], xd[1]], [(o["u12"], 1)], o["out1"], 8, 6, 64)])
+
+    # ---- fp64 on the CPU, rounding to 16 bits wherever a launch stores 16 bits
+    def cref(name, x):
+        w, sc, sh, _src, k, s, relu = params[name]
+        return ref_conv(x, w, sc, sh, None, s, relu, None)
+
+    r = {n: h16(cref(n, xs[params[n][3]].float()).float()).double() for n, *_ in spec}
+    x16 = [h16(t).double() for t in xs]
+    up = lambda t, f: F.interpolate(t, scale_factor=f, mode="nearest")
+    want0 = F.relu(x16[0] + up(r["u01"], 2) + up(r["u02"], 4))
+    want1 = F.relu(r["d10"] + x16[1] + up(r["u12"], 2))
+    want2 = F.relu(ref_conv(r["d20a"].float(), params["d20b"][0], params["d20b"][1], params["d20b"][2], None, 2, False, None)
+                   + x16[2] + r["d21"])
+    for name, want in (("out0", want0), ("out1", want1), ("out2", want2)):
+        got = o[name].float().cpu().permute(0, 3, 1, 2).double()
+        err = (got - want).abs()
+        tol = 1e-4 * float(want.abs().max()) + 1e-5
+        assert torch.isfinite(got).all(), name
+        assert float((err - want.abs() * 2.0 ** -10).max()) <= tol, (name, float(err.max()))
+    for n, *_ in spec:       # the level-0 maps themselves
+        got = o[n].float().cpu().permute(0, 3, 1, 2).double()
+        want = cref(n, xs[params[n][3]].float())
+        assert float(((got - want).abs() - want.abs() * 2.0 ** -10).max()) <= 1e-4 * float(want.abs().max()) + 1e-5, n

@@ -235,3 +235,92 @@ def test_data_parallel_training_two_ranks_on_the_gpu():
         opt.step()
     torch.cuda.synchronize()
     assert np.array_equal(opt.flat_param.detach().cpu().numpy(), res[0][1])
+
+
+# The in-place fold of a data gradient into an existing one (RSGNET_HIP_TRAIN_FOLD_ADD) removes one bf16 rounding of the
+# gradient MAP per BasicBlock; the difference random-walks down ~50 blocks (2^-9 * sqrt(50) ~ 1.4e-2 on the earliest
+# layers' maps).  A missing or doubled contribution anywhere moves a tensor by O(0.3-1).
+FOLD_BAR = 3e-2
+
+
+def _one_step_grads(monkeypatch, env):
+    """(heat maps, {name: gradient}) of one training step under the given RSGNET_HIP_TRAIN_* switches."""
+    from rsgnet_amd.loss import JointsMSELoss
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg, model, sd, x, target, tw, gold = _case()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    outs = []
+    for rep in range(3):                     # the third step replays the captured graphs (when graphs are on)
+        for p in model.parameters():
+            p.grad = None
+        model.load_state_dict(sd)            # same running statistics at every repetition
+        model.train()
+        out = model(x.cuda())
+        JointsMSELoss(True)(out, target.cuda(), tw.cuda()).backward()
+        torch.cuda.synchronize()
+        outs.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
+    for n in outs[0][1]:
+        assert torch.equal(outs[0][1][n], outs[2][1][n]), (n, "eager launches vs graph replay")
+    for k in env:
+        monkeypatch.delenv(k)
+    return outs[2]
+
+
+@pytest.mark.gpu
+def test_training_step_composition_is_independent_of_the_launch_structure(monkeypatch):
+    """The Python side of the training plan (rsgnet_amd/train.py) decides who writes a gradient buffer first and who
+    adds, folds data gradients into existing ones, defers the contributions of fuse lanes that share an input, reorders
+    lane buckets by kind, pipelines the weight-gradient reduction into the next launch and captures segments as HIP
+    graphs.  None of that may change WHAT is computed: with every switch off (one launch per op, eager, adds in
+    recording order) each gradient tensor must equal the default path's -- bit for bit where the operation order is
+    the same, within one bf16 rounding of the gradient MAP where the fold removes a rounding (the parameter gradients
+    are fp32 sums over those maps, so they move by a relative 2^-9 at most, far below the 1e-2 a wrong composition
+    in one layer would leave)."""
+    base = _one_step_grads(monkeypatch, {})
+    plain = _one_step_grads(monkeypatch, {"RSGNET_HIP_TRAIN_LANES": "0", "RSGNET_HIP_TRAIN_FUSE_LANES": "0",
+                                          "RSGNET_HIP_TRAIN_FOLD_ADD": "0", "RSGNET_HIP_TRAIN_WGRAD_PIPE": "0",
+                                          "RSGNET_HIP_TRAIN_GRAPH": "0"})
+    assert torch.equal(base[0], plain[0])                 # the forward has no such freedom at all
+    worst = []
+    for n, g in base[1].items():
+        h = plain[1][n]
+        den = float(h.double().norm())
+        rel = float((g.double() - h.double()).norm()) / max(den, 1e-30)
+        worst.append((rel, n))
+    worst.sort(reverse=True)
+    print("composition: largest relative L2 differences", worst[:5])
+    assert worst[0][0] < FOLD_BAR, worst[:8]
+    # each switch alone against the default, same bar: a failure names the switch
+    for k in ("RSGNET_HIP_TRAIN_LANES", "RSGNET_HIP_TRAIN_FOLD_ADD", "RSGNET_HIP_TRAIN_WGRAD_PIPE"):
+        one = _one_step_grads(monkeypatch, {k: "0"})
+        bad = [(float((one[1][n].double() - g.double()).norm()) / max(float(g.double().norm()), 1e-30), n) for n, g in base[1].items()]
+        bad.sort(reverse=True)
+        print(k, "= 0:", bad[:2])
+        assert bad[0][0] < FOLD_BAR, (k, bad[:6])
+        if k != "RSGNET_HIP_TRAIN_FOLD_ADD":              # no rounding differs: same sums in the same order
+            assert bad[0][0] == 0.0, (k, bad[:6])
+
+
+@pytest.mark.gpu
+def test_training_plan_refuses_a_stale_or_second_backward():
+    """One activation arena per (batch, device): a backward whose forward was overwritten by a later training-mode
+    forward, or a second backward through the same forward, must raise instead of using the wrong activations."""
+    from rsgnet_amd.loss import JointsMSELoss
+    cfg, model, sd, x, target, tw, gold = _case()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    crit = JointsMSELoss(True)
+    out1 = model(x.cuda())
+    loss1 = crit(out1, target.cuda(), tw.cuda())
+    out2 = model(x.flip(3).cuda())                       # a second forward before the first backward
+    loss2 = crit(out2, target.cuda(), tw.cuda())
+    with pytest.raises(RuntimeError, match="activations are gone"):
+        loss1.backward()
+    loss2.backward()                                      # the live one is fine
+    out3 = model(x.cuda())
+    l3 = crit(out3, target.cuda(), tw.cuda())
+    l3.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        l3.backward()

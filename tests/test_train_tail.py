@@ -182,6 +182,55 @@ def test_fused_adam_checkpoint_round_trip_against_torch_adam():
         assert (q.detach() - r.detach()).abs().max().item() < 5e-6
 
 
+@pytest.mark.gpu
+def test_fused_adam_resume_under_multisteplr_like_the_reference_trainer():
+    """tools/cp_train.py:184-193: optimizer.load_state_dict(checkpoint['optimizer']) and then
+    MultiStepLR(optimizer, LR_STEP, LR_FACTOR, last_epoch=checkpoint['epoch']).  torch raises KeyError unless the loaded
+    param_group still carries the scheduler's `initial_lr`; lr and the next steps must equal an uninterrupted run."""
+    from torch.optim.lr_scheduler import MultiStepLR
+    from rsgnet_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    shapes = ((6, 3), (17,), (2, 3, 3))
+    init = [torch.randn(s) for s in shapes]
+    grads = [[torch.randn(s) for s in shapes] for _ in range(6)]
+    mk = lambda ts: [torch.nn.Parameter(t.detach().clone().cuda()) for t in ts]
+
+    def epoch(opt, ps, k):
+        for q, g in zip(ps, grads[k]):
+            q.grad.copy_(g) if q.grad is not None else setattr(q, "grad", g.cuda().clone())
+        opt.step()
+
+    # uninterrupted: 6 epochs, lr drops after epochs 2 and 4
+    ps = mk(init)
+    opt = FusedAdam(ps, lr=1e-2)
+    sch = MultiStepLR(opt, [2, 4], 0.1)
+    lrs, ckpt = [], None
+    for k in range(6):
+        epoch(opt, ps, k)
+        sch.step()
+        lrs.append(opt.param_groups[0]["lr"])
+        if k == 2:
+            ckpt = dict(epoch=k + 1, optimizer=opt.state_dict(), params=[q.detach().clone() for q in ps])
+    assert "initial_lr" in ckpt["optimizer"]["param_groups"][0]
+    # resumed: a NEW optimizer built with the config's lr, state loaded, scheduler built with last_epoch
+    ps2 = mk(ckpt["params"])
+    opt2 = FusedAdam(ps2, lr=1e-2)
+    opt2.load_state_dict(ckpt["optimizer"])
+    assert opt2.param_groups[0]["initial_lr"] == 1e-2
+    sch2 = MultiStepLR(opt2, [2, 4], 0.1, last_epoch=ckpt["epoch"])      # KeyError before the fix
+    assert opt2.param_groups[0]["lr"] == pytest.approx(lrs[2])
+    for k in range(3, 6):
+        epoch(opt2, ps2, k)
+        sch2.step()
+        assert opt2.param_groups[0]["lr"] == pytest.approx(lrs[k])
+    for q, r in zip(ps2, ps):
+        assert torch.equal(q.detach(), r.detach())        # same kernel, same inputs, same step counts: same bits
+    with pytest.raises(ValueError):                       # still no weight decay on this path
+        bad = opt.state_dict()
+        bad["param_groups"][0]["weight_decay"] = 1e-4
+        FusedAdam(mk(init), lr=1e-2).load_state_dict(bad)
+
+
 def _dp_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
