@@ -44,6 +44,25 @@ def pmc_traffic(kernel_key, workload="hrnet_w32_256x192"):
     return {"bytes_per_launch": int((d["fetch_mb_per_launch"] + d["write_mb_per_launch"]) * 1e6),
             "fetch_mb": d["fetch_mb_per_launch"], "write_mb": d["write_mb_per_launch"],
             "source": os.path.basename(files[-1])}
+def pmc_mfma_busy(kernel_prefix, workload="hrnet_w32_256x192"):
+    """Matrix-pipe utilisation of a kernel from the committed SQ counter pass (profiles/*_sq_summary.json, tools/gpu_sq.sh +
+    tools/sq_summary.py): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the fraction of SIMD
+    cycles AT THE CLOCK THE CHIP HELD in which an MFMA executed (the clock under load is 2.0-2.1 GHz, not the 2.4 GHz
+    behind the 2.5 PFLOP/s peak that `frac` is priced against).  Headline workload only."""
+    import glob
+    if workload != "hrnet_w32_256x192":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_summary.json")))
+    for path in reversed(files):
+        with open(path) as f:
+            d = json.load(f)
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and v.get("mfma_busy_frac") is not None:
+                return {"mfma_busy_frac": v["mfma_busy_frac"], "wait_any_frac": v.get("wait_any_frac"),
+                        "wait_inst_any_frac": v.get("wait_inst_any_frac"), "source": os.path.basename(path)}
+    return None
+
+
 WORKLOADS = {
     "hrnet_w32_256x192": ("pose_hrnet", 32, (192, 256), 17, 64),
     "rsgnet_w32_256x192_coco": ("pose_rsgnet", 32, (192, 256), 17, 64),
@@ -465,6 +484,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel", a.workload),
+                         "mfma_util": pmc_mfma_busy("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel", a.workload),
                          "algorithmic_mb_per_launch": dom.get("alg_mb_per_launch"),
                          "kernel": dom_name, "launches": dom["launches"], "kernel_us_per_step": dom["us"],
                          "kernel_gflop_per_step": dom["gflop"],

@@ -301,6 +301,18 @@ size_t rsg_trp_tail_workspace_bytes(int32_t batch, int32_t S, int32_t C);
 int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,
                  const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
                  int32_t dtype, void* workspace, void* stream);
+/* RELATION_SUB_SAMPLE variant of the TRP (/root/reference/lib/models/association.py:254-268,286-287; set by
+ * experiments/crowdpose/hrnet/"rsgnet_w48_256x192_adam_lr1e-3 .yaml":42): the relation runs on the 2x2 max-pooled map
+ * and an up-sampling deconv + BatchNorm + ReLU precedes W.
+ *  rsg_maxpool2x2_nhwc16   nn.MaxPool2d((2,2)) on a 16-bit NHWC map in[b,y,x,0:c] (channel strides in_ld / out_ld)
+ *  rsg_f32_rows_to_nhwc16  E fp32 [rows,c] -> 16-bit rows of stride out_ld (the deconv is an MFMA conv on 16-bit maps)
+ *  rsg_trp_tail_in16       rsg_trp_tail whose input is the deconv's 16-bit NHWC output (stride e_ld) instead of fp32 E */
+int rsg_maxpool2x2_nhwc16(const void* in, int32_t in_ld, void* out, int32_t out_ld, int32_t batch, int32_t h, int32_t w,
+                          int32_t c, int32_t dtype, void* stream);
+int rsg_f32_rows_to_nhwc16(const float* in, void* out, int32_t out_ld, int64_t rows, int32_t c, int32_t dtype, void* stream);
+int rsg_trp_tail_in16(const void* e16, int32_t e_ld, const float* w, const float* bias, const float* gn_gamma,
+                      const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
+                      int32_t dtype, void* workspace, void* stream);
 /* optional materialisation of relation_score [batch,S,S] fp32 (association.py:294-295) */
 int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S, int32_t C,
                    int32_t dtype, void* stream);

@@ -43,6 +43,8 @@ CONFIGS = {
     "rsgnet_w32_256x192_crowdpose": ("pose_rsgnet", 32, (192, 256), 14),
     "hrnet_w48_384x288": ("pose_hrnet", 48, (288, 384), 17),
     "rsgnet_w48_384x288_coco": ("pose_rsgnet", 48, (288, 384), 17),
+    # experiments/crowdpose/hrnet/"rsgnet_w48_256x192_adam_lr1e-3 .yaml": RELATION_SUB_SAMPLE: true (line 42)
+    "rsgnet_w48_256x192_crowdpose_sub": ("pose_rsgnet", 48, (192, 256), 14, dict(sub_sample=True)),
 }
 CAL_BATCH, CAL_SEED = 4, 100
 EVAL_BATCH, EVAL_SEED = 2, 0
@@ -64,8 +66,8 @@ def _summ(t: torch.Tensor):
 
 
 def generate(tag: str) -> None:
-    name, width, wh, joints = CONFIGS[tag]
-    cfg = make_cfg(name, width, wh, joints)
+    name, width, wh, joints = CONFIGS[tag][:4]
+    cfg = make_cfg(name, width, wh, joints, **(CONFIGS[tag][4] if len(CONFIGS[tag]) > 4 else {}))
     is_rsg = name == "pose_rsgnet"
     t0 = time.time()
     ref = ri.build(cfg)

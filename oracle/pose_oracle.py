@@ -78,12 +78,21 @@ class Ctx:
     """Walk state: the weights, the mode switches and a few taps for block-level tests."""
 
     def __init__(self, sd: Mapping[str, torch.Tensor], dtype=torch.float32, calibrate=False,
-                 emulate: Optional[str] = None):
+                 emulate: Optional[str] = None, relu_masks: Optional[Mapping[str, torch.Tensor]] = None):
         self.sd: Dict[str, torch.Tensor] = sd if calibrate else dict(sd)
         self.dtype = dtype
         self.calibrate = calibrate
         self.emu = {None: None, "fp16": torch.float16, "bf16": torch.bfloat16}[emulate]
         self.taps: Dict[str, torch.Tensor] = {}
+        # teacher forcing (tests of the training path): {BatchNorm name or "<module>.fuse.<i>": 0/1 map [B,C,H,W]} taken
+        # from ANOTHER implementation's activations; a ReLU whose key is present multiplies by that map instead of
+        # deciding for itself, so both implementations differentiate the same piecewise-linear function
+        self.relu_masks = relu_masks
+
+    def relu(self, y: torch.Tensor, key: Optional[str]) -> torch.Tensor:
+        if self.relu_masks is not None and key is not None and key in self.relu_masks:
+            return y * self.relu_masks[key].to(y.dtype)
+        return F.relu(y)
 
     def p(self, name: str) -> torch.Tensor:
         return self.sd[name].to(self.dtype)
@@ -141,7 +150,7 @@ def conv_unit(ctx: Ctx, x, conv: str, bn: Optional[str] = None, *, stride=1, rel
             y = y * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)
         if residual is not None:
             y = y + residual
-        return F.relu(y) if relu else y
+        return ctx.relu(y, bn) if relu else y
 
     if bn is not None:
         s, t = _bn_coeffs(ctx, bn, None)
@@ -205,7 +214,7 @@ def hr_module(ctx: Ctx, xs: List[torch.Tensor], pre: str, n_out: int):
                     t = conv_unit(ctx, t, f"{fl}.{k}.0", f"{fl}.{k}.1", stride=2,
                                   relu=(k != i - j - 1))
             y = t if y is None else y + t
-        outs.append(ctx.store(F.relu(y)))
+        outs.append(ctx.store(ctx.relu(y, f"{pre}.fuse.{i}")))
     return outs
 
 
@@ -287,11 +296,16 @@ def kt_machine(ctx: Ctx, wk: torch.Tensor) -> torch.Tensor:
 
 
 def relation_head(ctx: Ctx, x, want_scores=True):
-    """SpatialRelationHead.forward (sub_sample=False), association.py:280-301.
+    """SpatialRelationHead.forward, association.py:280-301.
 
     Returns (relation_embs [B,C,H,W], relation_score [B,S,S] or None).  theta = phi = x (no
-    projection), attention is an un-normalised sigmoid of the Gram matrix.
+    projection), attention is an un-normalised sigmoid of the Gram matrix.  With sub_sample
+    (association.py:254-268,286-287; recognised by the W.0.0 deconv in the state dict) x is 2x2 max-pooled first
+    (S -> S/4) and W = deconv4x4s2 -> BatchNorm -> ReLU -> 1x1 -> GroupNorm brings the map back to H x W.
     """
+    sub = ctx.has("relation_head.W.0.0.weight")
+    if sub:
+        x = F.max_pool2d(x, 2)                                  # nn.MaxPool2d(kernel_size=(2, 2)), :286-287
     b, c, h, w = x.shape
     g = F.conv2d(x, ctx.p("relation_head.g.weight"), ctx.p("relation_head.g.bias"))
     g = g.view(b, c, -1).permute(0, 2, 1)                      # [B,S,C]
@@ -305,8 +319,13 @@ def relation_head(ctx: Ctx, x, want_scores=True):
             scores[i] = r
     e = embs.permute(0, 2, 1).contiguous().view(b, c, h, w)
     ctx.taps["relation_embs_raw"] = e
-    e = F.conv2d(e, ctx.p("relation_head.W.0.weight"), ctx.p("relation_head.W.0.bias"))
-    e = F.group_norm(e, 8, ctx.p("relation_head.W.1.weight"), ctx.p("relation_head.W.1.bias"), BN_EPS)
+    if sub:
+        e = conv_unit(ctx, ctx.store(e), "relation_head.W.0.0", "relation_head.W.0.1", relu=True, transposed=True)
+        e = F.conv2d(e, ctx.p("relation_head.W.1.0.weight"), ctx.p("relation_head.W.1.0.bias"))
+        e = F.group_norm(e, 8, ctx.p("relation_head.W.1.1.weight"), ctx.p("relation_head.W.1.1.bias"), BN_EPS)
+    else:
+        e = F.conv2d(e, ctx.p("relation_head.W.0.weight"), ctx.p("relation_head.W.0.bias"))
+        e = F.group_norm(e, 8, ctx.p("relation_head.W.1.weight"), ctx.p("relation_head.W.1.bias"), BN_EPS)
     return ctx.store(e), scores
 
 

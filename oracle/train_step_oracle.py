@@ -60,9 +60,11 @@ def gaussian_targets(batch: int, joints: int, hw: Tuple[int, int], seed: int, si
 
 
 def hrnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor,
-                     use_target_weight: bool = True, dtype=torch.float64):
+                     use_target_weight: bool = True, dtype=torch.float64, relu_masks=None):
     """One forward/backward of pose_hrnet in train() mode.
-    Returns (loss, heatmaps, {param name: gradient}, {buffer name: running statistic after the step})."""
+    Returns (loss, heatmaps, {param name: gradient}, {buffer name: running statistic after the step}).
+    relu_masks: teacher forcing (pose_oracle.Ctx.relu_masks): every ReLU listed there takes its 0/1 decisions from the
+    given map, so the gradient is that of the SAME piecewise-linear function another implementation differentiated."""
     work: Dict[str, torch.Tensor] = {}
     for k, v in sd.items():
         t = v.detach().clone()
@@ -70,7 +72,7 @@ def hrnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, targe
             t = t.to(dtype).requires_grad_(True)
         work[k] = t
     old = {k: v.detach().clone().double() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}
-    ctx = po.Ctx(work, dtype=dtype, calibrate=True)          # calibrate = batch statistics (training-mode BatchNorm)
+    ctx = po.Ctx(work, dtype=dtype, calibrate=True, relu_masks=relu_masks)   # calibrate = batch statistics (training-mode BatchNorm)
     ctx.sd = dict(work)                                       # the walk overwrites running stats; keep `work` intact
     ys = po.backbone(ctx, x.to(dtype), cfg)
     w, b = ctx.p("final_layer.weight"), ctx.p("final_layer.bias")

@@ -86,13 +86,15 @@ _BACKBONE = ["conv1", "bn1", "conv2", "bn2", "layer1", "transition1", "stage2", 
 
 
 def make_cfg(name: str = "pose_hrnet", width: int = 32, image_wh: Sequence[int] = (192, 256),
-             num_joints: int = 17, num_limbs: int | None = None) -> Cfg:
+             num_joints: int = 17, num_limbs: int | None = None, sub_sample: bool = False) -> Cfg:
     """The MODEL section of the reference's experiment yamls, built in code.
 
     ``make_cfg('pose_hrnet', 32)`` == experiments/coco/hrnet/w32_256x192_adam_lr1e-3.yaml:25-85,
     ``make_cfg('pose_rsgnet', 32)`` == experiments/coco/hrnet/rsgnet_w32_256x192_adam_lr1e-3.yaml:26-105,
     ``make_cfg('pose_rsgnet', 32, num_joints=14)`` == the CrowdPose yaml (NUM_LIMBS 14),
-    ``make_cfg('pose_rsgnet', 48, (288, 384))`` == rsgnet_w48_384x288 with NUM_TYPE_VECTOR as an int.
+    ``make_cfg('pose_rsgnet', 48, (288, 384))`` == rsgnet_w48_384x288 with NUM_TYPE_VECTOR as an int,
+    ``make_cfg('pose_rsgnet', 48, num_joints=14, sub_sample=True)`` == experiments/crowdpose/hrnet/
+    "rsgnet_w48_256x192_adam_lr1e-3 .yaml" (the one shipped config with RELATION_SUB_SAMPLE: true, line 42).
     """
     w = int(width)
     chans = [w, 2 * w, 4 * w, 8 * w]
@@ -106,6 +108,6 @@ def make_cfg(name: str = "pose_hrnet", width: int = 32, image_wh: Sequence[int] 
             num_limbs = 18 if num_joints == 17 else 14
         extra["OUTPUT_CONVS"] = list(chans)
         model.update(NUM_LIMBS=num_limbs, FINAL_DECONV_KERNEL_SIZE=4, NUM_TYPE_VECTOR=600,
-                     UP_SCALE=2, RELATION_SUB_SAMPLE=False,
+                     UP_SCALE=2, RELATION_SUB_SAMPLE=bool(sub_sample),
                      HEATMAP_SIZE=[image_wh[0] // 2, image_wh[1] // 2])
     return as_cfg(dict(MODEL=model))

@@ -301,6 +301,7 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
 #pragma unroll
                     for (int r = 0; r < 16; ++r) t1[c][j][r] = bn[r];
             }
+            RSG_CSTAMP(5);
             for (int ct2 = 0; ct2 < ntile2; ++ct2) {
                 const int cb2 = ct2 * 32 + hh * 16;
                 uint4 a2[KSE], an[2][2];
@@ -371,6 +372,7 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
                             t1[c][j] = DT::mfma(__builtin_bit_cast(typename DT::vec8, an[c][k]), __builtin_bit_cast(typename DT::vec8, o[k]), t1[c][j]);
                 }
             }
+            RSG_CSTAMP(6);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (op[j] < 0) continue;

@@ -231,6 +231,7 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
 template <class DT>
 __global__ void __launch_bounds__(256) conv_pair_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    RSG_CSTAMP(0);
     conv_body<DT, 64, 3, 3, 2, 2, 3, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 
@@ -238,6 +239,7 @@ __global__ void __launch_bounds__(256) conv_pair_kernel(const ConvArgs p) {
 template <class DT>
 __global__ void __launch_bounds__(256) conv_pair_next_kernel(const ConvNextArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    RSG_CSTAMP(0);
     conv_body<DT, 64, 3, 3, 2, 2, 4, true, 0, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 
@@ -245,6 +247,7 @@ __global__ void __launch_bounds__(256) conv_pair_next_kernel(const ConvNextArgs 
 template <class DT>
 __global__ void __launch_bounds__(256) conv_pair_next_cat_kernel(const ConvNextArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    RSG_CSTAMP(0);
     conv_body<DT, 64, 3, 3, 2, 2, 4, true, 0, true, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
 }
 

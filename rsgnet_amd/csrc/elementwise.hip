@@ -323,3 +323,80 @@ extern "C" int rsg_decode_heatmaps(const float* heat, const float* center, const
     RSG_CHECK_LAUNCH("decode");
     return 0;
 }
+
+
+// ---- TRP with RELATION_SUB_SAMPLE (association.py:254-268,286-287) --------------------------------------------
+// nn.MaxPool2d(kernel_size=(2, 2)) on a 16-bit NHWC map (a channel slice of a wider buffer: stride in_ld): one thread
+// per 8 channels of an output pixel, four 16-byte loads, one 16-byte store.  Max of 16-bit values is exact.
+template <class DT>
+__global__ void __launch_bounds__(256) maxpool2x2_kernel(const char* __restrict__ in, int in_ld, char* __restrict__ out,
+                                                        int out_ld, int ho, int wo, int c8, unsigned total) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const unsigned pix = i / (unsigned)c8, cg = i - pix * (unsigned)c8;
+    const unsigned t = pix / (unsigned)wo, x = pix - t * (unsigned)wo;
+    const unsigned b = t / (unsigned)ho, y = t - b * (unsigned)ho;
+    const int wi = 2 * wo;
+    const size_t p00 = ((size_t)b * (2 * ho) + 2 * y) * wi + 2 * x;
+    float m[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t src = p00 + (size_t)(q >> 1) * wi + (q & 1);
+        const uint4 raw = *reinterpret_cast<const uint4*>(in + (src * in_ld + cg * 8) * 2);
+        const typename DT::vec8 v = __builtin_bit_cast(typename DT::vec8, raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = q == 0 ? (float)v[e] : fmaxf(m[e], (float)v[e]);
+    }
+    typename DT::vec8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (typename DT::elem)m[e];
+    *reinterpret_cast<uint4*>(out + ((size_t)pix * out_ld + cg * 8) * 2) = __builtin_bit_cast(uint4, o);
+}
+
+extern "C" int rsg_maxpool2x2_nhwc16(const void* in, int32_t in_ld, void* out, int32_t out_ld, int32_t batch, int32_t h,
+                                     int32_t w, int32_t c, int32_t dtype, void* stream) {
+    if (!in || !out) RSG_FAIL("maxpool2x2: null pointer");
+    if (batch < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) RSG_FAIL("maxpool2x2: map %dx%d (even sizes only)", h, w);
+    if (c < 8 || c % 8 || in_ld < c || out_ld < c || in_ld % 8 || out_ld % 8 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+        RSG_FAIL("maxpool2x2: c=%d in_ld=%d out_ld=%d (multiples of 8, 16-byte aligned)", c, in_ld, out_ld);
+    const long total = (long)batch * (h / 2) * (w / 2) * (c / 8);
+    if (total >= (1L << 31)) RSG_FAIL("maxpool2x2: map too large");
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == RSG_BF16)
+        RSG_LAUNCH(maxpool2x2_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, (char*)out, out_ld, h / 2, w / 2, c / 8, (unsigned)total);
+    else
+        RSG_LAUNCH(maxpool2x2_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)in, in_ld, (char*)out, out_ld, h / 2, w / 2, c / 8, (unsigned)total);
+    RSG_CHECK_LAUNCH("maxpool2x2");
+    return 0;
+}
+
+// fp32 rows [rows, c] -> 16-bit rows with stride out_ld (TRP's relation embeddings E on their way into the
+// up-sampling deconv, which is an MFMA conv over 16-bit maps like every other conv of the plan)
+template <class DT>
+__global__ void __launch_bounds__(256) f32_rows_to_16_kernel(const float* __restrict__ in, char* __restrict__ out, int c8,
+                                                            int out_ld, unsigned total) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const unsigned row = i / (unsigned)c8, cg = i - row * (unsigned)c8;
+    const float4 a = *reinterpret_cast<const float4*>(in + (size_t)i * 8);
+    const float4 b = *reinterpret_cast<const float4*>(in + (size_t)i * 8 + 4);
+    const f32x8 f = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *reinterpret_cast<uint4*>(out + ((size_t)row * out_ld + cg * 8) * 2) =
+        __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+}
+
+extern "C" int rsg_f32_rows_to_nhwc16(const float* in, void* out, int32_t out_ld, int64_t rows, int32_t c, int32_t dtype,
+                                      void* stream) {
+    if (!in || !out) RSG_FAIL("f32_rows_to_nhwc16: null pointer");
+    if (rows < 1 || c < 8 || c % 8 || out_ld < c || out_ld % 8 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15))
+        RSG_FAIL("f32_rows_to_nhwc16: c=%d out_ld=%d (multiples of 8, 16-byte aligned)", c, out_ld);
+    const long total = (long)rows * (c / 8);
+    if (total >= (1L << 31)) RSG_FAIL("f32_rows_to_nhwc16: too many rows");
+    const int grid = (int)((total + 255) / 256);
+    if (dtype == RSG_BF16)
+        RSG_LAUNCH(f32_rows_to_16_kernel<BF16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (char*)out, c / 8, out_ld, (unsigned)total);
+    else
+        RSG_LAUNCH(f32_rows_to_16_kernel<F16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, (char*)out, c / 8, out_ld, (unsigned)total);
+    RSG_CHECK_LAUNCH("f32_rows_to_nhwc16");
+    return 0;
+}

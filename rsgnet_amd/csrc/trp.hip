@@ -297,8 +297,10 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-template <int C>
-__global__ void __launch_bounds__(256) trp_w_project_kernel(const float* __restrict__ e, const float* __restrict__ w,
+// IN = float: e is TRP's fp32 E [B,S,C].  IN = a 16-bit storage type: e is a 16-bit NHWC map with channel stride e_ld
+// (RELATION_SUB_SAMPLE: the output of the up-sampling deconv, association.py:254-268).
+template <int C, class IN>
+__global__ void __launch_bounds__(256) trp_w_project_kernel(const void* __restrict__ e_, int e_ld, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            float* __restrict__ part, int S) {
     constexpr int G = 8, CG = C / G;
@@ -309,10 +311,21 @@ __global__ void __launch_bounds__(256) trp_w_project_kernel(const float* __restr
     const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
     const size_t row = ((size_t)b * S + s) * C;
     float xv[C], yv[C];
+    if constexpr (sizeof(IN) == 4) {
+        const float* e = reinterpret_cast<const float*>(e_);
 #pragma unroll
-    for (int k = 0; k < C / 4; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(e + row + 4 * k);
-        xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+        for (int k = 0; k < C / 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(e + row + 4 * k);
+            xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+        }
+    } else {
+        const char* e = reinterpret_cast<const char*>(e_) + ((size_t)b * S + s) * e_ld * 2;
+#pragma unroll
+        for (int k = 0; k < C / 8; ++k) {
+            const typename IN::vec8 v = __builtin_bit_cast(typename IN::vec8, *reinterpret_cast<const uint4*>(e + 16 * k));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[8 * k + j] = (float)v[j];
+        }
     }
 #pragma unroll
     for (int co = 0; co < C; ++co) {
@@ -387,18 +400,22 @@ extern "C" size_t rsg_trp_tail_workspace_bytes(int32_t batch, int32_t S, int32_t
     return ((size_t)batch * S * C + (size_t)batch * (S / 256 + 1) * 8 * 2) * sizeof(float);
 }
 
-extern "C" int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,
-                            const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S,
-                            int32_t C, int32_t dtype, void* workspace, void* stream) {
+static int trp_tail_impl(const void* e, int e16_ld, const float* w, const float* bias, const float* gn_gamma,
+                         const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S,
+                         int32_t C, int32_t dtype, void* workspace, void* stream) {
     if (!e || !w || !bias || !gn_gamma || !gn_beta || !out || !workspace) RSG_FAIL("trp_tail: null pointer");
     if (C != 32 && C != 48) RSG_FAIL("trp_tail: C=%d (32 and 48 are built)", C);
     if (S % 256) RSG_FAIL("trp_tail: S=%d must be a multiple of 256", S);
     if (out_ld < C || out_ld % 8 || ((uintptr_t)out & 15)) RSG_FAIL("trp_tail: out_ld=%d / alignment", out_ld);
+    if (e16_ld && (e16_ld < C || e16_ld % 8 || ((uintptr_t)e & 15))) RSG_FAIL("trp_tail: e_ld=%d / alignment", e16_ld);
     float* y = (float*)workspace;
     float* part = y + (size_t)batch * S * C;
     dim3 grid(S / 256, batch);
-    if (C == 32) RSG_LAUNCH(trp_w_project_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, y, part, S);
-    else RSG_LAUNCH(trp_w_project_kernel<48>, grid, dim3(256), 0, (hipStream_t)stream, e, w, bias, y, part, S);
+#define RSG_WP(C_, IN_) RSG_LAUNCH((trp_w_project_kernel<C_, IN_>), grid, dim3(256), 0, (hipStream_t)stream, e, e16_ld, w, bias, y, part, S)
+    if (!e16_ld) { if (C == 32) RSG_WP(32, float); else RSG_WP(48, float); }
+    else if (dtype == RSG_BF16) { if (C == 32) RSG_WP(32, BF16); else RSG_WP(48, BF16); }
+    else { if (C == 32) RSG_WP(32, F16); else RSG_WP(48, F16); }
+#undef RSG_WP
     RSG_CHECK_LAUNCH("trp_tail(project)");
 #define RSG_GN(DT_, C_) RSG_LAUNCH((trp_gn_apply_kernel<DT_, C_>), grid, dim3(256), 0, (hipStream_t)stream, \
                                    (const float*)y, (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S)
@@ -407,4 +424,17 @@ extern "C" int rsg_trp_tail(const float* e, const float* w, const float* bias, c
 #undef RSG_GN
     RSG_CHECK_LAUNCH("trp_tail(groupnorm)");
     return 0;
+}
+
+extern "C" int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,
+                            const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S,
+                            int32_t C, int32_t dtype, void* workspace, void* stream) {
+    return trp_tail_impl(e, 0, w, bias, gn_gamma, gn_beta, out, out_ld, batch, S, C, dtype, workspace, stream);
+}
+
+extern "C" int rsg_trp_tail_in16(const void* e16, int32_t e_ld, const float* w, const float* bias, const float* gn_gamma,
+                                 const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S,
+                                 int32_t C, int32_t dtype, void* workspace, void* stream) {
+    if (e_ld < 8) RSG_FAIL("trp_tail_in16: e_ld=%d", e_ld);
+    return trp_tail_impl(e16, e_ld, w, bias, gn_gamma, gn_beta, out, out_ld, batch, S, C, dtype, workspace, stream);
 }

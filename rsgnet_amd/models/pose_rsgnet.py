@@ -73,14 +73,22 @@ class KTMachine(nn.Module):
 
 
 class SpatialRelationHead(nn.Module):
-    """TRP parameters (association.py:199-278): g 1x1 (+bias), W = 1x1 (+bias) -> GroupNorm(8)."""
+    """TRP parameters (association.py:199-278): g 1x1 (+bias), W = 1x1 (+bias) -> GroupNorm(8).
+
+    sub_sample (MODEL.RELATION_SUB_SAMPLE; experiments/crowdpose/hrnet/"rsgnet_w48_256x192_adam_lr1e-3 .yaml":42):
+    the relation is computed on the 2x2 max-pooled map and W becomes Sequential(up_sample_layer, W) with
+    up_sample_layer = ConvTranspose2d(4, stride 2, pad 1, no bias) -> BatchNorm2d -> ReLU (association.py:254-268), i.e.
+    parameters W.0.0.weight, W.0.1.*, W.1.0.{weight,bias}, W.1.1.{weight,bias}."""
 
     def __init__(self, channels: int, sub_sample: bool = False):
         super().__init__()
-        if sub_sample:
-            raise NotImplementedError("RELATION_SUB_SAMPLE=true is not used by any shipped config")
+        self.sub_sample = bool(sub_sample)
         self.g = nn.Conv2d(channels, channels, 1)
         self.W = nn.Sequential(nn.Conv2d(channels, channels, 1), nn.GroupNorm(8, channels))
+        if self.sub_sample:
+            up = nn.Sequential(nn.ConvTranspose2d(channels, channels, 4, 2, 1, 0, bias=False),
+                               nn.BatchNorm2d(channels, momentum=0.1), nn.ReLU(inplace=True))
+            self.W = nn.Sequential(up, self.W)
         for name, p in self.named_parameters():      # association.py:271-278
             if "bias" in name:
                 nn.init.constant_(p, 0)
@@ -93,7 +101,7 @@ class RelationScores:
 
     def __init__(self, plan):
         self._plan = plan
-        S = plan.S
+        S = plan.S_rel                         # S, or S/4 with RELATION_SUB_SAMPLE (the relation of the pooled map)
         self.shape = torch.Size((plan.batch, S, S))
 
     def materialize(self) -> torch.Tensor:

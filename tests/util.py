@@ -14,15 +14,23 @@ TAGS = {
     "rsgnet_w32_256x192_crowdpose": ("pose_rsgnet", 32, (192, 256), 14),
     "hrnet_w48_384x288": ("pose_hrnet", 48, (288, 384), 17),
     "rsgnet_w48_384x288_coco": ("pose_rsgnet", 48, (288, 384), 17),
+    # experiments/crowdpose/hrnet/"rsgnet_w48_256x192_adam_lr1e-3 .yaml": the shipped RELATION_SUB_SAMPLE: true config
+    "rsgnet_w48_256x192_crowdpose_sub": ("pose_rsgnet", 48, (192, 256), 14, dict(sub_sample=True)),
 }
+
+
+def case_cfg(tag):
+    from rsgnet_amd import make_cfg
+    name, width, wh, joints = TAGS[tag][:4]
+    return make_cfg(name, width, wh, joints, **(TAGS[tag][4] if len(TAGS[tag]) > 4 else {}))
 
 
 def load_case(tag):
     """(cfg, model, state_dict, input, golden dict) for a golden tag; weights by the synthetic rule."""
     from rsgnet_amd import make_cfg, models
     from rsgnet_amd.weights import synth_input, synth_state_dict
-    name, width, wh, joints = TAGS[tag]
-    cfg = make_cfg(name, width, wh, joints)
+    name, width, wh, joints = TAGS[tag][:4]
+    cfg = case_cfg(tag)
     model = getattr(models, name).get_pose_net(cfg, is_train=False)
     bn = dict(np.load(os.path.join(GOLD, f"bnstats_{tag}.npz")))
     sd = synth_state_dict(model.state_dict(), 0, bn)

@@ -20,7 +20,13 @@ for k, c in tot.items():
     if not any(s in k for s in ("chain", "conv_", "stem", "trp", "bilinear", "crop")):
         continue
     wc = max(c["SQ_WAVE_CYCLES"], 1.0)
-    out[k] = {"launches": cnt[k],
+    # matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts cycles over all SIMDs (32 per 32x32x16 MFMA); the chip's
+    # active time is GRBM_GUI_ACTIVE, which rocprofv3 reports SUMMED over the 8 XCDs (MI355X_MICROARCH.md, DVFS): 1024 SIMDs
+    gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+    mfma = None if not gui else round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * 1024.0), 4)
+    out[k] = {"launches": cnt[k], "mfma_busy_frac": mfma,
+              "mfma_busy_cycles_per_launch": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(cnt[k], 1)),
+              "gui_active_per_launch_per_xcd": round(gui / 8.0 / max(cnt[k], 1)),
               "wait_any_frac": round(c["SQ_WAIT_ANY"] / wc, 3),
               "wait_inst_any_frac": round(c["SQ_WAIT_INST_ANY"] / wc, 3),
               "active_inst_any_frac": round(c["SQ_ACTIVE_INST_ANY"] / wc, 3),
