@@ -234,24 +234,38 @@ def train_bench(a, rank, world, local, dev, dist):
     from rsgnet_amd.optim import FusedAdam
     from rsgnet_amd.parallel import DataParallelStep
     from rsgnet_amd.weights import synth_input, synth_state_dict
-    tag = "hrnet_w32_256x192"
+    rsg = a.workload.startswith("rsgnet")            # --workload rsgnet_w32_256x192_coco --train: the step of `rsgnet_train`
+    tag = "rsgnet_w32_256x192_coco" if rsg else "hrnet_w32_256x192"
     batch = a.batch or 32
-    cfg = make_cfg("pose_hrnet", 32, (192, 256), 17)
-    model = models.pose_hrnet.get_pose_net(cfg, is_train=False)
+    cfg = make_cfg("pose_rsgnet" if rsg else "pose_hrnet", 32, (192, 256), 17)
+    model = (models.pose_rsgnet if rsg else models.pose_hrnet).get_pose_net(cfg, is_train=False)
     bn = dict(np.load(os.path.join(ROOT, "tests", "golden", f"bnstats_{tag}.npz")))
     sd = synth_state_dict(model.state_dict(), 0, bn)
     model.load_state_dict(sd)
     model = model.to(dev).train()
     opt = FusedAdam(model.parameters(), lr=1e-3)
-    step_fn = DataParallelStep(model, JointsMSELoss(True), opt)
     x = synth_input(batch, (192, 256), seed=100 + rank).to(dev)
-    target, tw = tso.gaussian_targets(batch, 17, (64, 48), 200 + rank)
-    target, tw = target.to(dev), tw.to(dev)
     losses = []
+    if rsg:
+        from rsgnet_amd.loss import relation_target_vector, rsgnet_loss
+        crit = JointsMSELoss(True)
+        step_fn = DataParallelStep(model, lambda outs, *t: rsgnet_loss(outs, *t, crit), opt)
+        target, tw = tso.gaussian_targets(batch, 17, (128, 96), 200 + rank)
+        all_t, all_w = tso.gaussian_targets(batch, 17, (128, 96), 300 + rank)
+        limbs_t = tso.limb_targets(batch, 18, (128, 96), 400 + rank)
+        target, tw, all_t, all_w, limbs_t = (t.to(dev) for t in (target, tw, all_t, all_w, limbs_t))
 
-    def step():
-        loss, _ = step_fn(x, target, tw)
-        losses.append(loss)
+        def step():
+            loss, _ = step_fn(x, target, tw, all_t, all_w, limbs_t, relation_target=relation_target_vector(target))
+            losses.append(loss)
+    else:
+        step_fn = DataParallelStep(model, JointsMSELoss(True), opt)
+        target, tw = tso.gaussian_targets(batch, 17, (64, 48), 200 + rank)
+        target, tw = target.to(dev), tw.to(dev)
+
+        def step():
+            loss, _ = step_fn(x, target, tw)
+            losses.append(loss)
 
     for _ in range(max(a.warmup, 1)):
         step()
@@ -292,17 +306,17 @@ def train_bench(a, rank, world, local, dev, dist):
     gflop = 3 * GFLOP_PER_IMG[tag]                 # forward + data gradient + weight gradient
     whole = gflop * batch / (dev_ms / a.steps)
     dom_name, dom = max(fams.items(), key=lambda kv: kv[1]["us"])
-    line = {"metric": "images/sec HRNet-W32 256x192 training step (fwd+bwd+Adam)", "value": round(imgs, 1), "unit": "images/s",
+    line = {"metric": f"images/sec {'RSGNet' if rsg else 'HRNet'}-W32 256x192 training step (fwd+bwd+Adam)", "value": round(imgs, 1), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "hrnet_w32_256x192_train", "per_gpu_batch": batch, "global_batch": batch * world,
+            "config": {"workload": tag + "_train" + (" (backbone HIP, head PyTorch-ROCm operators)" if rsg else ""), "per_gpu_batch": batch, "global_batch": batch * world,
                        "image": "256x192", "parallelism": f"dp{world} (bucketed RCCL all-reduce of the flat fp32 gradient buffer)",
                        "optimizer": "Adam lr 1e-3 (FusedAdam)", "loss_first_last": [round(vals[0], 6), round(vals[-1], 6)]},
             "roofline": {"bound": "mfma", "achieved": round(whole, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(whole / PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "whole training step (3 x 15.29 GFLOP per image)", "device_ms_per_step": round(dev_ms / a.steps, 3),
+                         "kernel": f"whole training step (3 x {GFLOP_PER_IMG[tag]} GFLOP per image)", "device_ms_per_step": round(dev_ms / a.steps, 3),
                          "largest_family": dom_name, "families": fams}}
-    if not a.no_cpu_baseline and world == 1:
+    if not a.no_cpu_baseline and world == 1 and not rsg:
         cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
         torch.set_num_threads(cores)
         xs, ts, ws = x[:2].cpu(), target[:2].cpu(), tw[:2].cpu()

@@ -337,9 +337,10 @@ def rsgnet_forward(sd, cfg, x, relation_target=None, want_scores=True, **kw):
     ``want_scores=False`` (a test convenience: the 37.7 MB/crop map is the one thing the HIP path
     never materialises unless asked).
     """
+    grad = kw.pop("grad", False)             # True: build the autograd graph (oracle/train_step_oracle.rsgnet_train_step)
     ctx = kw.pop("ctx", None) or Ctx(sd, **kw)
     model = cfg["MODEL"]
-    with torch.no_grad():
+    with (torch.enable_grad() if grad else torch.no_grad()):
         vis = backbone(ctx, x, cfg)[0]
         ctx.taps["vis"] = vis
         wm, bm = ctx.p("multi_final_layer.weight"), ctx.p("multi_final_layer.bias")

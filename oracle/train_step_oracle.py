@@ -84,3 +84,51 @@ def hrnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, targe
     # calibrate mode stored (batch mean, unbiased batch variance): fold them in with the reference's momentum
     stats = {k: ((1 - BN_MOMENTUM) * old[k] + BN_MOMENTUM * ctx.sd[k].detach().double()) for k in old}
     return loss.detach(), heat.detach(), gd, stats
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# RSGNet: one step of `rsgnet_train`, /root/reference/lib/core/function.py:239-323
+# ------------------------------------------------------------------------------------------------------------------
+def relation_target_factor(target: torch.Tensor) -> torch.Tensor:
+    """function.py:261-268: person_target = max over joints, bilinear x1/2 (align_corners=True), flattened: the factor p
+    [B,S] of the relation target T = p^T p the reference materialises ([B,S,S])."""
+    person, _ = torch.max(target, dim=1)
+    b, h, w = person.shape
+    person = F.interpolate(person.reshape(b, 1, h, w), scale_factor=1 / 2, mode="bilinear", align_corners=True)
+    return person.reshape(b, -1)
+
+
+def limb_targets(batch: int, limbs: int, hw: Tuple[int, int], seed: int):
+    """Seeded stand-ins for the data set's limb maps (values in [0,1], a few blobs per channel).  Data, not a restatement."""
+    t, _ = gaussian_targets(batch, limbs, hw, seed, sigma=3.0)
+    return t.clamp(0, 1)
+
+
+def rsgnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, target, target_weight, all_ins_target,
+                      all_ins_target_weight, target_limbs, dtype=torch.float64, relu_masks=None):
+    """One forward/backward of pose_rsgnet in train() mode with the loss of rsgnet_train (function.py:272-299):
+    JointsMSELoss(kpt, target) + JointsMSELoss(multi, all_ins_target) + 0.01 * BCE(limbs, target_limbs)
+    + 0.001 * mean_b(mean_ij (T - R)^2).  Returns (loss, (multi, kpt, limbs, relation_mse), {name: gradient},
+    {running statistic after the step})."""
+    work: Dict[str, torch.Tensor] = {}
+    frozen = ("loc_features", "kt_machine.real_matrix_limb")            # requires_grad False in the reference (:691, :574)
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if not is_buffer(k):
+            t = t.to(dtype)
+            if k not in frozen:
+                t.requires_grad_(True)
+        work[k] = t
+    old = {k: v.detach().clone().double() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}
+    ctx = po.Ctx(work, dtype=dtype, calibrate=True, relu_masks=relu_masks)
+    ctx.sd = dict(work)
+    p = relation_target_factor(target.to(dtype))
+    rel_t = p[:, :, None] * p[:, None, :]
+    multi, kpt, limbs, rel = po.rsgnet_forward(work, cfg, x.to(dtype), relation_target=rel_t, ctx=ctx, grad=True)
+    loss = joints_mse_loss(kpt, target, target_weight) + joints_mse_loss(multi, all_ins_target, all_ins_target_weight) \
+        + 0.01 * F.binary_cross_entropy(limbs, target_limbs.to(dtype)) + 0.001 * torch.mean(rel)
+    names = [k for k in work if not is_buffer(k) and k not in frozen]
+    grads = torch.autograd.grad(loss, [work[k] for k in names], allow_unused=True)
+    gd = {k: (g.detach() if g is not None else None) for k, g in zip(names, grads)}
+    stats = {k: ((1 - BN_MOMENTUM) * old[k] + BN_MOMENTUM * ctx.sd[k].detach().double()) for k in old}
+    return loss.detach(), tuple(t.detach() for t in (multi, kpt, limbs, rel)), gd, stats

@@ -64,8 +64,7 @@ class HipPoseModule(nn.Module):
                                f"{x.device.type} tensor. There is no CPU fallback.")
         if not self.supports_training:
             raise NotImplementedError(
-                f"training-mode forward of {type(self).__name__} is not built (pose_hrnet is: SURVEY 8(e) config 4); "
-                "call model.eval()")
+                f"training-mode forward of {type(self).__name__} is not built; call model.eval()")
         from ..train import train_forward
         return train_forward(self, x)
 
@@ -110,7 +109,7 @@ class HipPoseModule(nn.Module):
         if self.training:
             raise NotImplementedError(
                 f"{type(self).__name__}: the inference plan serves model.eval() only; training-mode forward goes "
-                "through train_forward() (built for pose_hrnet).")
+                "through the training plan (rsgnet_amd/train.py, train_rsgnet.py).")
         sig = self._param_signature()
         if sig != getattr(self, "_plan_sig", None):
             self._plans = {}                  # parameters were updated in place since the plans were built

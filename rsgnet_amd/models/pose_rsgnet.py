@@ -158,7 +158,18 @@ class RSGNet(HipPoseModule):
         from ..plan import RSGNetPlan
         return RSGNetPlan(self, batch, device, self.compute_dtype)
 
+    #: training mode: backbone on the HIP training plan, head on PyTorch-ROCm operators with autograd
+    #: (rsgnet_amd/train_rsgnet.py: interim until the head's HIP kernels have a backward)
+    supports_training = True
+    train_head_on_torch = True
+
     def forward(self, x: torch.Tensor, relation_target=None):
+        if self.training:
+            if x.device.type != "cuda":
+                raise RuntimeError(f"{type(self).__name__} runs only on an AMD GPU through librsgnet_hip.so; got a "
+                                   f"{x.device.type} tensor. There is no CPU fallback.")
+            from ..train_rsgnet import train_forward
+            return train_forward(self, x, relation_target)
         plan, (multi, kpt, limbs) = self.run_plan(x)
         with torch.cuda.device(x.device):
             if relation_target is not None:

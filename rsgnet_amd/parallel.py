@@ -127,9 +127,12 @@ class DataParallelStep:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
-    def __call__(self, x, target, target_weight):
-        out = self.model(x)
-        loss = self.criterion(out, target, target_weight)
+    def __call__(self, x, *targets, **model_kwargs):
+        """pose_hrnet: step(input, target, target_weight).  pose_rsgnet (rsgnet_train, function.py:256-323):
+        step(input, target, target_weight, all_ins_target, all_ins_target_weight, target_limbs, relation_target=p) with
+        criterion = lambda outs, *t: rsgnet_amd.loss.rsgnet_loss(outs, *t, JointsMSELoss(True))."""
+        out = self.model(x, **model_kwargs)
+        loss = self.criterion(out, *targets)
         self.optimizer.zero_grad()
         if self.reducer is not None:
             self.reducer.begin()

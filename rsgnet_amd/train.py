@@ -82,8 +82,15 @@ class _WgradLaunch:
 class TrainPlan:
     """Forward and backward launch lists of pose_hrnet in training mode for one (batch, device)."""
 
-    def __init__(self, model: nn.Module, batch: int, device: torch.device):
+    #: top-level children of the HRNet backbone shared by pose_hrnet and pose_rsgnet (pose_rsgnet.py:921-953)
+    BACKBONE = ("conv1", "bn1", "conv2", "bn2", "layer1", "transition1", "stage2", "transition2", "stage3", "transition3", "stage4")
+
+    def __init__(self, model: nn.Module, batch: int, device: torch.device, head: bool = True):
+        """head=True: pose_hrnet (backbone + final_layer -> heat maps).  head=False: the backbone alone -- its output map
+        leaves as fp32 NCHW and its gradient comes back the same way (pose_rsgnet: rsgnet_amd/train_rsgnet.py runs the
+        head with torch operators on top of it)."""
         self.lib = hip.lib()
+        self.with_head = head
         self.model, self.batch, self.device = model, batch, device
         self.fwd: List[tuple] = []      # (name, launch(stream), group kind or None, group item maker or None)
         self.bwd: List[tuple] = []
@@ -103,7 +110,9 @@ class TrainPlan:
         self._shared_rids: set = set()
         self._defer: Optional[list] = None
         self._bn_momentum, self._bn_eps = 0.1, 1e-5
-        self._params = [p for p in model.parameters() if p.requires_grad]
+        # the parameters whose gradients THIS plan writes (everything of pose_hrnet; the backbone of pose_rsgnet)
+        self._params = [p for n, p in model.named_parameters()
+                        if p.requires_grad and (head or n.split(".")[0] in self.BACKBONE)]
         self._sig: Optional[Tuple[int, ...]] = None
         self._graphs: Optional[tuple] = None         # (forward graph, [one graph per backward segment])
         self._warm = 0
@@ -122,7 +131,8 @@ class TrainPlan:
                                for k, v in self._wgrad_lane_need.items() for par in (0, 1)}
         self._link_wgrads()
         self._build_pack_table()
-        self._bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+        self._bns = [m for n, m in model.named_modules() if isinstance(m, nn.BatchNorm2d)
+                     and (head or n.split(".")[0] in self.BACKBONE)]
         self._nbt = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
 
     # ------------------------------------------------------------------ helpers
@@ -388,6 +398,14 @@ class TrainPlan:
             for k, mod in enumerate(getattr(m, f"stage{s}")):
                 xs = self._hr_module(xs, mod, f"stage{s}.{k}")
             ys = xs
+        if not self.with_head:
+            x0 = ys[0]
+            if x0.C != m.final_layer.in_channels:
+                raise NotImplementedError(f"backbone output with {x0.C} channels in a padded buffer (HRNet-W48 training is not built)")
+            self.feat_src = x0
+            self.dfeat16 = torch.zeros_like(x0.data)      # the incoming gradient, NHWC bf16 (TrainPlan.backward fills it)
+            self._emit_op(dict(kind="feat", x=x0, name="backbone_output"))
+            return
         # classifier: 1x1 conv + bias -> fp32 NCHW heat maps (pose_hrnet.py:326-332,461)
         fl = m.final_layer
         if fl.kernel_size != (1, 1):
@@ -516,7 +534,9 @@ class TrainPlan:
             self._sink["bwd"] = bucket.setdefault(reg[1], []) if reg is not None else None
             self._defer = pending if reg is not None and reg[0] in self._shared_rids else None
             self._bwd_lane = reg[1] if reg is not None else 0
-            if kind == "final":
+            if kind == "feat":
+                self._contribute(op["x"], self.dfeat16, False, name)
+            elif kind == "final":
                 x, fl = op["x"], op["m"]
                 J = self.J
                 d16 = torch.zeros(B, x.H, x.W, 32, dtype=torch.bfloat16, device=self.device)
@@ -715,6 +735,8 @@ class TrainPlan:
             self._graphs[0].replay()
         else:
             self._run_forward()
+        if not self.with_head:
+            return self.feat_src.data.permute(0, 3, 1, 2).float().contiguous()
         return self.heat.clone()
 
     def backward(self, dheat: torch.Tensor, generation: Optional[int] = None) -> None:
@@ -731,7 +753,10 @@ class TrainPlan:
             raise RuntimeError("second backward through the same training-mode forward: its buffers were reused "
                                "(run the forward again; retain_graph is not supported by the HIP training plan)")
         self._backward_done = True
-        self.dheat.copy_(dheat)
+        if self.with_head:
+            self.dheat.copy_(dheat)
+        else:
+            self.dfeat16.copy_(dheat.permute(0, 2, 3, 1))          # fp32 NCHW -> bf16 NHWC (layout and type in one copy)
         hooks = getattr(self.model, "grad_ready_hooks", ())
         for k in range(len(self._bwd_segments)):
             if self._graphs is not None:
@@ -767,12 +792,13 @@ class _TrainFn(torch.autograd.Function):
 
 
 def train_forward(model: nn.Module, x: torch.Tensor) -> torch.Tensor:
-    """`model(x)` in training mode (models/_base.py calls this)."""
+    """`model(x)` in training mode (models/_base.py calls this): the heat maps of pose_hrnet, or -- for a model whose
+    head runs elsewhere (`model.train_head_on_torch`, pose_rsgnet) -- the backbone's output map [B,C0,H/4,W/4] fp32."""
     key = (int(x.shape[0]), x.device.index)
     plan = model._train_plans.get(key)
     if plan is None:
         with torch.cuda.device(x.device):
-            plan = TrainPlan(model, int(x.shape[0]), x.device)
+            plan = TrainPlan(model, int(x.shape[0]), x.device, head=not getattr(model, "train_head_on_torch", False))
         model._train_plans[key] = plan
     hook = getattr(model, "_train_hook", None)
     if hook is None or hook.device != x.device:
