@@ -313,6 +313,15 @@ int rsg_f32_rows_to_nhwc16(const float* in, void* out, int32_t out_ld, int64_t r
 int rsg_trp_tail_in16(const void* e16, int32_t e_ld, const float* w, const float* bias, const float* gn_gamma,
                       const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
                       int32_t dtype, void* workspace, void* stream);
+/* TRP backward for training (autograd of /root/reference/lib/models/association.py:288-297 and of the relation MSE,
+ * pose_rsgnet.py:1014-1018, which the reference leaves to torch on the materialised [B,S,S] map).  Inputs, all 16-bit of
+ * `dtype`: x, g = conv1x1(x) + b and de = dL/dE as rows [batch,S,ld]; xT, deT transposed [batch,C,S] with the keys of
+ * every 16-block in the order [0-3, 8-11, 4-7, 12-15] (rsg_trp_project_g's layout).  p [batch,S] fp32: factor of the
+ * relation target (T = p p^T) with coef[b] = dL/dmse_b * 2 / S^2, or null without relation loss.  Outputs fp32
+ * [batch,S,C]: dx = the gradient through the Gram product (add dg . Wg for the g path), dg = R . de.  C = 32, S % 128 == 0. */
+int rsg_trp_backward(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
+                     const void* xT, const void* deT, const float* p, const float* coef, float* dx, float* dg,
+                     int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
 /* optional materialisation of relation_score [batch,S,S] fp32 (association.py:294-295) */
 int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S, int32_t C,
                    int32_t dtype, void* stream);

@@ -233,6 +233,146 @@ extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p,
     return trp_launch<TRP_MSE>(a, batch, C, dtype, stream);
 }
 
+// ---- TRP backward (training; pose_rsgnet.py:987,1014-1018 under autograd) ---------------------------------------
+// Forward, per crop:  G = X Wg^T + bg,  R = sigmoid(X X^T),  E = R G,  mse = mean_ij (p_i p_j - R_ij)^2.
+// Given dE [S,C] and the upstream scalar of the relation loss (coef = dL/dmse * 2 / S^2), with R' = R (1 - R):
+//     dG_i = sum_j R_ij dE_j                                                    (R is symmetric: the forward's kernel with dE as values)
+//     dX_i = sum_j M_ij X_j,   M_ij = R'_ij [ dE_i.G_j + dE_j.G_i + 2 coef (R_ij - p_i p_j) ]     (A = X X^T: dA + dA^T)
+// The S x S map is never stored: one wave owns 32 query rows i and streams over the keys j in tiles of 32, recomputing
+// sigmoid(X X^T) per tile as the forward does.  Per tile three score products (X_j.X_i, G_j.dE_i, dE_j.G_i: K = C each)
+// and two value products (dE_j^T.P -> dG_i, X_j^T.M -> dX_i) run on the matrix cores; P and M go from accumulator
+// registers straight into the next MFMA's B operand (the forward's trick).  Operands are 16-bit (bf16 in training),
+// accumulation and outputs fp32.  Inputs: x, g, de as rows [B,S,C]; xT, deT transposed [B,C,S] with the keys of every
+// 16-block in the order [0-3, 8-11, 4-7, 12-15] (rsg_trp_project_g's layout).
+struct TrpBwdArgs {
+    const char *x, *g, *de;        // [B,S,ld*] 16-bit rows
+    const char *xT, *deT;          // [B,C,S] 16-bit, key-permuted
+    const float* p;                // [B,S] factor of the relation target, or null (no relation loss)
+    const float* coef;             // [B]: dL/dmse_b * 2 / S^2
+    float *dx, *dg;                // [B,S,C] fp32
+    int S, ldx, ldg, ldd;
+};
+
+template <class DT, int C>
+__global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
+    static_assert(C == 32, "the training head is built for 32 channels (HRNet-W32)");
+    constexpr int KQ = C / 16, PK = C / 8, RSK = PK + 1, NKP = 32 * PK, NGP = C * 4;
+    constexpr int KT = 2;                              // tiles of 32 keys per stage (one barrier per stage)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const size_t boff = (size_t)b * a.S;
+    const char* xb = a.x + boff * a.ldx * 2;
+    const char* gb = a.g + boff * a.ldg * 2;
+    const char* db = a.de + boff * a.ldd * 2;
+    typename DT::vec8 qx[KQ], qg[KQ], qd[KQ];          // query-side fragments: lane (n, hh) holds row q0+n, channels 16s+8hh..+8
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) {
+        qx[s] = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(xb + ((size_t)(q0 + n) * a.ldx + 16 * s + 8 * hh) * 2));
+        qg[s] = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(gb + ((size_t)(q0 + n) * a.ldg + 16 * s + 8 * hh) * 2));
+        qd[s] = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(db + ((size_t)(q0 + n) * a.ldd + 16 * s + 8 * hh) * 2));
+    }
+    f32x16 ydx, ydg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ydx[r] = ydg[r] = 0.f;
+    const float pq = a.p ? a.p[boff + q0 + n] : 0.f;
+    const float c2 = a.p ? 2.f * a.coef[b] : 0.f;
+
+    __shared__ uint4 tk[2][KT][3][32 * RSK];          // X, G, dE rows of the key tile
+    __shared__ uint4 tg[2][KT][2][C * 5];             // X^T, dE^T of the key tile
+    __shared__ float tp[2][KT][32];                   // p of the key tile
+    // staging: 256 threads = KT tiles x 128 pieces; every thread moves one 16-byte piece of each of the five operands
+    static_assert(NKP == 128 && NGP == 128 && KT == 2, "one piece per thread, operand and stage");
+    const int su = threadIdx.x >> 7, sq = threadIdx.x & 127;
+    const int krow = sq / PK, kpiece = sq % PK, grow = sq >> 2, gpiece = sq & 3;
+    uint4 v0, v1, v2, v3, v4;
+    float pv;
+    auto fetch = [&](int jstage) {
+        const int j0 = jstage + su * 32;
+        v0 = *reinterpret_cast<const uint4*>(xb + ((size_t)(j0 + krow) * a.ldx + kpiece * 8) * 2);
+        v1 = *reinterpret_cast<const uint4*>(gb + ((size_t)(j0 + krow) * a.ldg + kpiece * 8) * 2);
+        v2 = *reinterpret_cast<const uint4*>(db + ((size_t)(j0 + krow) * a.ldd + kpiece * 8) * 2);
+        v3 = *reinterpret_cast<const uint4*>(a.xT + (((size_t)b * C + grow) * a.S + j0 + gpiece * 8) * 2);
+        v4 = *reinterpret_cast<const uint4*>(a.deT + (((size_t)b * C + grow) * a.S + j0 + gpiece * 8) * 2);
+        pv = (a.p && threadIdx.x < 32 * KT) ? a.p[boff + jstage + threadIdx.x] : 0.f;
+    };
+    auto stash = [&](int buf) {
+        tk[buf][su][0][krow * RSK + kpiece] = v0;
+        tk[buf][su][1][krow * RSK + kpiece] = v1;
+        tk[buf][su][2][krow * RSK + kpiece] = v2;
+        tg[buf][su][0][grow * 5 + gpiece] = v3;
+        tg[buf][su][1][grow * 5 + gpiece] = v4;
+        if (threadIdx.x < 32 * KT) tp[buf][threadIdx.x >> 5][threadIdx.x & 31] = pv;
+    };
+    auto do_tile = [&](const uint4 (&tkb)[3][32 * RSK], const uint4 (&tgb)[2][C * 5], const float (&pk)[32]) {
+        f32x16 xa, x1, x2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xa[r] = x1[r] = x2[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) {
+            xa = DT::mfma(__builtin_bit_cast(typename DT::vec8, tkb[0][n * RSK + 2 * s + hh]), qx[s], xa);   // X_key . X_query
+            x1 = DT::mfma(__builtin_bit_cast(typename DT::vec8, tkb[1][n * RSK + 2 * s + hh]), qd[s], x1);   // G_key . dE_query
+            x2 = DT::mfma(__builtin_bit_cast(typename DT::vec8, tkb[2][n * RSK + 2 * s + hh]), qg[s], x2);   // dE_key . G_query
+        }
+        // element r of this lane: key = (r&3) + 8*(r>>2) + 4*hh of the tile, query = q0 + n
+        float pr[16], mr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float R = sigmoid_f32(xa[r]);
+            const float t = x1[r] + x2[r] + c2 * (R - pq * pk[(r & 3) + 8 * (r >> 2) + 4 * hh]);
+            pr[r] = R;
+            mr[r] = R * (1.f - R) * t;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            typename DT::vec8 pf, mf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pf[e] = (typename DT::elem)pr[8 * s + e]; mf[e] = (typename DT::elem)mr[8 * s + e]; }
+            ydg = DT::mfma(__builtin_bit_cast(typename DT::vec8, tgb[1][n * 5 + 2 * s + hh]), pf, ydg);      // dE^T . P
+            ydx = DT::mfma(__builtin_bit_cast(typename DT::vec8, tgb[0][n * 5 + 2 * s + hh]), mf, ydx);      // X^T . M
+        }
+    };
+    const int nstages = a.S / (32 * KT);
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < nstages; ++t) {
+        const bool more = t + 1 < nstages;
+        if (more) fetch((t + 1) * 32 * KT);
+#pragma unroll
+        for (int u = 0; u < KT; ++u) do_tile(tk[t & 1][u], tg[t & 1][u], tp[t & 1][u]);
+        if (more) stash((t + 1) & 1);
+        __syncthreads();
+    }
+    // y[r] = value for query q0+n, channel (r&3) + 8*(r>>2) + 4*hh
+    float* ox = a.dx + (boff + q0 + n) * C + 4 * hh;
+    float* og = a.dg + (boff + q0 + n) * C + 4 * hh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        *reinterpret_cast<float4*>(ox + 8 * k) = make_float4(ydx[4 * k], ydx[4 * k + 1], ydx[4 * k + 2], ydx[4 * k + 3]);
+        *reinterpret_cast<float4*>(og + 8 * k) = make_float4(ydg[4 * k], ydg[4 * k + 1], ydg[4 * k + 2], ydg[4 * k + 3]);
+    }
+}
+
+extern "C" int rsg_trp_backward(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
+                                const void* xT, const void* deT, const float* p, const float* coef, float* dx, float* dg,
+                                int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream) {
+    if (trp_check(x, ld_x, batch, S, C) || trp_check(g, ld_g, batch, S, C) || trp_check(de, ld_de, batch, S, C)) return 1;
+    if (C != 32) RSG_FAIL("trp_backward: C=%d (the training head is built for 32 channels)", C);
+    if (!xT || !deT || !dx || !dg || (p && !coef)) RSG_FAIL("trp_backward: null pointer");
+    if ((((uintptr_t)xT | (uintptr_t)deT | (uintptr_t)dx | (uintptr_t)dg) & 15)) RSG_FAIL("trp_backward: pointers must be 16-byte aligned");
+    TrpBwdArgs a;
+    a.x = (const char*)x; a.g = (const char*)g; a.de = (const char*)de; a.xT = (const char*)xT; a.deT = (const char*)deT;
+    a.p = p; a.coef = coef; a.dx = dx; a.dg = dg; a.S = S; a.ldx = ld_x; a.ldg = ld_g; a.ldd = ld_de;
+    dim3 grid(S / 128, batch);
+    if (dtype == RSG_BF16) RSG_LAUNCH((trp_backward_kernel<BF16, 32>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else RSG_LAUNCH((trp_backward_kernel<F16, 32>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH("trp_backward");
+    return 0;
+}
+
 // ---- g projection, transposed + key-permuted (association.py:288-289) -------------------------------
 template <class DT, int C>
 __global__ void __launch_bounds__(256) trp_project_g_kernel(const char* __restrict__ x, int ldx,

@@ -5,9 +5,12 @@ Two parts:
   * the HRNet backbone (stem .. stage4: 99 % of the step's arithmetic) runs on the HIP training plan of
     rsgnet_amd/train.py -- the same launch lists as `pose_hrnet`, recorded up to the backbone's output map, which comes out
     as ONE autograd node;
-  * the head (clue encoders, TRP, joints-of-target branch, SGM) is written here with PyTorch-ROCm operators on the model's
-    own modules, so autograd supplies its backward.  INTERIM: the HIP inference kernels of the head (csrc/trp.hip, the
-    grouped convs) have no backward yet; until they do, the head's training arithmetic is torch's (GPU, fp32).  The two
+  * the TRP's relation (association.py:288-297) and the relation MSE against the factored target (pose_rsgnet.py:1014-1018)
+    run on csrc/trp.hip in both directions (`TrpRelation` below): neither pass stores the [B,S,S] map (1.2 GB at batch 32,
+    S = 3072, which the reference's autograd keeps alive between forward and backward);
+  * the rest of the head (clue encoders, W, joints-of-target branch, SGM convs) is written here with PyTorch-ROCm operators
+    on the model's own modules, so autograd supplies its backward.  INTERIM: the grouped HIP convs of the inference head
+    have no backward yet; until they do, these small convs' training arithmetic is torch's (GPU, fp32).  The two
     weight-only sub-graphs keep their exact algebraic folds, which autograd differentiates: the type path is a 3x3 conv
     J -> C0 with W'[o,j] = sum_c type_conv.W[o,c] * Tm[j,c] (the [B,600,H,W] map of pose_rsgnet.py:974 is never built), and
     the relation target stays factored (T = p p^T) when it is given as [B,S].
@@ -27,6 +30,99 @@ def kt_machine_forward(kt, weight: torch.Tensor) -> torch.Tensor:
     t = k @ weight.reshape(n_out, n_in * h * w)
     t = kt.kpt_transformer(t)                                            # Linear -> LeakyReLU(0.02) -> Linear
     return t.reshape(t.shape[0], n_in, h, w)
+
+
+_KEY_ORDER = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)   # rsg_trp_project_g's order of the keys in a 16-block
+
+
+def _rows16(t: torch.Tensor) -> torch.Tensor:
+    """fp32 NCHW -> bf16 rows [B,S,C]."""
+    b, c, h, w = t.shape
+    return t.permute(0, 2, 3, 1).reshape(b, h * w, c).to(torch.bfloat16).contiguous()
+
+
+def _keys_transposed(rows: torch.Tensor) -> torch.Tensor:
+    """[B,S,C] -> [B,C,S] with every 16-block of keys in the kernel's order."""
+    b, s, c = rows.shape
+    idx = torch.tensor(_KEY_ORDER, device=rows.device)
+    return rows.transpose(1, 2).reshape(b, c, s // 16, 16).index_select(3, idx).reshape(b, c, s).contiguous()
+
+
+class TrpRelation(torch.autograd.Function):
+    """E = sigmoid(X X^T) (X Wg^T + bg) and mse_b = mean_ij (p_i p_j - sigmoid(X X^T)_ij)^2 on the HIP kernels, bf16
+    operands and fp32 accumulation as the backbone's training plan.  forward: rsg_trp_project_g + rsg_trp_attention
+    + rsg_trp_relation_mse; backward: rsg_trp_backward (sigmoid recomputed per tile) and three small fp32 matmuls for
+    the g projection's own gradients."""
+
+    @staticmethod
+    def forward(ctx, x, wg, bg, p):
+        from . import hip
+        if not x.is_cuda:
+            raise RuntimeError("TrpRelation runs on the HIP kernels: the input must be on the GPU")
+        lib = hip.lib()
+        b, c, h, w = x.shape
+        s = h * w
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        x16 = _rows16(x)
+        w32 = wg.detach().reshape(c, c).float().contiguous()
+        b32 = bg.detach().float().contiguous()
+        g_hi = torch.empty(b, c, s, dtype=torch.bfloat16, device=x.device)
+        hip.check(lib.rsg_trp_project_g(x16.data_ptr(), c, w32.data_ptr(), b32.data_ptr(), g_hi.data_ptr(), None,
+                                        b, s, c, hip.RSG_BF16, st), "trp_project_g")
+        e = torch.empty(b, s, c, dtype=torch.float32, device=x.device)
+        hip.check(lib.rsg_trp_attention(x16.data_ptr(), c, g_hi.data_ptr(), None, e.data_ptr(), b, s, c,
+                                        hip.RSG_BF16, st), "trp_attention")
+        mse = torch.zeros(b, dtype=torch.float32, device=x.device)
+        p32 = None
+        if p is not None:
+            p32 = p.detach().to(x.device, torch.float32).contiguous()
+            hip.check(lib.rsg_trp_relation_mse(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), b, s, c, hip.RSG_BF16, st),
+                      "trp_relation_mse")
+        ctx.save_for_backward(x16, w32, b32, p32)
+        ctx.shape = (b, c, h, w)
+        return e.reshape(b, h, w, c).permute(0, 3, 1, 2), mse
+
+    @staticmethod
+    def backward(ctx, d_e, d_mse):
+        from . import hip
+        lib = hip.lib()
+        x16, w32, b32, p32 = ctx.saved_tensors
+        b, c, h, w = ctx.shape
+        s = h * w
+        st = torch.cuda.current_stream(x16.device).cuda_stream
+        xf = x16.float()
+        g16 = torch.addmm(b32, xf.reshape(-1, c), w32.t()).to(torch.bfloat16).reshape(b, s, c)
+        de16 = _rows16(d_e) if d_e is not None else torch.zeros_like(x16)
+        x_t, de_t = _keys_transposed(x16), _keys_transposed(de16)
+        coef = None
+        if p32 is not None:
+            coef = (torch.zeros(b, device=x16.device) if d_mse is None else d_mse.float() * (2.0 / (s * s))).contiguous()
+        dx = torch.empty(b, s, c, dtype=torch.float32, device=x16.device)
+        dg = torch.empty_like(dx)
+        hip.check(lib.rsg_trp_backward(x16.data_ptr(), c, g16.data_ptr(), c, de16.data_ptr(), c, x_t.data_ptr(), de_t.data_ptr(),
+                                       None if p32 is None else p32.data_ptr(), None if coef is None else coef.data_ptr(),
+                                       dx.data_ptr(), dg.data_ptr(), b, s, c, hip.RSG_BF16, st), "trp_backward")
+        dg2 = dg.reshape(-1, c)
+        dx = dx + (dg2 @ w32).reshape(b, s, c)                               # g = x Wg^T + bg
+        d_w = (dg2.t() @ xf.reshape(-1, c)).reshape(c, c, 1, 1)
+        d_b = dg2.sum(0)
+        return dx.reshape(b, h, w, c).permute(0, 3, 1, 2), d_w, d_b, None
+
+
+def relation_head_hip(rh, x: torch.Tensor, p: Optional[torch.Tensor]):
+    """SpatialRelationHead.forward on TrpRelation; returns (relation features, relation mse [B] against T = p p^T)."""
+    if getattr(rh, "sub_sample", False):
+        x = F.max_pool2d(x, 2)
+    e, mse = TrpRelation.apply(x, rh.g.weight, rh.g.bias, p)
+    return rh.W(e), mse
+
+
+def trp_on_hip(rh, x: torch.Tensor, relation_target) -> bool:
+    """The HIP pair covers what training uses: 32 channels, S a multiple of 128, the target given as its factor [B,S]."""
+    if relation_target is None or relation_target.dim() != 2 or not x.is_cuda:
+        return False
+    s = x.shape[2] * x.shape[3] // (4 if getattr(rh, "sub_sample", False) else 1)
+    return x.shape[1] == 32 and s % 128 == 0
 
 
 def relation_head_forward(rh, x: torch.Tensor):
@@ -52,7 +148,11 @@ def head_forward(model, feat: torch.Tensor, relation_target: Optional[torch.Tens
     typ = m.type_conv[2](m.type_conv[1](F.conv2d(multi, w_fold, None, padding=1)))
     loc = m.loc_conv(m.loc_features).repeat(feat.shape[0], 1, 1, 1)       # :979-980
     f = m.predict_contact_net(m.contact_conv(torch.cat((vis, typ, loc), dim=1)))   # :982-984
-    rel_feats, score = relation_head_forward(m.relation_head, f)          # :987
+    hip_trp = trp_on_hip(m.relation_head, f, relation_target)
+    if hip_trp:
+        rel_feats, rel = relation_head_hip(m.relation_head, f, relation_target)   # :987 and :1014-1018
+    else:
+        rel_feats, score = relation_head_forward(m.relation_head, f)      # :987
     k = m.kpt_net(torch.cat((rel_feats, f), dim=1))                       # :991-992
     if m.scale_factor > 1:
         k = m.predict_convtranspose(k)
@@ -62,6 +162,8 @@ def head_forward(model, feat: torch.Tensor, relation_target: Optional[torch.Tens
         multi = F.interpolate(multi, scale_factor=2, mode="bilinear", align_corners=True)
         limbs = F.interpolate(limbs, scale_factor=2, mode="bilinear", align_corners=True)
     limbs = torch.sigmoid(limbs)                                          # :1013
+    if hip_trp:
+        return multi, kpt, limbs, rel
     rel = score
     if relation_target is not None:                                      # :1014-1018
         with torch.no_grad():

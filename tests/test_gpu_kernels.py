@@ -940,3 +940,84 @@ def test_trp_sub_sample_kernels(Cc, dtype):
     ulp = 2.0 ** -9 if dtype == "fp16" else 2.0 ** -7
     assert float((got - y).abs().max()) < ulp * float(y.abs().max())
     assert not out.cpu()[..., Cc:].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("with_target", [True, False])
+def test_trp_backward_kernel_matches_autograd(dtype, with_target):
+    """rsg_trp_backward against torch autograd (fp64, CPU) of the materialised formula on the same 16-bit operands:
+    L = sum(dE * (sigmoid(X X^T) G)) + sum_b dmse_b * mean_ij (p_i p_j - sigmoid(X X^T)_ij)^2, gradients wrt X and G
+    (association.py:288-297, pose_rsgnet.py:1014-1018).  The kernel rounds sigmoid and M to 16 bits before the second
+    product, so the bar is a few 16-bit ulps of the largest gradient."""
+    lib = hip.lib()
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    dt = hip.DTYPES[dtype]
+    B, S, Cc = 2, 384, 32
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(B, S, Cc, generator=g).abs() * 0.35).to(tdt)          # post-ReLU features: scores spread over (0.5, 1)
+    x[:, ::3] *= -1                                                        # and some below 0.5
+    gg = (torch.randn(B, S, Cc, generator=g)).to(tdt)
+    de = (torch.randn(B, S, Cc, generator=g) * 0.01).to(tdt)
+    p = torch.rand(B, S, generator=g)
+    dmse = torch.tensor([0.7, 1.3]) * 50
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    tr = lambda t: t.transpose(1, 2).reshape(B, Cc, S // 16, 16)[..., perm].reshape(B, Cc, S).contiguous()
+    dev = lambda t: t.contiguous().to(DEV)
+    xd, gd, ded, xtd, detd, pd = map(dev, (x, gg, de, tr(x), tr(de), p))
+    coef = dev(dmse * 2.0 / (S * S))
+    dx = torch.full((B, S, Cc), float("nan"), device=DEV)
+    dg = torch.full((B, S, Cc), float("nan"), device=DEV)
+    hip.check(lib.rsg_trp_backward(xd.data_ptr(), Cc, gd.data_ptr(), Cc, ded.data_ptr(), Cc, xtd.data_ptr(), detd.data_ptr(),
+                                   pd.data_ptr() if with_target else None, coef.data_ptr() if with_target else None,
+                                   dx.data_ptr(), dg.data_ptr(), B, S, Cc, dt, _stream()), "trp_backward")
+    torch.cuda.synchronize()
+    X = x.double().requires_grad_(True)
+    G = gg.double().requires_grad_(True)
+    R = torch.sigmoid(X @ X.transpose(1, 2))
+    L = (de.double() * (R @ G)).sum()
+    if with_target:
+        T = p.double()[:, :, None] * p.double()[:, None, :]
+        L = L + (dmse.double() * ((T - R) ** 2).mean(dim=(1, 2))).sum()
+    wx, wg = torch.autograd.grad(L, [X, G])
+    ulp = 2.0 ** -10 if dtype == "fp16" else 2.0 ** -7
+    ex = float((dx.cpu().double() - wx).abs().max()) / float(wx.abs().max())
+    eg = float((dg.cpu().double() - wg).abs().max()) / float(wg.abs().max())
+    print(f"  trp_backward {dtype} target={with_target}: dX err {ex:.2e}  dG err {eg:.2e} of the largest gradient")
+    assert ex < 2 * ulp and eg < 2 * ulp
+
+
+@pytest.mark.gpu
+def test_trp_relation_function_matches_materialised_autograd():
+    """rsgnet_amd.train_rsgnet.TrpRelation (HIP forward + backward, nothing S x S stored) against torch autograd of the
+    reference's materialised formulation (association.py:288-297 + the factored relation MSE) in fp64 on the CPU, from
+    the same bf16-rounded input: E, mse, and the gradients wrt the input map, g.weight and g.bias."""
+    from rsgnet_amd.train_rsgnet import TrpRelation
+    B, Cc, H, W = 2, 32, 16, 24
+    S = H * W
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(B, Cc, H, W, generator=g).abs() * 0.35).to(torch.bfloat16).float()
+    x[:, :, ::2, 1::3] *= -1
+    wg, bg = torch.randn(Cc, Cc, 1, 1, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1
+    p = torch.rand(B, S, generator=g)
+    de = torch.randn(B, Cc, H, W, generator=g) * 0.01
+    dm = torch.tensor([30.0, 60.0])
+    xd = x.to(DEV).requires_grad_(True)
+    wd, bd = wg.to(DEV).requires_grad_(True), bg.to(DEV).requires_grad_(True)
+    e, mse = TrpRelation.apply(xd, wd, bd, p.to(DEV))
+    loss = (e * de.to(DEV)).sum() + (mse * dm.to(DEV)).sum()
+    gx, gw, gb = torch.autograd.grad(loss, [xd, wd, bd])
+    X = x.double().requires_grad_(True)
+    Wg, Bg = wg.double().requires_grad_(True), bg.double().requires_grad_(True)
+    xf = X.reshape(B, Cc, S)
+    R = torch.sigmoid(xf.transpose(1, 2) @ xf)
+    G = F.conv2d(X, Wg, Bg).reshape(B, Cc, S).transpose(1, 2)
+    E = (R @ G).transpose(1, 2).reshape(B, Cc, H, W)
+    T = p.double()[:, :, None] * p.double()[:, None, :]
+    M = ((T - R) ** 2).mean(dim=(1, 2))
+    wx, ww, wb = torch.autograd.grad((E * de.double()).sum() + (M * dm.double()).sum(), [X, Wg, Bg])
+    rel = lambda a, b: float((a.detach().cpu().double() - b.detach()).abs().max()) / float(b.detach().abs().max())
+    errs = dict(E=rel(e, E), mse=rel(mse, M), dX=rel(gx, wx), dW=rel(gw, ww), db=rel(gb, wb))
+    print("  TrpRelation vs fp64:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["E"] < 3e-3 and errs["mse"] < 1e-4
+    assert errs["dX"] < 2 ** -6 and errs["dW"] < 2 ** -6 and errs["db"] < 2 ** -6
