@@ -162,6 +162,7 @@ class RSGNet(HipPoseModule):
     #: (rsgnet_amd/train_rsgnet.py: interim until the head's HIP kernels have a backward)
     supports_training = True
     train_head_on_torch = True
+    train_feat_nhwc16 = True          # the backbone's output map and its gradient cross the boundary as NHWC bf16
 
     def forward(self, x: torch.Tensor, relation_target=None):
         if self.training:

@@ -91,6 +91,7 @@ class TrainPlan:
         head with torch operators on top of it)."""
         self.lib = hip.lib()
         self.with_head = head
+        self.port16 = (not head) and bool(getattr(model, "train_feat_nhwc16", False))   # backbone output / gradient as NHWC bf16
         self.model, self.batch, self.device = model, batch, device
         self.fwd: List[tuple] = []      # (name, launch(stream), group kind or None, group item maker or None)
         self.bwd: List[tuple] = []
@@ -736,6 +737,8 @@ class TrainPlan:
         else:
             self._run_forward()
         if not self.with_head:
+            if self.port16:                               # the head's HIP operators take the plan's own format
+                return self.feat_src.data.clone()
             return self.feat_src.data.permute(0, 3, 1, 2).float().contiguous()
         return self.heat.clone()
 
@@ -755,6 +758,8 @@ class TrainPlan:
         self._backward_done = True
         if self.with_head:
             self.dheat.copy_(dheat)
+        elif self.port16:
+            self.dfeat16.copy_(dheat)                              # already NHWC (bf16, or fp32 from an accumulating autograd)
         else:
             self.dfeat16.copy_(dheat.permute(0, 2, 3, 1))          # fp32 NCHW -> bf16 NHWC (layout and type in one copy)
         hooks = getattr(self.model, "grad_ready_hooks", ())
@@ -787,7 +792,7 @@ class _TrainFn(torch.autograd.Function):
     def backward(ctx, dheat: torch.Tensor):
         plan: TrainPlan = ctx.plan
         with torch.cuda.device(dheat.device):
-            plan.backward(dheat.contiguous().float(), ctx.generation)
+            plan.backward(dheat.contiguous() if plan.port16 else dheat.contiguous().float(), ctx.generation)
         return None, None, None
 
 

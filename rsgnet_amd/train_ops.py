@@ -1,0 +1,281 @@
+"""HIP-backed autograd operators for the training-mode head of pose_rsgnet.
+
+The backbone trains on a recorded launch list (rsgnet_amd/train.py).  The head (pose_rsgnet.py:959-1013) mixes
+convolutions over maps with sub-graphs that depend on the weights alone (type_fc / KTMachine / the location clue), so it
+runs as ordinary autograd: each operator below is ONE node whose forward and backward are the library's kernels, the same
+ones the backbone's training plan launches:
+
+  ConvBnRelu   nn.Conv2d(bias=False) -> nn.BatchNorm2d (training mode: batch statistics, running statistics updated with
+               momentum 0.1) -> [ReLU]      rsg_conv_igemm, rsg_bn_stats/apply; backward rsg_bn_backward, rsg_conv_wgrad
+               (MFMA weight gradient) and the data gradient as rsg_conv_igemm over the transposed, flipped pack
+  Conv1x1Out   the 1x1 classifier convs (bias or not) writing fp32 NCHW maps (multi_final_layer, final_layer, the limb
+               classifier whose weight is KTMachine's output)
+
+Maps travel between them as dense NHWC bf16 tensors [B,H,W,C], C a multiple of 32 -- the training plan's own format, so
+the backbone's output map and its gradient cross the boundary without a conversion.  fp32 master weights are re-packed
+to the MFMA fragment order on the device in every forward (rsg_pack_conv_weights_device: forward and data-gradient forms
+in one launch).  No CPU path: every operator raises off the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+BF16 = hip.RSG_BF16
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def _bn_chunk(c: int) -> int:
+    """rsg_bn_* take a power-of-two channel count in [8, 256]: wider or odd maps are normalised in channel chunks
+    (BatchNorm is per channel, so this is exact)."""
+    k = 256
+    while k > 8 and c % k:
+        k //= 2
+    if c % k:
+        raise NotImplementedError(f"BatchNorm over {c} channels")
+    return k
+
+
+class _ConvState:
+    """Per-conv device buffers that outlive a step: the two weight packs, the packer's item table, workspaces."""
+
+    def __init__(self, cout: int, cin: int, k: int, device: torch.device):
+        lib = hip.lib()
+        self.cout, self.cin, self.k, self.device = cout, cin, k, device
+        self.cin_pad = int(lib.rsg_conv_padded_cin(cin))
+        self.cout_pad = _round_up(cout, 32)
+        u8 = dict(dtype=torch.uint8, device=device)
+        self.pack_fwd = torch.zeros(lib.rsg_conv_packed_bytes(cin, cout, k, k), **u8)
+        self.pack_bwd = torch.zeros(lib.rsg_conv_packed_bytes(cout, cin, k, k), **u8)     # transposed: packed cin = cout
+        blocks_fwd = int(lib.rsg_pack_item_blocks(cin, cout, k, k))
+        blocks_bwd = int(lib.rsg_pack_item_blocks(cout, cin, k, k))                         # as packed: cin and cout swapped
+        self.blocks = blocks_fwd + blocks_bwd
+        self.w_stage = torch.zeros(cout, cin, k, k, dtype=torch.float32, device=device)   # static address for the packer
+        items = (hip.PackItem * 2)()
+        for it, dst, tr, first in ((items[0], self.pack_fwd, 0, 0), (items[1], self.pack_bwd, 1, blocks_fwd)):
+            it.w, it.dst, it.cin, it.cout, it.kh, it.kw = self.w_stage.data_ptr(), dst.data_ptr(), cin, cout, k, k
+            it.transpose, it.first_block = tr, first
+        self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
+        self.zero_bias = torch.zeros(max(self.cout_pad, _round_up(self.cin_pad, 32)), dtype=torch.float32, device=device)
+        self._wgrad_ws: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+        self._bn_ws: Optional[torch.Tensor] = None
+
+    def pack(self, w: torch.Tensor):
+        """fp32 [O,I,k,k] (a parameter, or a tensor computed from parameters) -> both 16-bit packs."""
+        lib = hip.lib()
+        self.w_stage.copy_(w.detach().reshape(self.w_stage.shape))
+        hip.check(lib.rsg_pack_conv_weights_device(self.table.data_ptr(), 2, self.blocks, BF16, _stream(self.w_stage)),
+                  "pack_weights")
+
+    def wgrad_ws(self, b: int, h: int, w: int, cout_pad: Optional[int] = None) -> torch.Tensor:
+        cout_pad = cout_pad or self.cout_pad
+        key = (b, h, w, cout_pad)
+        ws = self._wgrad_ws.get(key)
+        if ws is None:
+            pad = (self.k - 1) // 2
+            need = int(hip.lib().rsg_conv_wgrad_workspace_bytes(b, h, w, self.cin_pad, h, w, cout_pad, self.k, self.k, 1, pad))
+            if not need:
+                raise NotImplementedError(f"weight gradient of a {self.k}x{self.k} conv {self.cin}->{self.cout}")
+            ws = self._wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def bn_ws(self) -> torch.Tensor:
+        if self._bn_ws is None:
+            self._bn_ws = torch.empty(hip.lib().rsg_bn_workspace_bytes(256), dtype=torch.uint8, device=self.device)
+        return self._bn_ws
+
+
+def conv_state(owner: nn.Module, key: str, cout: int, cin: int, k: int, device: torch.device) -> _ConvState:
+    cache = owner.__dict__.setdefault("_hip_conv_states", {})
+    st = cache.get(key)
+    if st is None or st.device != device or (st.cout, st.cin, st.k) != (cout, cin, k):
+        st = cache[key] = _ConvState(cout, cin, k, device)
+    return st
+
+
+def _conv(st: _ConvState, x16: torch.Tensor, pack: torch.Tensor, in_c: int, out_c: int, bias: torch.Tensor,
+          out16: Optional[torch.Tensor], out_f32: Optional[torch.Tensor], what: str):
+    """stride-1 'same' conv of a dense NHWC bf16 map through rsg_conv_igemm."""
+    b, h, w, c = x16.shape
+    if c != in_c or x16.dtype != torch.bfloat16 or not x16.is_contiguous():
+        raise ValueError(f"{what}: input {tuple(x16.shape)} {x16.dtype}, the conv wants dense bf16 with {in_c} channels")
+    d = hip.ConvDesc()
+    pad = (st.k - 1) // 2
+    d.inp, d.w_packed, d.bias = x16.data_ptr(), pack.data_ptr(), bias.data_ptr()
+    d.out16 = out16.data_ptr() if out16 is not None else None
+    d.out_nchw_f32 = out_f32.data_ptr() if out_f32 is not None else None
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = b, h, w, in_c, in_c
+    d.out_h, d.out_w, d.out_c, d.out_ld = h, w, out_c, _round_up(out_c, 32)
+    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = st.k, st.k, 1, pad, pad
+    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, h, w
+    d.relu, d.dtype = 0, BF16
+    hip.check(hip.lib().rsg_conv_igemm(C.byref(d), _stream(x16)), what)
+
+
+def _need_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} runs on the HIP kernels of librsgnet_hip.so only; got a {t.device.type} tensor")
+
+
+class ConvBnRelu(torch.autograd.Function):
+    """z = [ReLU](BatchNorm_train(conv(x))) on dense NHWC bf16 maps.  `w` is the fp32 [O,I,k,k] weight (gradient: fp32,
+    same shape), gamma/beta the BatchNorm's affine terms; `bn` supplies the running statistics (updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x16, w, gamma, beta, st: _ConvState, bn: nn.BatchNorm2d, relu: bool):
+        _need_gpu(x16, "ConvBnRelu")
+        lib = hip.lib()
+        b, h, wd, _ = x16.shape
+        px, O = b * h * wd, st.cout
+        if O != st.cout_pad:
+            raise NotImplementedError("ConvBnRelu: output channels must be a multiple of 32")
+        if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+            raise NotImplementedError("BatchNorm2d without momentum / running statistics / affine terms")
+        s = _stream(x16)
+        st.pack(w)
+        y = torch.empty(b, h, wd, O, dtype=torch.bfloat16, device=x16.device)
+        _conv(st, x16, st.pack_fwd, st.cin_pad, O, st.zero_bias, y, None, "conv forward")
+        ck = _bn_chunk(O)
+        n = O // ck
+        ys = [y] if n == 1 else [y[..., i * ck:(i + 1) * ck].contiguous() for i in range(n)]
+        mean = torch.empty(O, dtype=torch.float32, device=x16.device)
+        invstd = torch.empty_like(mean)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        zs = []
+        for i, yc in enumerate(ys):
+            lo = i * ck
+            rm, rv = bn.running_mean[lo:lo + ck], bn.running_var[lo:lo + ck]
+            hip.check(lib.rsg_bn_stats(yc.data_ptr(), px, ck, BF16, st.bn_ws().data_ptr(), mean[lo:].data_ptr(), invstd[lo:].data_ptr(),
+                                       rm.data_ptr(), rv.data_ptr(), float(bn.momentum), float(bn.eps), s), "bn_stats")
+            z = torch.empty_like(yc)
+            hip.check(lib.rsg_bn_apply(yc.data_ptr(), mean[lo:].data_ptr(), invstd[lo:].data_ptr(), g32[lo:].data_ptr(),
+                                       b32[lo:].data_ptr(), None, int(relu), z.data_ptr(), px, ck, BF16, s), "bn_apply")
+            zs.append(z)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        z = zs[0] if n == 1 else torch.cat(zs, dim=3)
+        ctx.st, ctx.relu, ctx.ck = st, relu, ck
+        ctx.save_for_backward(x16, z, mean, invstd, g32, *ys)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = hip.lib()
+        st, relu, ck = ctx.st, ctx.relu, ctx.ck
+        x16, z, mean, invstd, g32, *ys = ctx.saved_tensors
+        b, h, wd, _ = x16.shape
+        px, O, n = b * h * wd, st.cout, len(ys)
+        s = _stream(x16)
+        dz = dz.to(torch.bfloat16).contiguous()
+        dgamma = torch.empty(O, dtype=torch.float32, device=x16.device)
+        dbeta = torch.empty_like(dgamma)
+        dys = []
+        for i, yc in enumerate(ys):
+            lo = i * ck
+            dzc = dz if n == 1 else dz[..., lo:lo + ck].contiguous()
+            zc = z if n == 1 else z[..., lo:lo + ck].contiguous()
+            dy = torch.empty_like(yc)
+            hip.check(lib.rsg_bn_backward(dzc.data_ptr(), zc.data_ptr() if relu else None, yc.data_ptr(), mean[lo:].data_ptr(),
+                                          invstd[lo:].data_ptr(), g32[lo:].data_ptr(), dy.data_ptr(), None,
+                                          dgamma[lo:].data_ptr(), dbeta[lo:].data_ptr(), st.bn_ws().data_ptr(), px, ck, BF16, s),
+                      "bn_backward")
+            dys.append(dy)
+        dy = dys[0] if n == 1 else torch.cat(dys, dim=3)
+        dw = torch.empty(O, st.cin, st.k, st.k, dtype=torch.float32, device=x16.device)
+        pad = (st.k - 1) // 2
+        hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), dy.data_ptr(), dw.data_ptr(), st.wgrad_ws(b, h, wd).data_ptr(), b, h, wd,
+                                     st.cin, st.cin_pad, h, wd, O, st.cout_pad, st.k, st.k, 1, pad, BF16, s), "conv_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            cin_out = _round_up(st.cin, 32)
+            if cin_out != x16.shape[3]:
+                raise NotImplementedError(f"data gradient into a {x16.shape[3]}-channel map of a conv with {st.cin} inputs")
+            dx = torch.empty_like(x16)
+            _conv(st, dy, st.pack_bwd, st.cout_pad, st.cin, st.zero_bias, dx, None, "conv data gradient")
+        return dx, dw, dgamma, dbeta, None, None, None
+
+
+def conv_bn_relu(owner: nn.Module, key: str, x16: torch.Tensor, conv_w: torch.Tensor, bn: nn.BatchNorm2d, relu: bool = True):
+    """`owner`/`key` name the persistent device state (packs, workspaces) of this conv."""
+    O, I, k, _ = conv_w.shape
+    st = conv_state(owner, key, O, I, k, x16.device)
+    return ConvBnRelu.apply(x16, conv_w, bn.weight, bn.bias, st, bn, relu)
+
+
+class Conv1x1Out(torch.autograd.Function):
+    """out = conv1x1(x16, w) [+ bias] as an fp32 NCHW map [B,J,H,W] (the classifier heads, pose_rsgnet.py:961,1000,1005)."""
+
+    @staticmethod
+    def forward(ctx, x16, w, bias, st: _ConvState):
+        _need_gpu(x16, "Conv1x1Out")
+        b, h, wd, _ = x16.shape
+        J = st.cout
+        st.pack(w)
+        bias32 = torch.zeros(st.cout_pad, dtype=torch.float32, device=x16.device)
+        if bias is not None:
+            bias32[:J].copy_(bias.detach())
+        out = torch.empty(b, J, h, wd, dtype=torch.float32, device=x16.device)
+        _conv(st, x16, st.pack_fwd, st.cin_pad, J, bias32, None, out, "classifier conv")
+        ctx.st, ctx.has_bias = st, bias is not None
+        ctx.save_for_backward(x16)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = hip.lib()
+        st = ctx.st
+        x16, = ctx.saved_tensors
+        b, h, wd, _ = x16.shape
+        J, s = st.cout, _stream(x16)
+        dout = dout.float().contiguous()
+        dpad = int(lib.rsg_conv_padded_cin(J))           # the gradient map is the data-gradient conv's INPUT
+        d16 = torch.empty(b, h, wd, dpad, dtype=torch.bfloat16, device=x16.device)
+        hip.check(lib.rsg_nchw_f32_to_nhwc16(dout.data_ptr(), d16.data_ptr(), b, J, h, wd, dpad, BF16, s), "dheat")
+        dbias = None
+        if ctx.has_bias:
+            dbias = torch.empty(J, dtype=torch.float32, device=x16.device)
+            csw = torch.empty(lib.rsg_channel_sum_workspace_bytes(J), dtype=torch.uint8, device=x16.device)
+            hip.check(lib.rsg_channel_sum_nchw_f32(dout.data_ptr(), dbias.data_ptr(), csw.data_ptr(), b, J, h * wd, s), "dbias")
+        dw = torch.empty(J, st.cin, 1, 1, dtype=torch.float32, device=x16.device)
+        hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), d16.data_ptr(), dw.data_ptr(), st.wgrad_ws(b, h, wd, dpad).data_ptr(), b, h, wd,
+                                     st.cin, st.cin_pad, h, wd, J, dpad, 1, 1, 1, 0, BF16, s), "conv_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _round_up(st.cin, 32) != x16.shape[3]:
+                raise NotImplementedError(f"data gradient into a {x16.shape[3]}-channel map of a conv with {st.cin} inputs")
+            dx = torch.empty_like(x16)
+            _conv(st, d16, st.pack_bwd, dpad, st.cin, st.zero_bias, dx, None, "classifier data gradient")
+        return dx, dw, dbias, None
+
+
+def conv1x1_out(owner: nn.Module, key: str, x16: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]):
+    J, I = int(w.shape[0]), int(w.shape[1])
+    st = conv_state(owner, key, J, I, 1, x16.device)
+    return Conv1x1Out.apply(x16, w.reshape(J, I, 1, 1), bias, st)
+
+
+def nchw_to_nhwc16(t: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:
+    """fp32 NCHW -> dense NHWC bf16, channels zero-padded to c_pad (differentiable: torch ops)."""
+    b, c, h, w = t.shape
+    c_pad = c_pad or _round_up(c, 32)
+    x = t.permute(0, 2, 3, 1)
+    if c_pad != c:
+        x = torch.nn.functional.pad(x, (0, c_pad - c))
+    return x.to(torch.bfloat16).contiguous()
+
+
+def nhwc16_to_nchw(t: torch.Tensor, c: Optional[int] = None) -> torch.Tensor:
+    x = t if c is None else t[..., :c]
+    return x.permute(0, 3, 1, 2).float().contiguous()

@@ -1,19 +1,22 @@
 """Training-mode forward of `pose_rsgnet` (/root/reference/lib/models/pose_rsgnet.py:955-1021 under
 `model.train()`, driven by `rsgnet_train`, /root/reference/lib/core/function.py:239-323).
 
-Two parts:
   * the HRNet backbone (stem .. stage4: 99 % of the step's arithmetic) runs on the HIP training plan of
     rsgnet_amd/train.py -- the same launch lists as `pose_hrnet`, recorded up to the backbone's output map, which comes out
-    as ONE autograd node;
+    as ONE autograd node (NHWC bf16, the plan's own format);
+  * every conv -> BatchNorm -> ReLU unit of the head (vis_conv, type_conv, contact_conv, predict_contact_net, kpt_net,
+    predict_net, limbs_net) and the three 1x1 classifiers (multi_final_layer, final_layer, the limb classifier) are autograd
+    nodes on the library's kernels (rsgnet_amd/train_ops.py: rsg_conv_igemm, rsg_bn_*, rsg_conv_wgrad, the data gradient as a
+    conv over the transposed pack);
   * the TRP's relation (association.py:288-297) and the relation MSE against the factored target (pose_rsgnet.py:1014-1018)
     run on csrc/trp.hip in both directions (`TrpRelation` below): neither pass stores the [B,S,S] map (1.2 GB at batch 32,
     S = 3072, which the reference's autograd keeps alive between forward and backward);
-  * the rest of the head (clue encoders, W, joints-of-target branch, SGM convs) is written here with PyTorch-ROCm operators
-    on the model's own modules, so autograd supplies its backward.  INTERIM: the grouped HIP convs of the inference head
-    have no backward yet; until they do, these small convs' training arithmetic is torch's (GPU, fp32).  The two
-    weight-only sub-graphs keep their exact algebraic folds, which autograd differentiates: the type path is a 3x3 conv
-    J -> C0 with W'[o,j] = sum_c type_conv.W[o,c] * Tm[j,c] (the [B,600,H,W] map of pose_rsgnet.py:974 is never built), and
-    the relation target stays factored (T = p p^T) when it is given as [B,S].
+  * what depends on the weights alone stays an ordinary autograd expression over a few KB, evaluated on the device by
+    PyTorch-ROCm: type_fc (Linear -> BatchNorm1d over the J rows -> ReLU) folded with type_conv's weight into a 3x3 conv
+    J -> C0, W'[o,j] = sum_c type_conv.W[o,c] * Tm[j,c] (the [B,600,H,W] map of pose_rsgnet.py:974 is never built);
+    KTMachine (the limb classifier's weight from final_layer's); the location clue loc_conv(loc_features);
+  * INTERIM, still PyTorch-ROCm operators: W's 1x1 conv + GroupNorm behind the TRP, the up-sampling
+    ConvTranspose2d + BatchNorm + ReLU, the two x2 bilinear up-samplings and the sigmoid.
 """
 from __future__ import annotations
 
@@ -35,12 +38,6 @@ def kt_machine_forward(kt, weight: torch.Tensor) -> torch.Tensor:
 _KEY_ORDER = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)   # rsg_trp_project_g's order of the keys in a 16-block
 
 
-def _rows16(t: torch.Tensor) -> torch.Tensor:
-    """fp32 NCHW -> bf16 rows [B,S,C]."""
-    b, c, h, w = t.shape
-    return t.permute(0, 2, 3, 1).reshape(b, h * w, c).to(torch.bfloat16).contiguous()
-
-
 def _keys_transposed(rows: torch.Tensor) -> torch.Tensor:
     """[B,S,C] -> [B,C,S] with every 16-block of keys in the kernel's order."""
     b, s, c = rows.shape
@@ -50,9 +47,10 @@ def _keys_transposed(rows: torch.Tensor) -> torch.Tensor:
 
 class TrpRelation(torch.autograd.Function):
     """E = sigmoid(X X^T) (X Wg^T + bg) and mse_b = mean_ij (p_i p_j - sigmoid(X X^T)_ij)^2 on the HIP kernels, bf16
-    operands and fp32 accumulation as the backbone's training plan.  forward: rsg_trp_project_g + rsg_trp_attention
-    + rsg_trp_relation_mse; backward: rsg_trp_backward (sigmoid recomputed per tile) and three small fp32 matmuls for
-    the g projection's own gradients."""
+    operands and fp32 accumulation as the backbone's training plan.  x: rows [B,S,C] (bf16, or fp32 rounded here);
+    returns E [B,S,C] fp32 and mse [B].  forward: rsg_trp_project_g + rsg_trp_attention + rsg_trp_relation_mse;
+    backward: rsg_trp_backward (sigmoid recomputed per tile) and three small fp32 matmuls for the g projection's own
+    gradients."""
 
     @staticmethod
     def forward(ctx, x, wg, bg, p):
@@ -60,10 +58,9 @@ class TrpRelation(torch.autograd.Function):
         if not x.is_cuda:
             raise RuntimeError("TrpRelation runs on the HIP kernels: the input must be on the GPU")
         lib = hip.lib()
-        b, c, h, w = x.shape
-        s = h * w
+        b, s, c = x.shape
         st = torch.cuda.current_stream(x.device).cuda_stream
-        x16 = _rows16(x)
+        x16 = x.detach().to(torch.bfloat16).contiguous()
         w32 = wg.detach().reshape(c, c).float().contiguous()
         b32 = bg.detach().float().contiguous()
         g_hi = torch.empty(b, c, s, dtype=torch.bfloat16, device=x.device)
@@ -79,20 +76,19 @@ class TrpRelation(torch.autograd.Function):
             hip.check(lib.rsg_trp_relation_mse(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), b, s, c, hip.RSG_BF16, st),
                       "trp_relation_mse")
         ctx.save_for_backward(x16, w32, b32, p32)
-        ctx.shape = (b, c, h, w)
-        return e.reshape(b, h, w, c).permute(0, 3, 1, 2), mse
+        ctx.in_dtype = x.dtype
+        return e, mse
 
     @staticmethod
     def backward(ctx, d_e, d_mse):
         from . import hip
         lib = hip.lib()
         x16, w32, b32, p32 = ctx.saved_tensors
-        b, c, h, w = ctx.shape
-        s = h * w
+        b, s, c = x16.shape
         st = torch.cuda.current_stream(x16.device).cuda_stream
         xf = x16.float()
         g16 = torch.addmm(b32, xf.reshape(-1, c), w32.t()).to(torch.bfloat16).reshape(b, s, c)
-        de16 = _rows16(d_e) if d_e is not None else torch.zeros_like(x16)
+        de16 = d_e.to(torch.bfloat16).contiguous() if d_e is not None else torch.zeros_like(x16)
         x_t, de_t = _keys_transposed(x16), _keys_transposed(de16)
         coef = None
         if p32 is not None:
@@ -106,28 +102,27 @@ class TrpRelation(torch.autograd.Function):
         dx = dx + (dg2 @ w32).reshape(b, s, c)                               # g = x Wg^T + bg
         d_w = (dg2.t() @ xf.reshape(-1, c)).reshape(c, c, 1, 1)
         d_b = dg2.sum(0)
-        return dx.reshape(b, h, w, c).permute(0, 3, 1, 2), d_w, d_b, None
+        return dx.to(ctx.in_dtype), d_w, d_b, None
 
 
-def relation_head_hip(rh, x: torch.Tensor, p: Optional[torch.Tensor]):
-    """SpatialRelationHead.forward on TrpRelation; returns (relation features, relation mse [B] against T = p p^T)."""
-    if getattr(rh, "sub_sample", False):
-        x = F.max_pool2d(x, 2)
-    e, mse = TrpRelation.apply(x, rh.g.weight, rh.g.bias, p)
-    return rh.W(e), mse
-
-
-def trp_on_hip(rh, x: torch.Tensor, relation_target) -> bool:
+def trp_on_hip(rh, channels: int, positions: int, relation_target) -> bool:
     """The HIP pair covers what training uses: 32 channels, S a multiple of 128, the target given as its factor [B,S]."""
-    if relation_target is None or relation_target.dim() != 2 or not x.is_cuda:
+    if relation_target is None or relation_target.dim() != 2:
         return False
-    s = x.shape[2] * x.shape[3] // (4 if getattr(rh, "sub_sample", False) else 1)
-    return x.shape[1] == 32 and s % 128 == 0
+    s = positions // (4 if getattr(rh, "sub_sample", False) else 1)
+    return channels == 32 and s % 128 == 0
+
+
+def type_conv_weight(m) -> torch.Tensor:
+    """type_conv[0] applied to scores^T @ type_fc(type_features) (pose_rsgnet.py:971-977) == a 3x3 conv J -> C0 over the
+    scores with this weight, exactly (both maps are linear in the scores)."""
+    tm = m.type_fc(m.type_features)                                       # [J,T], training-mode BatchNorm1d over the J rows
+    return torch.einsum("ocyx,jc->ojyx", m.type_conv[0].weight, tm)
 
 
 def relation_head_forward(rh, x: torch.Tensor):
     """SpatialRelationHead.forward (association.py:280-301) with the score map materialised ([B,S,S] fp32: what the
-    reference does; 1.2 GB at batch 32, S = 3072)."""
+    reference does; 1.2 GB at batch 32, S = 3072): the path for a target given as [B,S,S] or not at all."""
     if getattr(rh, "sub_sample", False):
         x = F.max_pool2d(x, 2)
     b, c, h, w = x.shape
@@ -138,26 +133,41 @@ def relation_head_forward(rh, x: torch.Tensor):
     return rh.W(e), score
 
 
-def head_forward(model, feat: torch.Tensor, relation_target: Optional[torch.Tensor]):
-    """pose_rsgnet.py:959-1021 from the backbone's output map `feat` [B,C0,H/4,W/4] (fp32 NCHW, requires grad)."""
+def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Tensor]):
+    """pose_rsgnet.py:959-1021 from the backbone's output map `feat16` [B,H/4,W/4,C0] (NHWC bf16, requires grad)."""
+    from .train_ops import conv1x1_out, conv_bn_relu, nchw_to_nhwc16, nhwc16_to_nchw
     m = model
-    multi = m.multi_final_layer(feat)                                     # :961
-    vis = m.vis_conv(feat)                                                # :965
-    tm = m.type_fc(m.type_features)                                       # [J,T], training-mode BatchNorm1d over the J rows (:971-972)
-    w_fold = torch.einsum("ocyx,jc->ojyx", m.type_conv[0].weight, tm)     # == type_conv(scores^T @ Tm), :974-977, exactly
-    typ = m.type_conv[2](m.type_conv[1](F.conv2d(multi, w_fold, None, padding=1)))
-    loc = m.loc_conv(m.loc_features).repeat(feat.shape[0], 1, 1, 1)       # :979-980
-    f = m.predict_contact_net(m.contact_conv(torch.cat((vis, typ, loc), dim=1)))   # :982-984
-    hip_trp = trp_on_hip(m.relation_head, f, relation_target)
-    if hip_trp:
-        rel_feats, rel = relation_head_hip(m.relation_head, f, relation_target)   # :987 and :1014-1018
+    B, H, W, c0 = feat16.shape
+    taps = getattr(m, "_train_taps", None)              # tests: the units' outputs by BatchNorm name (ReLU decisions)
+    if taps is not None:
+        def conv_bn_relu(owner, key, x16, w, bn, _f=conv_bn_relu):
+            z = _f(owner, key, x16, w, bn)
+            taps[key + ".1"] = z.detach()
+            return z
+    multi = conv1x1_out(m, "multi_final_layer", feat16, m.multi_final_layer.weight, m.multi_final_layer.bias)   # :961
+    vis = conv_bn_relu(m, "vis_conv", feat16, m.vis_conv[0].weight, m.vis_conv[1])                            # :965
+    typ = conv_bn_relu(m, "type_conv", nchw_to_nhwc16(multi), type_conv_weight(m), m.type_conv[1])           # :971-977
+    loc = nchw_to_nhwc16(m.loc_conv(m.loc_features)).expand(B, -1, -1, -1)                                     # :979-980
+    f = conv_bn_relu(m, "contact_conv", torch.cat((vis, typ, loc), dim=3), m.contact_conv[0].weight, m.contact_conv[1])
+    f = conv_bn_relu(m, "predict_contact_net", f, m.predict_contact_net[0].weight, m.predict_contact_net[1])   # :982-984
+    rh = m.relation_head
+    hip_trp = trp_on_hip(rh, c0, H * W, relation_target)
+    if hip_trp:                                                           # :987 and :1014-1018
+        x = f
+        if getattr(rh, "sub_sample", False):
+            x = nchw_to_nhwc16(F.max_pool2d(nhwc16_to_nchw(f), 2))
+        b, hr, wr, _ = x.shape
+        e, rel = TrpRelation.apply(x.reshape(b, hr * wr, c0), rh.g.weight, rh.g.bias, relation_target)
+        rel_feats = rh.W(e.reshape(b, hr, wr, c0).permute(0, 3, 1, 2))
     else:
-        rel_feats, score = relation_head_forward(m.relation_head, f)      # :987
-    k = m.kpt_net(torch.cat((rel_feats, f), dim=1))                       # :991-992
+        rel_feats, score = relation_head_forward(rh, nhwc16_to_nchw(f))
+    k = conv_bn_relu(m, "kpt_net", torch.cat((nchw_to_nhwc16(rel_feats), f), dim=3), m.kpt_net[0].weight, m.kpt_net[1])   # :991-992
     if m.scale_factor > 1:
-        k = m.predict_convtranspose(k)
-    kpt = m.final_layer(m.predict_net(k))                                 # :999-1000
-    limbs = F.conv2d(m.limbs_net(f), kt_machine_forward(m.kt_machine, m.final_layer.weight))   # :1003-1005
+        k = nchw_to_nhwc16(m.predict_convtranspose(nhwc16_to_nchw(k)))
+    k = conv_bn_relu(m, "predict_net", k, m.predict_net[0].weight, m.predict_net[1])
+    kpt = conv1x1_out(m, "final_layer", k, m.final_layer.weight, m.final_layer.bias)                           # :999-1000
+    lm = conv_bn_relu(m, "limbs_net", f, m.limbs_net[0].weight, m.limbs_net[1])
+    limbs = conv1x1_out(m, "limbs", lm, kt_machine_forward(m.kt_machine, m.final_layer.weight), None)         # :1003-1005
     if m.scale_factor > 1:
         multi = F.interpolate(multi, scale_factor=2, mode="bilinear", align_corners=True)
         limbs = F.interpolate(limbs, scale_factor=2, mode="bilinear", align_corners=True)
@@ -177,5 +187,5 @@ def head_forward(model, feat: torch.Tensor, relation_target: Optional[torch.Tens
 def train_forward(model, x: torch.Tensor, relation_target: Optional[torch.Tensor] = None):
     """`model(x, relation_target)` under `model.train()` for pose_rsgnet."""
     from .train import train_forward as backbone_forward
-    feat = backbone_forward(model, x)                                     # HIP: one autograd node for the whole backbone
-    return head_forward(model, feat, relation_target)
+    feat16 = backbone_forward(model, x)                                   # HIP: one autograd node for the whole backbone
+    return head_forward(model, feat16, relation_target)

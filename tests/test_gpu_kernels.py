@@ -97,6 +97,9 @@ CONV_CASES = [
     (2, 96, 96, 16, 12, 3, 1, True, False),      # contact_conv
     (2, 17, 32, 16, 12, 3, 1, True, False),      # folded type conv (17 -> padded 32)
     (2, 32, 32, 128, 96, 3, 1, True, False),     # predict_net
+    (2, 64, 32, 16, 24, 3, 1, True, False),      # kpt_net
+    (2, 32, 64, 16, 24, 3, 1, False, False),     # data gradient of kpt_net (32 -> 64 channels, stride 1)
+    (2, 32, 96, 16, 24, 3, 1, False, False),     # data gradient of predict_contact_net
     # ... and ragged / odd tails
     (1, 32, 32, 7, 5, 3, 1, True, True),
     (2, 64, 64, 13, 9, 3, 2, True, False),

@@ -1,0 +1,89 @@
+"""HIP-backed autograd operators of the RSGNet training head (rsgnet_amd/train_ops.py) against torch autograd in fp64 on
+the CPU, from the same bf16-rounded inputs (pose_rsgnet.py:961-1005: the conv -> BatchNorm -> ReLU units and the 1x1
+classifiers)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    b = b.detach().double()
+    return float((a.detach().cpu().double() - b).norm() / (b.norm() + 1e-300))
+
+
+@pytest.mark.parametrize("cin,cout,k", [(32, 32, 3), (96, 96, 3), (96, 32, 3), (64, 32, 3), (17, 32, 3)])
+def test_conv_bn_relu_matches_autograd(cin, cout, k):
+    from rsgnet_amd import hip
+    from rsgnet_amd.train_ops import conv_bn_relu
+    B, H, W = 2, 16, 24
+    g = torch.Generator().manual_seed(cin * 100 + cout + k)
+    cpad = int(hip.lib().rsg_conv_padded_cin(cin))
+    cpad = (cpad + 31) // 32 * 32
+    x = torch.zeros(B, H, W, cpad)
+    x[..., :cin] = torch.randn(B, H, W, cin, generator=g)
+    x = x.to(torch.bfloat16)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(torch.bfloat16).float()
+    bn = nn.BatchNorm2d(cout, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+    dz = torch.randn(B, H, W, cout, generator=g).to(torch.bfloat16)
+    # HIP
+    owner = nn.Module()
+    gam, bet = bn.weight.detach().clone(), bn.bias.detach().clone()
+    bnd = bn.cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    z = conv_bn_relu(owner, "unit", xd, wd, bnd)
+    gx, gw, gg, gb = torch.autograd.grad((z.float() * dz.cuda().float()).sum(), [xd, wd, bnd.weight, bnd.bias])
+    # fp64 reference (NCHW), teacher-forced: the ReLU takes its decisions from the HIP output, so both sides differentiate
+    # the same piecewise-linear function (a flipped decision at a near-zero pixel is rounding, not an error of the backward)
+    X = x[..., :cin].double().permute(0, 3, 1, 2).requires_grad_(True)
+    Wt = w.double().requires_grad_(True)
+    G, Bt = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rm, rv = torch.zeros(cout, dtype=torch.float64), torch.ones(cout, dtype=torch.float64)
+    Y = F.conv2d(X, Wt, None, padding=(k - 1) // 2)
+    Z = F.batch_norm(Y, rm, rv, G, Bt, True, 0.1, 1e-5) * (z.detach() > 0).permute(0, 3, 1, 2).cpu().double()
+    wx, ww, wg, wb = torch.autograd.grad((Z * dz.double().permute(0, 3, 1, 2)).sum(), [X, Wt, G, Bt])
+    torch.cuda.synchronize()
+    ez = float((z.detach().cpu().double().permute(0, 3, 1, 2) - Z.detach()).abs().max()) / float(Z.detach().abs().max())
+    errs = dict(z=ez, dx=_rel(gx[..., :cin].permute(0, 3, 1, 2), wx), dw=_rel(gw, ww), dgamma=_rel(gg, wg), dbeta=_rel(gb, wb))
+    print(f"  conv_bn_relu {cin}->{cout} k{k}:", {n: f"{v:.2e}" for n, v in errs.items()})
+    assert ez < 2 ** -6                                            # two bf16 roundings (y, z) of values up to |Z|max
+    assert errs["dx"] < 1e-2 and errs["dw"] < 1e-2 and errs["dgamma"] < 1e-2 and errs["dbeta"] < 1e-2, errs
+    assert not gx[..., cin:].any()                                 # padding channels carry no gradient
+    assert float((bnd.running_mean.cpu().double() - rm).abs().max()) < 2e-3 * max(1.0, float(rm.abs().max()))
+    assert float((bnd.running_var.cpu().double() - rv).abs().max()) < 1e-2 * float(rv.abs().max())
+    assert int(bnd.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("J,bias", [(17, True), (18, False), (14, True)])
+def test_conv1x1_out_matches_autograd(J, bias):
+    from rsgnet_amd.train_ops import conv1x1_out
+    B, H, W, Cc = 2, 16, 24, 32
+    g = torch.Generator().manual_seed(J)
+    x = torch.randn(B, H, W, Cc, generator=g).to(torch.bfloat16)
+    w = (torch.randn(J, Cc, 1, 1, generator=g) * 0.2).to(torch.bfloat16).float()
+    b = torch.randn(J, generator=g) * 0.1 if bias else None
+    dout = torch.randn(B, J, H, W, generator=g).to(torch.bfloat16).float()
+    X = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    Wt = w.double().requires_grad_(True)
+    Bt = b.double().requires_grad_(True) if bias else None
+    O = F.conv2d(X, Wt, Bt)
+    want = torch.autograd.grad((O * dout.double()).sum(), [X, Wt] + ([Bt] if bias else []))
+    owner = nn.Module()
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True) if bias else None
+    out = conv1x1_out(owner, "cls", xd, wd, bd)
+    got = torch.autograd.grad((out * dout.cuda()).sum(), [xd, wd] + ([bd] if bias else []))
+    torch.cuda.synchronize()
+    assert out.shape == (B, J, H, W) and out.dtype == torch.float32
+    eo = float((out.detach().cpu().double() - O.detach()).abs().max()) / float(O.abs().max())
+    errs = dict(out=eo, dx=_rel(got[0].permute(0, 3, 1, 2), want[0]), dw=_rel(got[1], want[1]))
+    if bias:
+        errs["db"] = _rel(got[2], want[2])
+    print(f"  conv1x1_out 32->{J}:", {n: f"{v:.2e}" for n, v in errs.items()})
+    assert eo < 1e-5 and errs["dx"] < 1e-2 and errs["dw"] < 1e-4 and errs.get("db", 0) < 1e-5, errs
