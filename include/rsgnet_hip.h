@@ -266,6 +266,11 @@ int rsg_conv_fuse_group_run(const void* table_host, int32_t blocks, int32_t lds,
  * (pose_rsgnet.py:1009-1013) */
 int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t planes, int32_t h, int32_t w,
                             int32_t sigmoid, void* stream);
+/* Backward of rsg_bilinear2x_nchw_f32 (training; autograd of F.interpolate(scale_factor=2, 'bilinear', align_corners=True)
+ * [+ torch.sigmoid], /root/reference/lib/models/pose_rsgnet.py:1009-1013): din [planes,h,w] from dout [planes,2h,2w];
+ * prob = the forward's sigmoid output (the gradient then passes through p (1 - p) first) or NULL.  Gather form, fixed order. */
+int rsg_bilinear2x_backward_nchw_f32(const float* dout, const float* prob, float* din, int32_t planes, int32_t h,
+                                     int32_t w, void* stream);
 
 /* Flip-test merge on the device (lib/core/function.py:400-427 with lib/utils/transforms.py:23-37):
  * out = 0.5 * (h + shift(flip_back(h_flipped))), fp32 NCHW [batch,joints,height,width].  perm_host[j] is the
@@ -313,6 +318,16 @@ int rsg_f32_rows_to_nhwc16(const float* in, void* out, int32_t out_ld, int64_t r
 int rsg_trp_tail_in16(const void* e16, int32_t e_ld, const float* w, const float* bias, const float* gn_gamma,
                       const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
                       int32_t dtype, void* workspace, void* stream);
+/* Backward of rsg_trp_tail (training; autograd of W = conv1x1 + bias -> GroupNorm(8,C), association.py:298-300).
+ * dout: gradient of the tail's 16-bit output, rows [batch,S,ld]; fwd_workspace: the workspace rsg_trp_tail filled in the
+ * forward (y = W e + b in fp32 and the group partials).  Writes dy (gradient of y) and de = W^T dy, both fp32 [batch,S,C], and
+ * `partials` (rsg_trp_tail_backward_partial_floats floats): [batch][S/256][2C] per-workgroup sums of dout*yhat (first C) and
+ * dout (next C) -- dgamma / dbeta are their sums over the first two axes -- followed by the group sums the second launch
+ * merges.  dW = dy^T e and dbias = sum dy are left to the caller's BLAS.  C = 32, S % 256 == 0, fixed summation order. */
+size_t rsg_trp_tail_backward_partial_floats(int32_t batch, int32_t S, int32_t C);
+int rsg_trp_tail_backward(const void* dout, int32_t ld, const void* fwd_workspace, const float* w, const float* gn_gamma,
+                          float* dy, float* de, float* partials, int32_t batch, int32_t S, int32_t C, int32_t dtype,
+                          void* stream);
 /* TRP backward for training (autograd of /root/reference/lib/models/association.py:288-297 and of the relation MSE,
  * pose_rsgnet.py:1014-1018, which the reference leaves to torch on the materialised [B,S,S] map).  Inputs, all 16-bit of
  * `dtype`: x, g = conv1x1(x) + b and de = dL/dE as rows [batch,S,ld]; xT, deT transposed [batch,C,S] with the keys of

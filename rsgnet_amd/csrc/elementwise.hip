@@ -223,6 +223,70 @@ extern "C" int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t plan
     return 0;
 }
 
+// ---- backward of the above (training: pose_rsgnet.py:1009-1013 under autograd) -------------------------------------------
+// din[pl,y,x] = sum over the output pixels that read (y,x) of their bilinear weight * g, g = dout (* p (1 - p) behind the
+// sigmoid, p = the forward's output).  Gather form, fixed order: one thread per INPUT pixel walks the <= 6 x 6 output pixels
+// whose source window can touch it and recomputes their weights with the forward's own float expressions.
+__global__ void __launch_bounds__(256) bilinear2x_backward_kernel(const float* __restrict__ dout, const float* __restrict__ prob,
+                                                                 float* __restrict__ din, int h, int w, long total) {
+    const int ow = 2 * w, oh = 2 * h;
+    const float ry = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
+    const float rx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+        const unsigned t = i / (unsigned)w;
+        const int x = (int)(i - t * w);
+        const unsigned pl = t / (unsigned)h;
+        const int y = (int)(t - pl * h);
+        // output rows / columns whose floor(source) is y-1 or y (x-1 or x): source = r * o, r < 1/2
+        const int oy_lo = ry > 0.f ? max((int)floorf((float)(y - 1) / ry), 0) : 0;
+        const int oy_hi = ry > 0.f ? min((int)ceilf((float)(y + 1) / ry), oh - 1) : oh - 1;
+        const int ox_lo = rx > 0.f ? max((int)floorf((float)(x - 1) / rx), 0) : 0;
+        const int ox_hi = rx > 0.f ? min((int)ceilf((float)(x + 1) / rx), ow - 1) : ow - 1;
+        const float* gp = dout + (size_t)pl * oh * ow;
+        const float* pp = prob ? prob + (size_t)pl * oh * ow : nullptr;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            const float sy = ry * oy;
+            int y0 = (int)sy;
+            if (y0 > h - 1) y0 = h - 1;
+            const int y1 = y0 < h - 1 ? y0 + 1 : y0;
+            const float wy = sy - (float)y0;
+            const float cy = (y0 == y ? 1.f - wy : 0.f) + (y1 == y ? wy : 0.f);
+            if (cy == 0.f) continue;
+            float row = 0.f;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const float sx = rx * ox;
+                int xa = (int)sx;
+                if (xa > w - 1) xa = w - 1;
+                const int xb = xa < w - 1 ? xa + 1 : xa;
+                const float wx = sx - (float)xa;
+                const float cx = (xa == x ? 1.f - wx : 0.f) + (xb == x ? wx : 0.f);
+                if (cx == 0.f) continue;
+                float g = gp[(size_t)oy * ow + ox];
+                if (pp) {
+                    const float p = pp[(size_t)oy * ow + ox];
+                    g *= p * (1.f - p);
+                }
+                row += cx * g;
+            }
+            acc += cy * row;
+        }
+        din[i] = acc;
+    }
+}
+
+extern "C" int rsg_bilinear2x_backward_nchw_f32(const float* dout, const float* prob, float* din, int32_t planes, int32_t h,
+                                                int32_t w, void* stream) {
+    if (!dout || !din || planes < 1 || h < 1 || w < 2 || (w % 2)) RSG_FAIL("bilinear2x_backward: bad arguments");
+    const long total = (long)planes * h * w;
+    if (total * 4 >= (1L << 31)) RSG_FAIL("bilinear2x_backward: too many elements for 32-bit indexing");
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    RSG_LAUNCH(bilinear2x_backward_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dout, prob, din, h, w, total);
+    RSG_CHECK_LAUNCH("bilinear2x_backward");
+    return 0;
+}
+
 // ---- flip-test merge (lib/core/function.py:400-427, lib/utils/transforms.py:23-37) ---------------------
 // out = 0.5 * (h + shift(flip_back(hf))): flip_back reverses W and swaps the left/right joint channels,
 // SHIFT_HEATMAP moves the flipped map one pixel to the right (column 0 keeps its value).  The reference

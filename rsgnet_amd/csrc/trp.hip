@@ -578,3 +578,150 @@ extern "C" int rsg_trp_tail_in16(const void* e16, int32_t e_ld, const float* w, 
     if (e_ld < 8) RSG_FAIL("trp_tail_in16: e_ld=%d", e_ld);
     return trp_tail_impl(e16, e_ld, w, bias, gn_gamma, gn_beta, out, out_ld, batch, S, C, dtype, workspace, stream);
 }
+
+// ---- backward of W (training; autograd of association.py:298-300) ------------------------------------------------------
+// out = gamma * yhat + beta, yhat = (y - mean_g) * rstd_g over the S x C/8 values of a crop's channel group, y = W e + b.
+//   dgamma_c = sum dout * yhat, dbeta_c = sum dout;  dyhat = dout * gamma;
+//   dy = rstd_g * (dyhat - mean_g(dyhat) - yhat * mean_g(dyhat * yhat));  de = W^T dy  (dW = dy^T e and db = sum dy are two
+//   small GEMM-shaped sums over the B*S rows, left to the caller's BLAS).
+// Launch 1: per workgroup of 256 positions the column sums of [dout*yhat | dout | per-group dyhat, dyhat*yhat] through an LDS
+// tile (fixed order).  Launch 2: merges a crop's group sums over its workgroups (fixed order), writes dy and de.
+// y and the forward's (mean, M2) partials are read from the forward's workspace (rsg_trp_tail keeps them there).
+template <int C>
+__device__ __forceinline__ void gn_group_stats(const float* part, int b, int nb, float* mean_s, float* rstd_s) {
+    constexpr int G = 8, CG = C / G;
+    if (threadIdx.x < G) {
+        const int g = threadIdx.x;
+        const float* pi = part + ((size_t)b * nb * G + g) * 2;
+        const float nk = 256.f * CG;
+        float mean = 0.f;
+        for (int k = 0; k < nb; ++k) mean += pi[(size_t)k * G * 2];
+        mean /= (float)nb;
+        float m2 = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            const float d = pi[(size_t)k * G * 2] - mean;
+            m2 += pi[(size_t)k * G * 2 + 1] + nk * d * d;
+        }
+        mean_s[g] = mean;
+        rstd_s[g] = rsqrtf(m2 / (nk * (float)nb) + 1e-5f);           // the expressions of trp_gn_apply_kernel
+    }
+}
+
+template <class DT, int C>
+__global__ void __launch_bounds__(256) trp_tail_bwd_sums_kernel(const char* __restrict__ dout, int ld, const float* __restrict__ y,
+                                                               const float* __restrict__ part, const float* __restrict__ gamma,
+                                                               float* __restrict__ pc, float* __restrict__ pg, int S) {
+    constexpr int G = 8, CG = C / G, NC = 2 * C + 2 * G, PITCH = NC + 1;
+    extern __shared__ float tile[];                                   // [256][PITCH]
+    __shared__ float mean_s[G], rstd_s[G];
+    const int b = blockIdx.y, nb = gridDim.x;
+    gn_group_stats<C>(part, b, nb, mean_s, rstd_s);
+    __syncthreads();
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const float* yr = y + ((size_t)b * S + s) * C;
+    const char* dr = dout + ((size_t)b * S + s) * ld * 2;
+    float* tr = tile + threadIdx.x * PITCH;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const int ch = g * CG + c;
+            const float yh = (yr[ch] - mean_s[g]) * rstd_s[g];
+            const float d = (float)reinterpret_cast<const typename DT::elem*>(dr)[ch];
+            tr[ch] = d * yh;
+            tr[C + ch] = d;
+            const float dyh = d * gamma[ch];
+            a1 += dyh;
+            a2 += dyh * yh;
+        }
+        tr[2 * C + 2 * g] = a1;
+        tr[2 * C + 2 * g + 1] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x < NC) {
+        float acc = 0.f;
+        for (int r = 0; r < 256; ++r) acc += tile[r * PITCH + threadIdx.x];
+        const size_t blk = (size_t)b * nb + blockIdx.x;
+        if (threadIdx.x < 2 * C) pc[blk * 2 * C + threadIdx.x] = acc;
+        else pg[blk * 2 * G + (threadIdx.x - 2 * C)] = acc;
+    }
+}
+
+template <class DT, int C>
+__global__ void __launch_bounds__(256) trp_tail_bwd_apply_kernel(const char* __restrict__ dout, int ld, const float* __restrict__ y,
+                                                                const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                const float* __restrict__ w, const float* __restrict__ pg,
+                                                                float* __restrict__ dy, float* __restrict__ de, int S) {
+    constexpr int G = 8, CG = C / G;
+    __shared__ float ws[C * C];
+    __shared__ float mean_s[G], rstd_s[G], m1_s[G], m2_s[G];
+    const int b = blockIdx.y, nb = gridDim.x;
+    for (int i = threadIdx.x; i < C * C; i += 256) ws[i] = w[i];
+    gn_group_stats<C>(part, b, nb, mean_s, rstd_s);
+    if (threadIdx.x < G) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int k = 0; k < nb; ++k) {
+            a1 += pg[((size_t)b * nb + k) * 2 * G + 2 * threadIdx.x];
+            a2 += pg[((size_t)b * nb + k) * 2 * G + 2 * threadIdx.x + 1];
+        }
+        const float inv_n = 1.f / ((float)S * CG);
+        m1_s[threadIdx.x] = a1 * inv_n;
+        m2_s[threadIdx.x] = a2 * inv_n;
+    }
+    __syncthreads();
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)b * S + s) * C;
+    const char* dr = dout + ((size_t)b * S + s) * ld * 2;
+    float dyv[C], dev[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        const int g = ch / CG;
+        const float yh = (y[row + ch] - mean_s[g]) * rstd_s[g];
+        const float dyh = (float)reinterpret_cast<const typename DT::elem*>(dr)[ch] * gamma[ch];
+        dyv[ch] = rstd_s[g] * (dyh - m1_s[g] - yh * m2_s[g]);
+        dev[ch] = 0.f;
+    }
+#pragma unroll
+    for (int co = 0; co < C; ++co)
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) dev[ci] = fmaf(ws[co * C + ci], dyv[co], dev[ci]);
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+        *reinterpret_cast<float4*>(dy + row + 4 * k) = make_float4(dyv[4 * k], dyv[4 * k + 1], dyv[4 * k + 2], dyv[4 * k + 3]);
+        *reinterpret_cast<float4*>(de + row + 4 * k) = make_float4(dev[4 * k], dev[4 * k + 1], dev[4 * k + 2], dev[4 * k + 3]);
+    }
+}
+
+extern "C" size_t rsg_trp_tail_backward_partial_floats(int32_t batch, int32_t S, int32_t C) {
+    return (size_t)batch * (S / 256) * (2 * C + 16);
+}
+
+extern "C" int rsg_trp_tail_backward(const void* dout, int32_t ld, const void* fwd_workspace, const float* w, const float* gn_gamma,
+                                     float* dy, float* de, float* partials, int32_t batch, int32_t S, int32_t C, int32_t dtype,
+                                     void* stream) {
+    if (!dout || !fwd_workspace || !w || !gn_gamma || !dy || !de || !partials) RSG_FAIL("trp_tail_backward: null pointer");
+    if (C != 32) RSG_FAIL("trp_tail_backward: C=%d (the training head is built for 32 channels)", C);
+    if (S % 256 || S < 256 || batch < 1) RSG_FAIL("trp_tail_backward: S=%d must be a multiple of 256", S);
+    if (ld < C || ld % 8 || ((uintptr_t)dout & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)de & 15)) RSG_FAIL("trp_tail_backward: ld=%d / alignment", ld);
+    const float* y = (const float*)fwd_workspace;
+    const float* part = y + (size_t)batch * S * C;
+    float* pc = partials;                                               // [batch][S/256][2C]: sums of dout*yhat, then of dout
+    float* pg = partials + (size_t)batch * (S / 256) * 2 * C;           // [batch][S/256][8][2]
+    dim3 grid(S / 256, batch);
+    const int lds = 256 * (2 * C + 16 + 1) * (int)sizeof(float);
+    const void* sums_fn = dtype == RSG_BF16 ? (const void*)trp_tail_bwd_sums_kernel<BF16, 32> : (const void*)trp_tail_bwd_sums_kernel<F16, 32>;
+    if (hipFuncSetAttribute(sums_fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        RSG_FAIL("trp_tail_backward: cannot reserve %d B of LDS", lds);
+    if (dtype == RSG_BF16) {
+        RSG_LAUNCH((trp_tail_bwd_sums_kernel<BF16, 32>), grid, dim3(256), lds, (hipStream_t)stream, (const char*)dout, ld, y, part, gn_gamma, pc, pg, S);
+        RSG_CHECK_LAUNCH("trp_tail_backward(sums)");
+        RSG_LAUNCH((trp_tail_bwd_apply_kernel<BF16, 32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dout, ld, y, part, gn_gamma, w, (const float*)pg, dy, de, S);
+    } else {
+        RSG_LAUNCH((trp_tail_bwd_sums_kernel<F16, 32>), grid, dim3(256), lds, (hipStream_t)stream, (const char*)dout, ld, y, part, gn_gamma, pc, pg, S);
+        RSG_CHECK_LAUNCH("trp_tail_backward(sums)");
+        RSG_LAUNCH((trp_tail_bwd_apply_kernel<F16, 32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dout, ld, y, part, gn_gamma, w, (const float*)pg, dy, de, S);
+    }
+    RSG_CHECK_LAUNCH("trp_tail_backward(apply)");
+    return 0;
+}

@@ -116,6 +116,9 @@ SYMBOLS = {
     "rsg_conv_fuse_group_run": (C.c_int, [_vp, _i, _i, _i, _vp]),
     "rsg_nchw_f32_to_nhwc16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsg_nchw_f32_to_s2d_nhwc16": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsg_bilinear2x_backward_nchw_f32": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "rsg_trp_tail_backward_partial_floats": (C.c_size_t, [_i, _i, _i]),
+    "rsg_trp_tail_backward": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_backward": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_maxpool2x2_nhwc16": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "rsg_f32_rows_to_nhwc16": (C.c_int, [_vp, _vp, _i, C.c_int64, _i, _i, _vp]),

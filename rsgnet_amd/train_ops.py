@@ -8,6 +8,10 @@ ones the backbone's training plan launches:
   ConvBnRelu   nn.Conv2d(bias=False) -> nn.BatchNorm2d (training mode: batch statistics, running statistics updated with
                momentum 0.1) -> [ReLU]      rsg_conv_igemm, rsg_bn_stats/apply; backward rsg_bn_backward, rsg_conv_wgrad
                (MFMA weight gradient) and the data gradient as rsg_conv_igemm over the transposed, flipped pack
+  GroupNormTail  W of the TRP (association.py:298-300): conv1x1 + bias -> GroupNorm(8, C) on the fp32 relation output E;
+               rsg_trp_tail forward, rsg_trp_tail_backward (dy, dE, the per-workgroup sums of dgamma / dbeta)
+  Bilinear2x   F.interpolate(scale_factor=2, 'bilinear', align_corners=True) [+ sigmoid] on fp32 NCHW maps
+               (pose_rsgnet.py:1009-1013): rsg_bilinear2x_nchw_f32 / rsg_bilinear2x_backward_nchw_f32
   Conv1x1Out   the 1x1 classifier convs (bias or not) writing fp32 NCHW maps (multi_final_layer, final_layer, the limb
                classifier whose weight is KTMachine's output)
 
@@ -264,6 +268,66 @@ def conv1x1_out(owner: nn.Module, key: str, x16: torch.Tensor, w: torch.Tensor, 
     J, I = int(w.shape[0]), int(w.shape[1])
     st = conv_state(owner, key, J, I, 1, x16.device)
     return Conv1x1Out.apply(x16, w.reshape(J, I, 1, 1), bias, st)
+
+
+class GroupNormTail(torch.autograd.Function):
+    """out16 [B,S,C] bf16 = GroupNorm(8, C)(e @ w^T + bias) from the TRP's fp32 rows e [B,S,C]."""
+
+    @staticmethod
+    def forward(ctx, e, w, bias, gamma, beta):
+        _need_gpu(e, "GroupNormTail")
+        lib = hip.lib()
+        b, s, c = e.shape
+        e32 = e.detach().float().contiguous()
+        w32 = w.detach().reshape(c, c).float().contiguous()
+        b32, g32, be32 = (t.detach().float().contiguous() for t in (bias, gamma, beta))
+        ws = torch.empty(lib.rsg_trp_tail_workspace_bytes(b, s, c) // 4, dtype=torch.float32, device=e.device)
+        out = torch.empty(b, s, c, dtype=torch.bfloat16, device=e.device)
+        hip.check(lib.rsg_trp_tail(e32.data_ptr(), w32.data_ptr(), b32.data_ptr(), g32.data_ptr(), be32.data_ptr(), out.data_ptr(), c,
+                                   b, s, c, BF16, ws.data_ptr(), _stream(e)), "trp_tail")
+        ctx.save_for_backward(e32, w32, g32, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = hip.lib()
+        e32, w32, g32, ws = ctx.saved_tensors
+        b, s, c = e32.shape
+        dout = dout.to(torch.bfloat16).contiguous()
+        dy = torch.empty_like(e32)
+        de = torch.empty_like(e32)
+        part = torch.empty(lib.rsg_trp_tail_backward_partial_floats(b, s, c), dtype=torch.float32, device=e32.device)
+        hip.check(lib.rsg_trp_tail_backward(dout.data_ptr(), c, ws.data_ptr(), w32.data_ptr(), g32.data_ptr(), dy.data_ptr(),
+                                            de.data_ptr(), part.data_ptr(), b, s, c, BF16, _stream(e32)), "trp_tail_backward")
+        pc = part[:b * (s // 256) * 2 * c].reshape(-1, 2, c).sum(0)        # [2,C]: dgamma, dbeta
+        dy2 = dy.reshape(-1, c)
+        dw = (dy2.t() @ e32.reshape(-1, c)).reshape(c, c, 1, 1)
+        return de, dw, dy2.sum(0), pc[0], pc[1]
+
+
+class Bilinear2x(torch.autograd.Function):
+    """fp32 NCHW [B,C,H,W] -> [B,C,2H,2W], bilinear with align_corners=True, optionally followed by a sigmoid."""
+
+    @staticmethod
+    def forward(ctx, x, sigmoid: bool):
+        _need_gpu(x, "Bilinear2x")
+        b, c, h, w = x.shape
+        x32 = x.detach().float().contiguous()
+        out = torch.empty(b, c, 2 * h, 2 * w, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().rsg_bilinear2x_nchw_f32(x32.data_ptr(), out.data_ptr(), b * c, h, w, int(sigmoid), _stream(x)), "bilinear2x")
+        ctx.sigmoid = sigmoid
+        ctx.save_for_backward(out if sigmoid else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        prob, = ctx.saved_tensors
+        b, c, oh, ow = dout.shape
+        dout = dout.float().contiguous()
+        din = torch.empty(b, c, oh // 2, ow // 2, dtype=torch.float32, device=dout.device)
+        hip.check(hip.lib().rsg_bilinear2x_backward_nchw_f32(dout.data_ptr(), prob.data_ptr() if prob is not None else None,
+                                                             din.data_ptr(), b * c, oh // 2, ow // 2, _stream(dout)), "bilinear2x_backward")
+        return din, None
 
 
 def nchw_to_nhwc16(t: torch.Tensor, c_pad: Optional[int] = None) -> torch.Tensor:

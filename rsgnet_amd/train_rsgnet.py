@@ -15,8 +15,10 @@
     PyTorch-ROCm: type_fc (Linear -> BatchNorm1d over the J rows -> ReLU) folded with type_conv's weight into a 3x3 conv
     J -> C0, W'[o,j] = sum_c type_conv.W[o,c] * Tm[j,c] (the [B,600,H,W] map of pose_rsgnet.py:974 is never built);
     KTMachine (the limb classifier's weight from final_layer's); the location clue loc_conv(loc_features);
-  * INTERIM, still PyTorch-ROCm operators: W's 1x1 conv + GroupNorm behind the TRP, the up-sampling
-    ConvTranspose2d + BatchNorm + ReLU, the two x2 bilinear up-samplings and the sigmoid.
+  * W behind the TRP (1x1 conv + bias -> GroupNorm, association.py:298-300: `GroupNormTail`) and the two x2 bilinear
+    up-samplings with the limb maps' sigmoid (`Bilinear2x`) are autograd nodes on the library's kernels too;
+  * INTERIM, still a PyTorch-ROCm operator: the up-sampling ConvTranspose2d + BatchNorm + ReLU of the keypoint branch
+    (and the sub-sampled TRP variant's).
 """
 from __future__ import annotations
 
@@ -135,7 +137,7 @@ def relation_head_forward(rh, x: torch.Tensor):
 
 def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Tensor]):
     """pose_rsgnet.py:959-1021 from the backbone's output map `feat16` [B,H/4,W/4,C0] (NHWC bf16, requires grad)."""
-    from .train_ops import conv1x1_out, conv_bn_relu, nchw_to_nhwc16, nhwc16_to_nchw
+    from .train_ops import Bilinear2x, GroupNormTail, conv1x1_out, conv_bn_relu, nchw_to_nhwc16, nhwc16_to_nchw
     m = model
     B, H, W, c0 = feat16.shape
     taps = getattr(m, "_train_taps", None)              # tests: the units' outputs by BatchNorm name (ReLU decisions)
@@ -158,20 +160,25 @@ def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Te
             x = nchw_to_nhwc16(F.max_pool2d(nhwc16_to_nchw(f), 2))
         b, hr, wr, _ = x.shape
         e, rel = TrpRelation.apply(x.reshape(b, hr * wr, c0), rh.g.weight, rh.g.bias, relation_target)
-        rel_feats = rh.W(e.reshape(b, hr, wr, c0).permute(0, 3, 1, 2))
+        if not getattr(rh, "sub_sample", False) and (hr * wr) % 256 == 0:       # W = conv1x1 + bias -> GroupNorm(8, C)
+            rel16 = GroupNormTail.apply(e, rh.W[0].weight, rh.W[0].bias, rh.W[1].weight, rh.W[1].bias).reshape(b, hr, wr, c0)
+        else:                                                             # the sub-sampled variant's up-sampler: torch
+            rel16 = nchw_to_nhwc16(rh.W(e.reshape(b, hr, wr, c0).permute(0, 3, 1, 2)))
     else:
         rel_feats, score = relation_head_forward(rh, nhwc16_to_nchw(f))
-    k = conv_bn_relu(m, "kpt_net", torch.cat((nchw_to_nhwc16(rel_feats), f), dim=3), m.kpt_net[0].weight, m.kpt_net[1])   # :991-992
+        rel16 = nchw_to_nhwc16(rel_feats)
+    k = conv_bn_relu(m, "kpt_net", torch.cat((rel16, f), dim=3), m.kpt_net[0].weight, m.kpt_net[1])          # :991-992
     if m.scale_factor > 1:
         k = nchw_to_nhwc16(m.predict_convtranspose(nhwc16_to_nchw(k)))
     k = conv_bn_relu(m, "predict_net", k, m.predict_net[0].weight, m.predict_net[1])
     kpt = conv1x1_out(m, "final_layer", k, m.final_layer.weight, m.final_layer.bias)                           # :999-1000
     lm = conv_bn_relu(m, "limbs_net", f, m.limbs_net[0].weight, m.limbs_net[1])
     limbs = conv1x1_out(m, "limbs", lm, kt_machine_forward(m.kt_machine, m.final_layer.weight), None)         # :1003-1005
-    if m.scale_factor > 1:
-        multi = F.interpolate(multi, scale_factor=2, mode="bilinear", align_corners=True)
-        limbs = F.interpolate(limbs, scale_factor=2, mode="bilinear", align_corners=True)
-    limbs = torch.sigmoid(limbs)                                          # :1013
+    if m.scale_factor > 1:                                                # :1008-1013
+        multi = Bilinear2x.apply(multi, False)
+        limbs = Bilinear2x.apply(limbs, True)
+    else:
+        limbs = torch.sigmoid(limbs)
     if hip_trp:
         return multi, kpt, limbs, rel
     rel = score

@@ -87,3 +87,53 @@ def test_conv1x1_out_matches_autograd(J, bias):
         errs["db"] = _rel(got[2], want[2])
     print(f"  conv1x1_out 32->{J}:", {n: f"{v:.2e}" for n, v in errs.items()})
     assert eo < 1e-5 and errs["dx"] < 1e-2 and errs["dw"] < 1e-4 and errs.get("db", 0) < 1e-5, errs
+
+
+@pytest.mark.parametrize("sigmoid", [False, True])
+@pytest.mark.parametrize("shape", [(2, 17, 16, 24), (1, 3, 5, 6), (2, 18, 64, 48)])
+def test_bilinear2x_backward_matches_autograd(shape, sigmoid):
+    """rsg_bilinear2x_backward_nchw_f32 (gather form) against torch autograd of F.interpolate(x2, bilinear,
+    align_corners=True) [+ sigmoid] in fp64 (pose_rsgnet.py:1009-1013)."""
+    from rsgnet_amd.train_ops import Bilinear2x
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    dout = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], generator=g)
+    X = x.double().requires_grad_(True)
+    O = F.interpolate(X, scale_factor=2, mode="bilinear", align_corners=True)
+    if sigmoid:
+        O = torch.sigmoid(O)
+    want, = torch.autograd.grad((O * dout.double()).sum(), [X])
+    xd = x.cuda().requires_grad_(True)
+    out = Bilinear2x.apply(xd, sigmoid)
+    got, = torch.autograd.grad((out * dout.cuda()).sum(), [xd])
+    torch.cuda.synchronize()
+    assert float((out.detach().cpu().double() - O.detach()).abs().max()) < 3e-5          # fp32 source coordinates against fp64 ones
+    e = float((got.cpu().double() - want).abs().max()) / float(want.abs().max())
+    print(f"  bilinear2x backward {shape} sigmoid={sigmoid}: {e:.2e} of the largest gradient")
+    assert e < 5e-6
+
+
+@pytest.mark.parametrize("B,S", [(2, 256), (3, 768)])
+def test_groupnorm_tail_matches_autograd(B, S):
+    """GroupNormTail (rsg_trp_tail forward, rsg_trp_tail_backward) against torch autograd in fp64 of
+    GroupNorm(8, 32)(conv1x1(e) + bias) (association.py:298-300): output, dE, dW, dbias, dgamma, dbeta."""
+    from rsgnet_amd.train_ops import GroupNormTail
+    Cc = 32
+    g = torch.Generator().manual_seed(B * S)
+    e = torch.randn(B, S, Cc, generator=g) * 3
+    w, bias = torch.randn(Cc, Cc, 1, 1, generator=g) * 0.2, torch.randn(Cc, generator=g) * 0.1
+    gam, bet = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    dout = torch.randn(B, S, Cc, generator=g).to(torch.bfloat16)
+    E, Wt, Bi, Ga, Be = (t.double().requires_grad_(True) for t in (e, w, bias, gam, bet))
+    Y = E @ Wt.reshape(Cc, Cc).t() + Bi
+    O = F.group_norm(Y.permute(0, 2, 1).reshape(B, Cc, S, 1), 8, Ga, Be, 1e-5).reshape(B, Cc, S).permute(0, 2, 1)
+    want = torch.autograd.grad((O * dout.double()).sum(), [E, Wt, Bi, Ga, Be])
+    dev = [t.cuda().requires_grad_(True) for t in (e, w, bias, gam, bet)]
+    out = GroupNormTail.apply(*dev)
+    got = torch.autograd.grad((out.float() * dout.cuda().float()).sum(), dev)
+    torch.cuda.synchronize()
+    eo = float((out.detach().cpu().double() - O.detach()).abs().max()) / float(O.detach().abs().max())
+    errs = {n: _rel(a, b) for n, a, b in zip(("dE", "dW", "dbias", "dgamma", "dbeta"), got, want)}
+    print(f"  groupnorm tail B={B} S={S}: out {eo:.2e}", {n: f"{v:.2e}" for n, v in errs.items()})
+    assert eo < 2 ** -7                                            # one bf16 rounding of the output
+    assert all(v < 1e-4 for v in errs.values()), errs
