@@ -12,6 +12,8 @@ ones the backbone's training plan launches:
                rsg_trp_tail forward, rsg_trp_tail_backward (dy, dE, the per-workgroup sums of dgamma / dbeta)
   Bilinear2x   F.interpolate(scale_factor=2, 'bilinear', align_corners=True) [+ sigmoid] on fp32 NCHW maps
                (pose_rsgnet.py:1009-1013): rsg_bilinear2x_nchw_f32 / rsg_bilinear2x_backward_nchw_f32
+  DeconvBnRelu nn.ConvTranspose2d(4, 2, 1, bias=False) -> BatchNorm2d -> ReLU (the keypoint branch's up-sampler) as four
+               sub-pixel 2x2 convs; backward through the same conv / MFMA weight-gradient kernels
   Conv1x1Out   the 1x1 classifier convs (bias or not) writing fp32 NCHW maps (multi_final_layer, final_layer, the limb
                classifier whose weight is KTMachine's output)
 
@@ -95,6 +97,17 @@ class _ConvState:
             ws = self._wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws
 
+    def wgrad_ws3(self, b: int, h: int, w: int) -> torch.Tensor:
+        """workspace of a 3x3 pad-1 weight gradient over this conv's channels (the deconv phases' route)."""
+        key = (b, h, w, -3)
+        ws = self._wgrad_ws.get(key)
+        if ws is None:
+            need = int(hip.lib().rsg_conv_wgrad_workspace_bytes(b, h, w, self.cin_pad, h, w, self.cout_pad, 3, 3, 1, 1))
+            if not need:
+                raise NotImplementedError(f"3x3 weight gradient {self.cin}->{self.cout}")
+            ws = self._wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
+
     def bn_ws(self) -> torch.Tensor:
         if self._bn_ws is None:
             self._bn_ws = torch.empty(hip.lib().rsg_bn_workspace_bytes(256), dtype=torch.uint8, device=self.device)
@@ -110,20 +123,25 @@ def conv_state(owner: nn.Module, key: str, cout: int, cin: int, k: int, device: 
 
 
 def _conv(st: _ConvState, x16: torch.Tensor, pack: torch.Tensor, in_c: int, out_c: int, bias: torch.Tensor,
-          out16: Optional[torch.Tensor], out_f32: Optional[torch.Tensor], what: str):
-    """stride-1 'same' conv of a dense NHWC bf16 map through rsg_conv_igemm."""
+          out16: Optional[torch.Tensor], out_f32: Optional[torch.Tensor], what: str, pads: Optional[Tuple[int, int]] = None,
+          up: Tuple[int, int, int] = (1, 0, 0), residual: Optional[torch.Tensor] = None):
+    """stride-1 conv of a dense NHWC bf16 map through rsg_conv_igemm: 'same' padding unless `pads` = (pad_y, pad_x) is
+    given (the 2x2 sub-pixel convs of a ConvTranspose2d); up = (factor, y, x) places output pixel (y,x) at
+    (factor*y + up_y, factor*x + up_x) of the physical output map; residual: a 16-bit map added in the epilogue."""
     b, h, w, c = x16.shape
     if c != in_c or x16.dtype != torch.bfloat16 or not x16.is_contiguous():
         raise ValueError(f"{what}: input {tuple(x16.shape)} {x16.dtype}, the conv wants dense bf16 with {in_c} channels")
     d = hip.ConvDesc()
-    pad = (st.k - 1) // 2
+    pad_y, pad_x = pads if pads is not None else ((st.k - 1) // 2, (st.k - 1) // 2)
     d.inp, d.w_packed, d.bias = x16.data_ptr(), pack.data_ptr(), bias.data_ptr()
     d.out16 = out16.data_ptr() if out16 is not None else None
     d.out_nchw_f32 = out_f32.data_ptr() if out_f32 is not None else None
     d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = b, h, w, in_c, in_c
     d.out_h, d.out_w, d.out_c, d.out_ld = h, w, out_c, _round_up(out_c, 32)
-    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = st.k, st.k, 1, pad, pad
-    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = 1, 0, 0, h, w
+    d.kh, d.kw, d.stride, d.pad_y, d.pad_x = st.k, st.k, 1, pad_y, pad_x
+    d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = up[0], up[1], up[2], up[0] * h, up[0] * w
+    if residual is not None:
+        d.residual, d.res_ld = residual.data_ptr(), residual.shape[-1]
     d.relu, d.dtype = 0, BF16
     hip.check(hip.lib().rsg_conv_igemm(C.byref(d), _stream(x16)), what)
 
@@ -140,36 +158,14 @@ class ConvBnRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x16, w, gamma, beta, st: _ConvState, bn: nn.BatchNorm2d, relu: bool):
         _need_gpu(x16, "ConvBnRelu")
-        lib = hip.lib()
         b, h, wd, _ = x16.shape
-        px, O = b * h * wd, st.cout
+        O = st.cout
         if O != st.cout_pad:
             raise NotImplementedError("ConvBnRelu: output channels must be a multiple of 32")
-        if bn.momentum is None or not bn.track_running_stats or not bn.affine:
-            raise NotImplementedError("BatchNorm2d without momentum / running statistics / affine terms")
-        s = _stream(x16)
         st.pack(w)
         y = torch.empty(b, h, wd, O, dtype=torch.bfloat16, device=x16.device)
         _conv(st, x16, st.pack_fwd, st.cin_pad, O, st.zero_bias, y, None, "conv forward")
-        ck = _bn_chunk(O)
-        n = O // ck
-        ys = [y] if n == 1 else [y[..., i * ck:(i + 1) * ck].contiguous() for i in range(n)]
-        mean = torch.empty(O, dtype=torch.float32, device=x16.device)
-        invstd = torch.empty_like(mean)
-        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        zs = []
-        for i, yc in enumerate(ys):
-            lo = i * ck
-            rm, rv = bn.running_mean[lo:lo + ck], bn.running_var[lo:lo + ck]
-            hip.check(lib.rsg_bn_stats(yc.data_ptr(), px, ck, BF16, st.bn_ws().data_ptr(), mean[lo:].data_ptr(), invstd[lo:].data_ptr(),
-                                       rm.data_ptr(), rv.data_ptr(), float(bn.momentum), float(bn.eps), s), "bn_stats")
-            z = torch.empty_like(yc)
-            hip.check(lib.rsg_bn_apply(yc.data_ptr(), mean[lo:].data_ptr(), invstd[lo:].data_ptr(), g32[lo:].data_ptr(),
-                                       b32[lo:].data_ptr(), None, int(relu), z.data_ptr(), px, ck, BF16, s), "bn_apply")
-            zs.append(z)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
-        z = zs[0] if n == 1 else torch.cat(zs, dim=3)
+        z, mean, invstd, g32, ys, ck = _bn_forward(st, y, gamma, beta, bn, relu)
         ctx.st, ctx.relu, ctx.ck = st, relu, ck
         ctx.save_for_backward(x16, z, mean, invstd, g32, *ys)
         return z
@@ -180,23 +176,8 @@ class ConvBnRelu(torch.autograd.Function):
         st, relu, ck = ctx.st, ctx.relu, ctx.ck
         x16, z, mean, invstd, g32, *ys = ctx.saved_tensors
         b, h, wd, _ = x16.shape
-        px, O, n = b * h * wd, st.cout, len(ys)
-        s = _stream(x16)
-        dz = dz.to(torch.bfloat16).contiguous()
-        dgamma = torch.empty(O, dtype=torch.float32, device=x16.device)
-        dbeta = torch.empty_like(dgamma)
-        dys = []
-        for i, yc in enumerate(ys):
-            lo = i * ck
-            dzc = dz if n == 1 else dz[..., lo:lo + ck].contiguous()
-            zc = z if n == 1 else z[..., lo:lo + ck].contiguous()
-            dy = torch.empty_like(yc)
-            hip.check(lib.rsg_bn_backward(dzc.data_ptr(), zc.data_ptr() if relu else None, yc.data_ptr(), mean[lo:].data_ptr(),
-                                          invstd[lo:].data_ptr(), g32[lo:].data_ptr(), dy.data_ptr(), None,
-                                          dgamma[lo:].data_ptr(), dbeta[lo:].data_ptr(), st.bn_ws().data_ptr(), px, ck, BF16, s),
-                      "bn_backward")
-            dys.append(dy)
-        dy = dys[0] if n == 1 else torch.cat(dys, dim=3)
+        O, s = st.cout, _stream(x16)
+        dy, dgamma, dbeta = _bn_backward(st, dz.to(torch.bfloat16).contiguous(), z, ys, mean, invstd, g32, relu, ck)
         dw = torch.empty(O, st.cin, st.k, st.k, dtype=torch.float32, device=x16.device)
         pad = (st.k - 1) // 2
         hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), dy.data_ptr(), dw.data_ptr(), st.wgrad_ws(b, h, wd).data_ptr(), b, h, wd,
@@ -216,6 +197,138 @@ def conv_bn_relu(owner: nn.Module, key: str, x16: torch.Tensor, conv_w: torch.Te
     O, I, k, _ = conv_w.shape
     st = conv_state(owner, key, O, I, k, x16.device)
     return ConvBnRelu.apply(x16, conv_w, bn.weight, bn.bias, st, bn, relu)
+
+
+def _bn_forward(st: _ConvState, y: torch.Tensor, gamma, beta, bn: nn.BatchNorm2d, relu: bool):
+    """Training-mode BatchNorm [+ReLU] of a dense NHWC bf16 map in channel chunks; returns (z, mean, invstd, chunks of y)."""
+    lib = hip.lib()
+    b, h, wd, O = y.shape
+    px, s = b * h * wd, _stream(y)
+    if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+        raise NotImplementedError("BatchNorm2d without momentum / running statistics / affine terms")
+    ck = _bn_chunk(O)
+    n = O // ck
+    ys = [y] if n == 1 else [y[..., i * ck:(i + 1) * ck].contiguous() for i in range(n)]
+    mean = torch.empty(O, dtype=torch.float32, device=y.device)
+    invstd = torch.empty_like(mean)
+    g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    zs = []
+    for i, yc in enumerate(ys):
+        lo = i * ck
+        rm, rv = bn.running_mean[lo:lo + ck], bn.running_var[lo:lo + ck]
+        hip.check(lib.rsg_bn_stats(yc.data_ptr(), px, ck, BF16, st.bn_ws().data_ptr(), mean[lo:].data_ptr(), invstd[lo:].data_ptr(),
+                                   rm.data_ptr(), rv.data_ptr(), float(bn.momentum), float(bn.eps), s), "bn_stats")
+        z = torch.empty_like(yc)
+        hip.check(lib.rsg_bn_apply(yc.data_ptr(), mean[lo:].data_ptr(), invstd[lo:].data_ptr(), g32[lo:].data_ptr(),
+                                   b32[lo:].data_ptr(), None, int(relu), z.data_ptr(), px, ck, BF16, s), "bn_apply")
+        zs.append(z)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return (zs[0] if n == 1 else torch.cat(zs, dim=3)), mean, invstd, g32, ys, ck
+
+
+def _bn_backward(st: _ConvState, dz: torch.Tensor, z: torch.Tensor, ys, mean, invstd, g32, relu: bool, ck: int):
+    """-> (dy [B,H,W,O] bf16, dgamma, dbeta)."""
+    lib = hip.lib()
+    n, O = len(ys), mean.numel()
+    b, h, wd, _ = dz.shape
+    px, s = b * h * wd, _stream(dz)
+    dgamma = torch.empty(O, dtype=torch.float32, device=dz.device)
+    dbeta = torch.empty_like(dgamma)
+    dys = []
+    for i, yc in enumerate(ys):
+        lo = i * ck
+        dzc = dz if n == 1 else dz[..., lo:lo + ck].contiguous()
+        zc = z if n == 1 else z[..., lo:lo + ck].contiguous()
+        dy = torch.empty_like(yc)
+        hip.check(lib.rsg_bn_backward(dzc.data_ptr(), zc.data_ptr() if relu else None, yc.data_ptr(), mean[lo:].data_ptr(),
+                                      invstd[lo:].data_ptr(), g32[lo:].data_ptr(), dy.data_ptr(), None,
+                                      dgamma[lo:].data_ptr(), dbeta[lo:].data_ptr(), st.bn_ws().data_ptr(), px, ck, BF16, s),
+                  "bn_backward")
+        dys.append(dy)
+    return (dys[0] if n == 1 else torch.cat(dys, dim=3)), dgamma, dbeta
+
+
+_DECONV_TAPS = {0: (3, 1), 1: (2, 0)}       # output phase p, tap a of the 2x2 conv -> index into the 4-wide deconv kernel
+_DECONV_PHASE = (1, 0, 1, 0)                # deconv kernel index k -> the output phase that uses it ...
+_DECONV_ROW3 = (2, 1, 1, 0)                 # ... and its row a + p in the 3x3 pad-1 window of that phase's weight gradient
+
+
+def _deconv_index(device):
+    """Index arrays: phase weights [4,O,I,2,2] out of W^T [O,I,4,4]; deconv weight gradient [4,4,...] out of the four 3x3
+    weight gradients [4,O,I,3,3]."""
+    ky = torch.tensor([[_DECONV_TAPS[py][a] for a in (0, 1)] for py in (0, 1) for _ in (0, 1)], device=device)     # [4,2]
+    kx = torch.tensor([[_DECONV_TAPS[px][b] for b in (0, 1)] for _ in (0, 1) for px in (0, 1)], device=device)
+    ph = torch.tensor([[2 * _DECONV_PHASE[y] + _DECONV_PHASE[x] for x in range(4)] for y in range(4)], device=device)
+    ry = torch.tensor([[_DECONV_ROW3[y] for _ in range(4)] for y in range(4)], device=device)
+    rx = torch.tensor([[_DECONV_ROW3[x] for x in range(4)] for _ in range(4)], device=device)
+    return ky[:, :, None].expand(4, 2, 2), kx[:, None, :].expand(4, 2, 2), ph, ry, rx
+
+
+class DeconvBnRelu(torch.autograd.Function):
+    """z = ReLU(BatchNorm_train(ConvTranspose2d(k=4, s=2, p=1, bias=False)(x))) on dense NHWC bf16 maps [B,H,W,C] ->
+    [B,2H,2W,O] (pose_rsgnet.py:741-750, the keypoint branch's up-sampler).  The transposed conv runs as four sub-pixel 2x2
+    convs, out[2y+py, 2x+px] = sum_ab W[i,o,ky(py,a),kx(px,b)] in[y+a-(1-py), x+b-(1-px)], each writing its phase of the
+    output (rsg_conv_igemm with up = 2).  Backward: per phase the data gradient is the 2x2 conv of that phase of dy with the
+    transposed, flipped taps (accumulated through the conv's residual operand), the weight gradient the 3x3 MFMA weight
+    gradient of (x, phase of dy), of which the phase's four taps are kept.  `wt`: the module's weight [I,O,4,4]."""
+
+    @staticmethod
+    def forward(ctx, x16, wt, gamma, beta, states, bn: nn.BatchNorm2d):
+        _need_gpu(x16, "DeconvBnRelu")
+        b, h, wd, cin = x16.shape
+        I, O = int(wt.shape[0]), int(wt.shape[1])
+        if tuple(wt.shape[2:]) != (4, 4) or I != cin or O % 32 or I % 32:
+            raise NotImplementedError(f"DeconvBnRelu: weight {tuple(wt.shape)} on a {cin}-channel map")
+        y = torch.empty(b, 2 * h, 2 * wd, O, dtype=torch.bfloat16, device=x16.device)
+        idx = getattr(states[0], "deconv_index", None)
+        if idx is None:
+            idx = states[0].deconv_index = _deconv_index(x16.device)
+        wph = wt.detach().float().permute(1, 0, 2, 3)[:, :, idx[0], idx[1]].permute(2, 0, 1, 3, 4)      # [4,O,I,2,2]
+        for py in (0, 1):
+            for px in (0, 1):
+                st = states[2 * py + px]
+                st.pack(wph[2 * py + px])
+                _conv(st, x16, st.pack_fwd, I, O, st.zero_bias, y, None, "deconv phase", pads=(1 - py, 1 - px), up=(2, py, px))
+        z, mean, invstd, g32, ys, ck = _bn_forward(states[0], y, gamma, beta, bn, True)
+        ctx.states, ctx.ck, ctx.io = states, ck, (I, O)
+        ctx.save_for_backward(x16, z, mean, invstd, g32, *ys)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = hip.lib()
+        states, ck, (I, O) = ctx.states, ctx.ck, ctx.io
+        x16, z, mean, invstd, g32, *ys = ctx.saved_tensors
+        b, h, wd, _ = x16.shape
+        s = _stream(x16)
+        dy, dgamma, dbeta = _bn_backward(states[0], dz.to(torch.bfloat16).contiguous(), z, ys, mean, invstd, g32, True, ck)
+        dw3 = torch.empty(4, O, I, 3, 3, dtype=torch.float32, device=x16.device)
+        dx = torch.empty_like(x16) if ctx.needs_input_grad[0] else None
+        first = True
+        for py in (0, 1):
+            for px in (0, 1):
+                st = states[2 * py + px]
+                dph = dy[:, py::2, px::2, :].contiguous()
+                # weight gradient: the 2x2 taps sit at rows a - pad_y + 1 of a 3x3 pad-1 window
+                hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), dph.data_ptr(), dw3[2 * py + px].data_ptr(), st.wgrad_ws3(b, h, wd).data_ptr(),
+                                             b, h, wd, I, I, h, wd, O, O, 3, 3, 1, 1, BF16, s), "deconv wgrad")
+                if dx is not None:
+                    _conv(st, dph, st.pack_bwd, O, I, st.zero_bias, dx, None, "deconv data gradient", pads=(py, px),
+                          residual=None if first else dx)
+                    first = False
+        _, _, ph, ry, rx = states[0].deconv_index
+        dwt = dw3[ph, :, :, ry, rx].permute(3, 2, 0, 1).contiguous()      # [4,4,O,I] -> [I,O,4,4]
+        return dx, dwt, dgamma, dbeta, None, None
+
+
+def deconv_bn_relu(owner: nn.Module, key: str, x16: torch.Tensor, deconv: nn.ConvTranspose2d, bn: nn.BatchNorm2d):
+    if deconv.kernel_size != (4, 4) or deconv.stride != (2, 2) or deconv.padding != (1, 1) or deconv.output_padding != (0, 0) \
+            or deconv.bias is not None:
+        raise NotImplementedError("only ConvTranspose2d(k=4, s=2, p=1, bias=False) is built (every shipped config)")
+    I, O = int(deconv.weight.shape[0]), int(deconv.weight.shape[1])
+    states = [conv_state(owner, f"{key}.phase{q}", O, I, 2, x16.device) for q in range(4)]
+    return DeconvBnRelu.apply(x16, deconv.weight, bn.weight, bn.bias, states, bn)
 
 
 class Conv1x1Out(torch.autograd.Function):
@@ -270,6 +383,17 @@ def conv1x1_out(owner: nn.Module, key: str, x16: torch.Tensor, w: torch.Tensor, 
     return Conv1x1Out.apply(x16, w.reshape(J, I, 1, 1), bias, st)
 
 
+def rows_gram(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a^T b for two tall fp32 row matrices [N,ca], [N,cb] (N ~ 1e5, c = 32): as ONE GEMM this shape runs on a single
+    workgroup's worth of tiles (283 us measured); as a batched product over row chunks with a fixed-order sum of the chunk
+    results it takes a few microseconds."""
+    n = a.shape[0]
+    ch = 1024
+    while n % ch:
+        ch //= 2
+    return torch.bmm(a.reshape(n // ch, ch, -1).transpose(1, 2), b.reshape(n // ch, ch, -1)).sum(0)
+
+
 class GroupNormTail(torch.autograd.Function):
     """out16 [B,S,C] bf16 = GroupNorm(8, C)(e @ w^T + bias) from the TRP's fp32 rows e [B,S,C]."""
 
@@ -301,7 +425,7 @@ class GroupNormTail(torch.autograd.Function):
                                             de.data_ptr(), part.data_ptr(), b, s, c, BF16, _stream(e32)), "trp_tail_backward")
         pc = part[:b * (s // 256) * 2 * c].reshape(-1, 2, c).sum(0)        # [2,C]: dgamma, dbeta
         dy2 = dy.reshape(-1, c)
-        dw = (dy2.t() @ e32.reshape(-1, c)).reshape(c, c, 1, 1)
+        dw = rows_gram(dy2, e32.reshape(-1, c)).reshape(c, c, 1, 1)
         return de, dw, dy2.sum(0), pc[0], pc[1]
 
 

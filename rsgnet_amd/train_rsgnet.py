@@ -17,8 +17,9 @@
     KTMachine (the limb classifier's weight from final_layer's); the location clue loc_conv(loc_features);
   * W behind the TRP (1x1 conv + bias -> GroupNorm, association.py:298-300: `GroupNormTail`) and the two x2 bilinear
     up-samplings with the limb maps' sigmoid (`Bilinear2x`) are autograd nodes on the library's kernels too;
-  * INTERIM, still a PyTorch-ROCm operator: the up-sampling ConvTranspose2d + BatchNorm + ReLU of the keypoint branch
-    (and the sub-sampled TRP variant's).
+  * the keypoint branch's up-sampler (ConvTranspose2d + BatchNorm + ReLU) runs as four sub-pixel 2x2 convs with their
+    backward on the same kernels (`DeconvBnRelu`); only the sub-sampled TRP variant's up-sampler
+    (RELATION_SUB_SAMPLE, one shipped CrowdPose config) is still a PyTorch-ROCm operator in training.
 """
 from __future__ import annotations
 
@@ -102,7 +103,8 @@ class TrpRelation(torch.autograd.Function):
                                        dx.data_ptr(), dg.data_ptr(), b, s, c, hip.RSG_BF16, st), "trp_backward")
         dg2 = dg.reshape(-1, c)
         dx = dx + (dg2 @ w32).reshape(b, s, c)                               # g = x Wg^T + bg
-        d_w = (dg2.t() @ xf.reshape(-1, c)).reshape(c, c, 1, 1)
+        from .train_ops import rows_gram
+        d_w = rows_gram(dg2, xf.reshape(-1, c)).reshape(c, c, 1, 1)
         d_b = dg2.sum(0)
         return dx.to(ctx.in_dtype), d_w, d_b, None
 
@@ -137,13 +139,18 @@ def relation_head_forward(rh, x: torch.Tensor):
 
 def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Tensor]):
     """pose_rsgnet.py:959-1021 from the backbone's output map `feat16` [B,H/4,W/4,C0] (NHWC bf16, requires grad)."""
-    from .train_ops import Bilinear2x, GroupNormTail, conv1x1_out, conv_bn_relu, nchw_to_nhwc16, nhwc16_to_nchw
+    from .train_ops import Bilinear2x, GroupNormTail, conv1x1_out, conv_bn_relu, deconv_bn_relu, nchw_to_nhwc16, nhwc16_to_nchw
     m = model
     B, H, W, c0 = feat16.shape
     taps = getattr(m, "_train_taps", None)              # tests: the units' outputs by BatchNorm name (ReLU decisions)
     if taps is not None:
         def conv_bn_relu(owner, key, x16, w, bn, _f=conv_bn_relu):
             z = _f(owner, key, x16, w, bn)
+            taps[key + ".1"] = z.detach()
+            return z
+
+        def deconv_bn_relu(owner, key, x16, dc, bn, _f=deconv_bn_relu):
+            z = _f(owner, key, x16, dc, bn)
             taps[key + ".1"] = z.detach()
             return z
     multi = conv1x1_out(m, "multi_final_layer", feat16, m.multi_final_layer.weight, m.multi_final_layer.bias)   # :961
@@ -169,7 +176,7 @@ def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Te
         rel16 = nchw_to_nhwc16(rel_feats)
     k = conv_bn_relu(m, "kpt_net", torch.cat((rel16, f), dim=3), m.kpt_net[0].weight, m.kpt_net[1])          # :991-992
     if m.scale_factor > 1:
-        k = nchw_to_nhwc16(m.predict_convtranspose(nhwc16_to_nchw(k)))
+        k = deconv_bn_relu(m, "predict_convtranspose", k, m.predict_convtranspose[0], m.predict_convtranspose[1])
     k = conv_bn_relu(m, "predict_net", k, m.predict_net[0].weight, m.predict_net[1])
     kpt = conv1x1_out(m, "final_layer", k, m.final_layer.weight, m.final_layer.bias)                           # :999-1000
     lm = conv_bn_relu(m, "limbs_net", f, m.limbs_net[0].weight, m.limbs_net[1])

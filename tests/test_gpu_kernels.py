@@ -1005,11 +1005,14 @@ def test_trp_relation_function_matches_materialised_autograd():
     p = torch.rand(B, S, generator=g)
     de = torch.randn(B, Cc, H, W, generator=g) * 0.01
     dm = torch.tensor([30.0, 60.0])
-    xd = x.to(DEV).requires_grad_(True)
+    xd = x.permute(0, 2, 3, 1).reshape(B, S, Cc).contiguous().to(DEV).requires_grad_(True)     # rows [B,S,C], as the head hands them over
     wd, bd = wg.to(DEV).requires_grad_(True), bg.to(DEV).requires_grad_(True)
     e, mse = TrpRelation.apply(xd, wd, bd, p.to(DEV))
-    loss = (e * de.to(DEV)).sum() + (mse * dm.to(DEV)).sum()
+    de_rows = de.permute(0, 2, 3, 1).reshape(B, S, Cc).to(DEV)
+    loss = (e * de_rows).sum() + (mse * dm.to(DEV)).sum()
     gx, gw, gb = torch.autograd.grad(loss, [xd, wd, bd])
+    e = e.reshape(B, H, W, Cc).permute(0, 3, 1, 2)
+    gx = gx.reshape(B, H, W, Cc).permute(0, 3, 1, 2)
     X = x.double().requires_grad_(True)
     Wg, Bg = wg.double().requires_grad_(True), bg.double().requires_grad_(True)
     xf = X.reshape(B, Cc, S)

@@ -137,3 +137,39 @@ def test_groupnorm_tail_matches_autograd(B, S):
     print(f"  groupnorm tail B={B} S={S}: out {eo:.2e}", {n: f"{v:.2e}" for n, v in errs.items()})
     assert eo < 2 ** -7                                            # one bf16 rounding of the output
     assert all(v < 1e-4 for v in errs.values()), errs
+
+
+def test_deconv_bn_relu_matches_autograd():
+    """DeconvBnRelu (ConvTranspose2d(4,2,1) as four sub-pixel 2x2 convs -> training-mode BatchNorm -> ReLU; backward through
+    the conv and MFMA weight-gradient kernels) against torch autograd in fp64, the ReLU decisions taken from the HIP
+    output (pose_rsgnet.py:741-750)."""
+    from rsgnet_amd.train_ops import deconv_bn_relu
+    B, H, W, Cc = 2, 16, 24, 32
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, Cc, generator=g).to(torch.bfloat16)
+    dc = nn.ConvTranspose2d(Cc, Cc, 4, 2, 1, 0, bias=False)
+    bn = nn.BatchNorm2d(Cc, momentum=0.1)
+    with torch.no_grad():
+        dc.weight.copy_((torch.randn(Cc, Cc, 4, 4, generator=g) * 0.1).to(torch.bfloat16).float())
+        bn.weight.copy_(torch.rand(Cc, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(Cc, generator=g) * 0.2)
+    dz = torch.randn(B, 2 * H, 2 * W, Cc, generator=g).to(torch.bfloat16)
+    w0, gam, bet = dc.weight.detach().clone(), bn.weight.detach().clone(), bn.bias.detach().clone()
+    owner = nn.Module()
+    dcd, bnd = dc.cuda(), bn.cuda().train()
+    xd = x.cuda().requires_grad_(True)
+    z = deconv_bn_relu(owner, "up", xd, dcd, bnd)
+    gx, gw, gg, gb = torch.autograd.grad((z.float() * dz.cuda().float()).sum(), [xd, dcd.weight, bnd.weight, bnd.bias])
+    torch.cuda.synchronize()
+    X = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    Wt, G, Bt = w0.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rm, rv = torch.zeros(Cc, dtype=torch.float64), torch.ones(Cc, dtype=torch.float64)
+    Y = F.conv_transpose2d(X, Wt, None, stride=2, padding=1)
+    Z = F.batch_norm(Y, rm, rv, G, Bt, True, 0.1, 1e-5) * (z.detach() > 0).permute(0, 3, 1, 2).cpu().double()
+    wx, ww, wg, wb = torch.autograd.grad((Z * dz.double().permute(0, 3, 1, 2)).sum(), [X, Wt, G, Bt])
+    assert z.shape == (B, 2 * H, 2 * W, Cc)
+    ez = float((z.detach().cpu().double().permute(0, 3, 1, 2) - Z.detach()).abs().max()) / float(Z.detach().abs().max())
+    errs = dict(z=ez, dx=_rel(gx.permute(0, 3, 1, 2), wx), dw=_rel(gw, ww), dgamma=_rel(gg, wg), dbeta=_rel(gb, wb))
+    print("  deconv_bn_relu:", {n: f"{v:.2e}" for n, v in errs.items()})
+    assert ez < 2 ** -6
+    assert errs["dx"] < 1e-2 and errs["dw"] < 1e-2 and errs["dgamma"] < 1e-2 and errs["dbeta"] < 1e-2, errs
