@@ -659,3 +659,84 @@ def test_rsgnet_hip_head_matches_the_torch_head_on_the_same_feature_map():
     assert len(rows) >= 40
     if os.environ.get("RSGNET_TEST_MEASURE") != "1":
         assert e_feat < HIP_HEAD_BAR and rows[0][0] < HIP_HEAD_BAR and np.median([r[0] for r in rows]) < HIP_HEAD_MEDIAN_BAR, rows[:6]
+
+
+def _rsg_step_args(x, target, tw, all_t, all_w, limbs_t, sl):
+    from rsgnet_amd.loss import relation_target_vector
+    tc = target[sl].cuda()
+    return (x[sl].cuda(), tc, tw[sl].cuda(), all_t[sl].cuda(), all_w[sl].cuda(), limbs_t[sl].cuda()), relation_target_vector(tc)
+
+
+def _dp_gpu_worker_rsgnet(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rsgnet_amd.loss import JointsMSELoss, rsgnet_loss
+    from rsgnet_amd.optim import FusedAdam
+    from rsgnet_amd.parallel import DataParallelStep
+    cfg, model, sd, data, gold = _rsg_case()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    crit = JointsMSELoss(True)
+    step = DataParallelStep(model, lambda outs, *t: rsgnet_loss(outs, *t, crit), opt)
+    args, p = _rsg_step_args(*data, slice(rank, rank + 1))          # one crop per rank
+    losses = []
+    for _ in range(2):
+        loss, _ = step(*args, relation_target=p)
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    q.put((rank, losses, opt.flat_param.detach().cpu().numpy().copy(), opt.grad_scale))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rsgnet_data_parallel_training_two_ranks_on_the_gpu():
+    """`rsgnet_train`'s loop body (function.py:256-323) data-parallel: two processes, one crop each, both on cuda:0, gloo
+    for the exchange, two DataParallelStep iterations of pose_rsgnet with FusedAdam.  The head's gradients reach the flat
+    buffer through autograd before the backbone's backward list starts, the backbone's during it; the buckets are
+    all-reduced behind the backward segments.  Both ranks must end with bit-identical parameters, equal to one process
+    that computes the two per-crop gradients one after the other and sums them itself."""
+    import torch.multiprocessing as mp
+    from rsgnet_amd.loss import JointsMSELoss, rsgnet_loss
+    from rsgnet_amd.optim import FusedAdam
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34600 + os.getpid() % 2000
+    ps = [ctx.Process(target=_dp_gpu_worker_rsgnet, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = {}
+    for _ in ps:
+        r, losses, flat, gs = q.get(timeout=400)
+        res[r] = (losses, flat, gs)
+    for p in ps:
+        p.join(60)
+    assert res[0][2] == 0.5 and np.array_equal(res[0][1], res[1][1])          # replicas stay identical, bit for bit
+    assert all(np.isfinite(res[r][0]).all() for r in res)
+    cfg, model, sd, data, gold = _rsg_case()
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    opt.grad_scale = 0.5
+    crit = JointsMSELoss(True)
+    keep = lambda: {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    bn_state = [keep() for _ in range(2)]
+    for it in range(2):
+        total = torch.zeros_like(opt.flat_grad)
+        for r in range(2):
+            live = model.state_dict()                                # every replica keeps its own running statistics
+            for k, v in bn_state[r].items():
+                live[k].copy_(v)
+            args, p = _rsg_step_args(*data, slice(r, r + 1))
+            loss = rsgnet_loss(model(args[0], relation_target=p), *args[1:], crit)
+            opt.zero_grad()
+            loss.backward()
+            total += opt.flat_grad
+            bn_state[r] = keep()
+            assert abs(float(loss.detach()) - res[r][0][it]) <= 1e-6 * abs(res[r][0][it]) + 1e-9
+        opt.flat_grad.copy_(total)
+        opt.step()
+    torch.cuda.synchronize()
+    assert np.array_equal(opt.flat_param.detach().cpu().numpy(), res[0][1])

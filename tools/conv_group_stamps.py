@@ -67,6 +67,28 @@ for m in members:
 xcc = (raw[:, 7] >> 32) & 0xf
 hwid = raw[:, 7] & 0xffffffff
 cu = ((hwid >> 8) & 0xf) | (((hwid >> 13) & 0x7) << 4) | (xcc << 8)
+# cold-start effects: the phases of a workgroup by its rank among the workgroups of the SAME item on its CU (entry order)
+first = 0
+for m in members:
+    t = tiles.get(m)
+    if t is None:
+        continue
+    n = t["tile"][7] if len(t["tile"]) > 7 else 0
+    idx = np.arange(first, first + n)
+    idx = idx[st[idx, 4] > 0]
+    ranks = np.zeros(len(idx), int)
+    for c in np.unique(cu[idx]):
+        sel = np.where(cu[idx] == c)[0]
+        ranks[sel[np.argsort(st[idx[sel], 0])]] = np.arange(len(sel))
+    line = []
+    for r in (0, 1, 2, 3):
+        mm = ranks == r if r < 3 else ranks >= 3
+        if mm.any():
+            b = st[idx[mm]]
+            line.append(f"rank{'>=' if r == 3 else ' '}{r}: n {mm.sum():4d} args {np.median(b[:, 1] - b[:, 0]):5.0f} stage {np.median(b[:, 2] - b[:, 1]):5.0f} "
+                        f"mfma {np.median(b[:, 3] - b[:, 2]):5.0f} store {np.median(b[:, 4] - b[:, 3]):5.0f}")
+    print(f"  {m:26s} " + " | ".join(line))
+    first += n
 per = []
 for c in np.unique(cu):
     m = cu == c
