@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+    flags += os.environ.get("RSGNET_HIP_EXTRA_CFLAGS", "").split()       # experiment builds (-D switches)
     if os.environ.get("RSGNET_HIP_DEBUG_BUILD") == "1":     # diagnostic library: timing switches that give WRONG results
         flags.append("-DRSG_DEBUG")
     # MFMA accumulators in VGPRs (gfx950 has one unified register file): the default AGPR form costs
