@@ -41,10 +41,15 @@ def kt_machine_forward(kt, weight: torch.Tensor) -> torch.Tensor:
 _KEY_ORDER = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)   # rsg_trp_project_g's order of the keys in a 16-block
 
 
+_KEY_INDEX = {}
+
+
 def _keys_transposed(rows: torch.Tensor) -> torch.Tensor:
     """[B,S,C] -> [B,C,S] with every 16-block of keys in the kernel's order."""
     b, s, c = rows.shape
-    idx = torch.tensor(_KEY_ORDER, device=rows.device)
+    idx = _KEY_INDEX.get(rows.device)
+    if idx is None:                       # built once per device (a host-to-device copy has no place in a captured graph)
+        idx = _KEY_INDEX[rows.device] = torch.tensor(_KEY_ORDER, device=rows.device)
     return rows.transpose(1, 2).reshape(b, c, s // 16, 16).index_select(3, idx).reshape(b, c, s).contiguous()
 
 
@@ -199,7 +204,9 @@ def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Te
 
 
 def train_forward(model, x: torch.Tensor, relation_target: Optional[torch.Tensor] = None):
-    """`model(x, relation_target)` under `model.train()` for pose_rsgnet."""
+    """`model(x, relation_target)` under `model.train()` for pose_rsgnet.  The head's ~300 launches per step are enqueued
+    eagerly: capturing them (forward and autograd backward) with torch.cuda.make_graphed_callables ends in a segmentation
+    fault inside hipStreamEndCapture on ROCm 7.2 (the backward's launches come from autograd's device thread)."""
     from .train import train_forward as backbone_forward
     feat16 = backbone_forward(model, x)                                   # HIP: one autograd node for the whole backbone
     return head_forward(model, feat16, relation_target)
