@@ -75,7 +75,7 @@ class _ConvState:
             it.transpose, it.first_block = tr, first
         self.table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(device)
         self.zero_bias = torch.zeros(max(self.cout_pad, _round_up(self.cin_pad, 32)), dtype=torch.float32, device=device)
-        self._wgrad_ws: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
+        self._wgrad_ws: Dict[tuple, torch.Tensor] = {}
         self._bn_ws: Optional[torch.Tensor] = None
 
     def pack(self, w: torch.Tensor):
@@ -85,13 +85,14 @@ class _ConvState:
         hip.check(lib.rsg_pack_conv_weights_device(self.table.data_ptr(), 2, self.blocks, BF16, _stream(self.w_stage)),
                   "pack_weights")
 
-    def wgrad_ws(self, b: int, h: int, w: int, cout_pad: Optional[int] = None) -> torch.Tensor:
+    def wgrad_ws(self, b: int, h: int, w: int, cout_pad: Optional[int] = None, xc: Optional[int] = None) -> torch.Tensor:
         cout_pad = cout_pad or self.cout_pad
-        key = (b, h, w, cout_pad)
+        xc = xc or self.cin_pad
+        key = (b, h, w, cout_pad, xc)
         ws = self._wgrad_ws.get(key)
         if ws is None:
             pad = (self.k - 1) // 2
-            need = int(hip.lib().rsg_conv_wgrad_workspace_bytes(b, h, w, self.cin_pad, h, w, cout_pad, self.k, self.k, 1, pad))
+            need = int(hip.lib().rsg_conv_wgrad_workspace_bytes(b, h, w, xc, h, w, cout_pad, self.k, self.k, 1, pad))
             if not need:
                 raise NotImplementedError(f"weight gradient of a {self.k}x{self.k} conv {self.cin}->{self.cout}")
             ws = self._wgrad_ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -99,7 +100,7 @@ class _ConvState:
 
     def wgrad_ws3(self, b: int, h: int, w: int) -> torch.Tensor:
         """workspace of a 3x3 pad-1 weight gradient over this conv's channels (the deconv phases' route)."""
-        key = (b, h, w, -3)
+        key = (b, h, w, -3, 0)
         ws = self._wgrad_ws.get(key)
         if ws is None:
             need = int(hip.lib().rsg_conv_wgrad_workspace_bytes(b, h, w, self.cin_pad, h, w, self.cout_pad, 3, 3, 1, 1))
@@ -129,14 +130,14 @@ def _conv(st: _ConvState, x16: torch.Tensor, pack: torch.Tensor, in_c: int, out_
     given (the 2x2 sub-pixel convs of a ConvTranspose2d); up = (factor, y, x) places output pixel (y,x) at
     (factor*y + up_y, factor*x + up_x) of the physical output map; residual: a 16-bit map added in the epilogue."""
     b, h, w, c = x16.shape
-    if c != in_c or x16.dtype != torch.bfloat16 or not x16.is_contiguous():
-        raise ValueError(f"{what}: input {tuple(x16.shape)} {x16.dtype}, the conv wants dense bf16 with {in_c} channels")
+    if c < in_c or c % 8 or x16.dtype != torch.bfloat16 or not x16.is_contiguous():
+        raise ValueError(f"{what}: input {tuple(x16.shape)} {x16.dtype}, the conv wants dense bf16 with at least {in_c} channels")
     d = hip.ConvDesc()
     pad_y, pad_x = pads if pads is not None else ((st.k - 1) // 2, (st.k - 1) // 2)
     d.inp, d.w_packed, d.bias = x16.data_ptr(), pack.data_ptr(), bias.data_ptr()
     d.out16 = out16.data_ptr() if out16 is not None else None
     d.out_nchw_f32 = out_f32.data_ptr() if out_f32 is not None else None
-    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = b, h, w, in_c, in_c
+    d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = b, h, w, in_c, c          # channels [in_c, c) of the buffer are not read
     d.out_h, d.out_w, d.out_c, d.out_ld = h, w, out_c, _round_up(out_c, 32)
     d.kh, d.kw, d.stride, d.pad_y, d.pad_x = st.k, st.k, 1, pad_y, pad_x
     d.up, d.up_y, d.up_x, d.phys_h, d.phys_w = up[0], up[1], up[2], up[0] * h, up[0] * w
@@ -180,8 +181,9 @@ class ConvBnRelu(torch.autograd.Function):
         dy, dgamma, dbeta = _bn_backward(st, dz.to(torch.bfloat16).contiguous(), z, ys, mean, invstd, g32, relu, ck)
         dw = torch.empty(O, st.cin, st.k, st.k, dtype=torch.float32, device=x16.device)
         pad = (st.k - 1) // 2
-        hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), dy.data_ptr(), dw.data_ptr(), st.wgrad_ws(b, h, wd).data_ptr(), b, h, wd,
-                                     st.cin, st.cin_pad, h, wd, O, st.cout_pad, st.k, st.k, 1, pad, BF16, s), "conv_wgrad")
+        xc = x16.shape[3]                                  # the map's channel stride (>= the conv's padded input channels)
+        hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), dy.data_ptr(), dw.data_ptr(), st.wgrad_ws(b, h, wd, xc=xc).data_ptr(), b, h, wd,
+                                     st.cin, xc, h, wd, O, st.cout_pad, st.k, st.k, 1, pad, BF16, s), "conv_wgrad")
         dx = None
         if ctx.needs_input_grad[0]:
             cin_out = _round_up(st.cin, 32)
@@ -366,8 +368,9 @@ class Conv1x1Out(torch.autograd.Function):
             csw = torch.empty(lib.rsg_channel_sum_workspace_bytes(J), dtype=torch.uint8, device=x16.device)
             hip.check(lib.rsg_channel_sum_nchw_f32(dout.data_ptr(), dbias.data_ptr(), csw.data_ptr(), b, J, h * wd, s), "dbias")
         dw = torch.empty(J, st.cin, 1, 1, dtype=torch.float32, device=x16.device)
-        hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), d16.data_ptr(), dw.data_ptr(), st.wgrad_ws(b, h, wd, dpad).data_ptr(), b, h, wd,
-                                     st.cin, st.cin_pad, h, wd, J, dpad, 1, 1, 1, 0, BF16, s), "conv_wgrad")
+        xc = x16.shape[3]
+        hip.check(lib.rsg_conv_wgrad(x16.data_ptr(), d16.data_ptr(), dw.data_ptr(), st.wgrad_ws(b, h, wd, dpad, xc).data_ptr(), b, h, wd,
+                                     st.cin, xc, h, wd, J, dpad, 1, 1, 1, 0, BF16, s), "conv_wgrad")
         dx = None
         if ctx.needs_input_grad[0]:
             if _round_up(st.cin, 32) != x16.shape[3]:

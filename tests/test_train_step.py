@@ -740,3 +740,41 @@ def test_rsgnet_data_parallel_training_two_ranks_on_the_gpu():
         opt.step()
     torch.cuda.synchronize()
     assert np.array_equal(opt.flat_param.detach().cpu().numpy(), res[0][1])
+
+
+@pytest.mark.gpu
+def test_rsgnet_crowdpose_training_steps_run_and_learn():
+    """pose_rsgnet with the CrowdPose head (14 joints: the type conv reads 14 channels of a 32-channel buffer, the
+    classifiers' gradient maps are 16 channels wide) through `rsgnet_train`'s loop body with FusedAdam: finite outputs and
+    gradients for every trainable parameter, a falling loss over a few steps on one batch."""
+    from rsgnet_amd.loss import JointsMSELoss, relation_target_vector, rsgnet_loss
+    from rsgnet_amd.optim import FusedAdam
+    from tests.util import load_case
+    cfg, model, sd, _x, _gold = load_case("rsgnet_w32_256x192_crowdpose")
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    B, J, L = 2, 14, cfg.MODEL.NUM_LIMBS
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 3, 256, 192, generator=g).cuda()
+    target, tw = tso.gaussian_targets(B, J, (128, 96), 3)
+    all_t, all_w = tso.gaussian_targets(B, J, (128, 96), 4)
+    limbs_t = tso.limb_targets(B, L, (128, 96), 5)
+    args = tuple(t.cuda() for t in (target, tw, all_t, all_w, limbs_t))
+    p = relation_target_vector(args[0])
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    crit = JointsMSELoss(True)
+    losses = []
+    for it in range(5):
+        outs = model(x, relation_target=p)
+        assert [tuple(o.shape) for o in outs] == [(B, J, 128, 96), (B, J, 128, 96), (B, L, 128, 96), (B,)]
+        loss = rsgnet_loss(outs, *args, crit)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            for k, q in model.named_parameters():
+                if q.requires_grad:
+                    assert q.grad is not None and torch.isfinite(q.grad).all() and (q.grad != 0).any(), k
+        opt.step()
+        losses.append(loss.item())
+    print("rsgnet crowdpose losses", losses)
+    assert all(np.isfinite(losses)) and losses[-1] < 0.9 * losses[0]
