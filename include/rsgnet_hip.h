@@ -46,6 +46,14 @@ int rsg_tune(const char* key, int32_t value);
  *          and lands on physical pixel (y*up + up_y, x*up + up_x)  (up=1, up_y=up_x=0 for plain convs;
  *          up=2 for the deconv phases).
  */
+/* A wide map (HRNet layer1's 256 channels, /root/reference/lib/models/pose_hrnet.py:63-101) stored as channel-tile PLANES
+ * [C/32][batch*h*w][32] instead of dense NHWC [batch*h*w][C]: the MFMA accumulator layout of the conv kernels has a lane's
+ * pixel on the lane axis and 16 channels in registers, so a wave's store (or residual load) of one 32-channel tile is
+ * 32 pixels x 64 B -- one contiguous 2 KB run in planes, 32 pieces at a 512-byte stride in NHWC.  The pixel stride (ld) of
+ * such a map is 32. */
+#define RSG_LAYOUT_OUT_PLANES 1
+#define RSG_LAYOUT_RES_PLANES 2
+#define RSG_LAYOUT_IN_PLANES 4
 typedef struct rsg_conv_desc {
     const void* in;
     const void* w_packed;      /* from rsg_pack_conv_weights_host, copied to the device */
@@ -63,7 +71,8 @@ typedef struct rsg_conv_desc {
     int32_t relu_tile_mask;    /* 0 = use `relu` for all channels; else bit t = ReLU on output channels [32t, 32t+32) */
     int32_t out_c_store;       /* 0 = write round_up(out_c,32) channels of out16; else only [0, out_c_store) (multiple
                                   of 8): for outputs that are a channel slice narrower than a 32-channel tile */
-    int32_t reserved;
+    int32_t layout;            /* RSG_LAYOUT_* bits; 0 = every map dense NHWC.  Honoured by rsg_conv_pair / rsg_conv_pair_next
+                                  (OUT, RES: the tail's output / residual) and rsg_conv_dual (IN) only */
     /* two more addends of the epilogue (same layout rules as `residual`; NULL = none): the HRNet fuse sum of the
        lowest-resolution output rides on the last conv that feeds it (pose_hrnet.py:259-266) */
     const void* residual2;

@@ -14,6 +14,10 @@ struct ConvArgs {
     int B, Hin, Win, ldi;
     int Hout, Wout, Cout, ldo, ldr, ldr2, ldr3;
     int CoutStore;   // channels [0, CoutStore) are written to the 16-bit output (multiple of 8)
+    // conv_pair / conv_pair_next tails only: elements between the 32-channel tiles of `out` and of `res` (32 = the dense
+    // NHWC map; batch*H*W*32 with ldo / ldr = 32: the map as channel-tile PLANES [C/32][pixel][32], in which a wave's 32
+    // pixels x 64 B of an accumulator tile are one contiguous 2 KB run instead of 32 pieces at a 512-byte stride)
+    int tso, tsr;
     int SI, oy0, ox0;
     int up, upy, upx, Hp, Wp;
     int relu;

@@ -316,7 +316,7 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
                 for (int j = 0; j < 2; ++j) {
                     rv[j][0] = rv[j][1] = make_uint4(0, 0, 0, 0);
                     if (p.res && op[j] >= 0) {
-                        const char* rp = p.res + ((size_t)op[j] * p.ldr + cb2) * 2;
+                        const char* rp = p.res + ((size_t)op[j] * p.ldr + (size_t)ct2 * p.tsr + hh * 16) * 2;
                         rv[j][0] = *reinterpret_cast<const uint4*>(rp);
                         rv[j][1] = *reinterpret_cast<const uint4*>(rp + 16);
                     }
@@ -359,7 +359,7 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
                         o[k] = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
                     }
                     if (op[j] >= 0) {
-                        char* dst = p.out + ((size_t)op[j] * p.ldo + cb2) * 2;
+                        char* dst = p.out + ((size_t)op[j] * p.ldo + (size_t)ct2 * p.tso + hh * 16) * 2;
                         *reinterpret_cast<uint4*>(dst) = o[0];
                         *reinterpret_cast<uint4*>(dst + 16) = o[1];
                     }
@@ -418,7 +418,7 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
                     op[j] = ok ? (b * p.Hout + y0 + py) * p.Wout + x0 + px : -1;
                     rv[j][0] = rv[j][1] = make_uint4(0, 0, 0, 0);
                     if (p.res && ok) {
-                        const char* rp = p.res + ((size_t)op[j] * p.ldr + cb2) * 2;
+                        const char* rp = p.res + ((size_t)op[j] * p.ldr + (size_t)ct2 * p.tsr + hh * 16) * 2;
                         rv[j][0] = *reinterpret_cast<const uint4*>(rp);
                         rv[j][1] = *reinterpret_cast<const uint4*>(rp + 16);
                     }
@@ -441,7 +441,7 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
 #pragma unroll
                 for (int j = 0; j < NPH; ++j) {
                     if (op[j] < 0) continue;
-                    char* dst = p.out + ((size_t)op[j] * p.ldo + cb2) * 2;
+                    char* dst = p.out + ((size_t)op[j] * p.ldo + (size_t)ct2 * p.tso + hh * 16) * 2;
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const f32x8 rf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, rv[j][k]), f32x8);

@@ -182,6 +182,7 @@ static conv_fn lookup(int cinb, int taps, int wm, int nt) {
 
 // Validates a descriptor, picks the tiling and fills the kernel arguments.
 int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& grid) {
+    a.tso = a.tsr = 32;                 // dense NHWC maps (the pair tails may be told otherwise: RSG_LAYOUT_*)
     if (!d || !d->in || !d->w_packed || !d->bias || (!d->out16 && !d->out_nchw_f32))
         RSG_FAIL("conv: null pointer in descriptor");
     if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1) || (d->kh == 2 && d->kw == 2)))
@@ -274,8 +275,12 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
     if (inner->kh != 3 || inner->kw != 3 || inner->stride != 1 || inner->out_c != 64 || inner->in_c % 64 ||
         inner->up != 1 || inner->out_nchw_f32)
         RSG_FAIL("conv_pair: the inner conv must be 3x3 stride 1 with 64 output channels and cin a multiple of 64");
-    if (tail_out_c < 32 || tail_out_c % 32 || out_ld < tail_out_c || out_ld % 8 || (residual && (res_ld < tail_out_c || res_ld % 8)))
-        RSG_FAIL("conv_pair: tail_out_c=%d out_ld=%d res_ld=%d", tail_out_c, out_ld, res_ld);
+    const bool planes_out = (inner->layout & RSG_LAYOUT_OUT_PLANES) != 0, planes_res = residual && (inner->layout & RSG_LAYOUT_RES_PLANES);
+    if (tail_out_c < 32 || tail_out_c % 32 || (planes_out ? out_ld != 32 : (out_ld < tail_out_c || out_ld % 8)) ||
+        (residual && (planes_res ? res_ld != 32 : (res_ld < tail_out_c || res_ld % 8))))
+        RSG_FAIL("conv_pair: tail_out_c=%d out_ld=%d res_ld=%d (a map in channel-tile planes has a pixel stride of 32)", tail_out_c, out_ld, res_ld);
+    if ((planes_out || planes_res) && head_x) RSG_FAIL("conv_pair: the fused-head form takes dense maps only");
+    if ((long long)inner->batch * inner->out_h * inner->out_w * tail_out_c * 2 >= (1LL << 31)) RSG_FAIL("conv_pair: map too large");
     if (((uintptr_t)tail_w_packed | (uintptr_t)tail_bias | (uintptr_t)residual | (uintptr_t)out16) & 15)
         RSG_FAIL("conv_pair: pointers must be 16-byte aligned");
     rsg_conv_desc d = *inner;
@@ -306,6 +311,9 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
     if (rsg_conv_prepare(&d, a, t, grid)) return 1;
     if (grid.y != 1 || t.CINB != 64) RSG_FAIL("conv_pair: unexpected tiling");
     a.out = (char*)out16; a.ldo = out_ld; a.res = (const char*)residual; a.ldr = res_ld;
+    const int plane = inner->batch * inner->out_h * inner->out_w * 32;      // elements of one 32-channel plane
+    a.tso = planes_out ? plane : 32;
+    a.tsr = planes_res ? plane : 32;
     a.relu = relu ? -1 : 0; a.Cout = tail_out_c; a.CoutStore = tail_out_c;
     a.wpk2 = (const uint4*)tail_w_packed; a.bias2 = tail_bias; a.C2 = tail_out_c;
     if (t.lds < t.TH * t.TW * 144) t.lds = t.TH * t.TW * 144;

@@ -13,6 +13,7 @@ struct DualArgs {
     const uint4* wA; const float* bA; char* outA;
     const uint4* wB; const float* bB; char* outB;
     int B, H, W, ldi;
+    int tsi;        // elements between the 32-channel tiles of `in` (32 = dense NHWC; batch*H*W*32 with ldi = 32: channel-tile planes)
     int ldoA, storeA, ldoB;
     int nchunks, tiles_x, tiles_y, RP;
     int reluA, reluB;
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
                     const int iy = iy0 + ty, ix = ix0 + tx;
                     lo[j] = ty * p.RP + tx * PS + cg * 16;
                     if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                        r[j] = *reinterpret_cast<const uint4*>(p.in + ((img + (size_t)iy * p.W + ix) * p.ldi + ch * CINB + cg * 8) * 2);
+                        r[j] = *reinterpret_cast<const uint4*>(p.in + ((img + (size_t)iy * p.W + ix) * p.ldi + (size_t)(ch * (CINB / 32) + (cg >> 2)) * p.tsi + (cg & 3) * 8) * 2);
                 }
             }
 #pragma unroll
@@ -188,15 +189,17 @@ extern "C" int rsg_conv_dual(const rsg_conv_desc* a, const void* wB_packed, cons
         RSG_FAIL("conv_dual: output channels %d / %d (built: <= 32 with 64, <= 64 with 96)", a->out_c, cout_b);
     if ((a->in_h | a->in_w) & 1) RSG_FAIL("conv_dual: the map must have even height and width");
     const int store = a->out_c_store ? a->out_c_store : 32 * cta;
-    if (a->in_ld < a->in_c || (a->in_ld & 7) || a->out_ld < store || (a->out_ld & 7) || store % 8 || store > 32 * cta || out_ld_b < cout_b || (out_ld_b & 7))
+    const bool planes_in = (a->layout & RSG_LAYOUT_IN_PLANES) != 0;
+    if ((planes_in ? a->in_ld != 32 : a->in_ld < a->in_c) || (a->in_ld & 7) || a->out_ld < store || (a->out_ld & 7) || store % 8 || store > 32 * cta || out_ld_b < cout_b || (out_ld_b & 7))
         RSG_FAIL("conv_dual: strides");
     if (((uintptr_t)a->in | (uintptr_t)a->w_packed | (uintptr_t)a->bias | (uintptr_t)a->out16 | (uintptr_t)wB_packed | (uintptr_t)biasB | (uintptr_t)outB16) & 15)
         RSG_FAIL("conv_dual: pointers must be 16-byte aligned");
-    if ((long long)a->batch * a->in_h * a->in_w * a->in_ld * 2 >= (1LL << 31)) RSG_FAIL("conv_dual: map too large for 32-bit offsets");
+    if ((long long)a->batch * a->in_h * a->in_w * (planes_in ? a->in_c : a->in_ld) * 2 >= (1LL << 31)) RSG_FAIL("conv_dual: map too large for 32-bit offsets");
     DualArgs p;
     p.in = (const char*)a->in; p.wA = (const uint4*)a->w_packed; p.bA = a->bias; p.outA = (char*)a->out16;
     p.wB = (const uint4*)wB_packed; p.bB = biasB; p.outB = (char*)outB16;
     p.B = a->batch; p.H = a->in_h; p.W = a->in_w; p.ldi = a->in_ld;
+    p.tsi = planes_in ? a->batch * a->in_h * a->in_w * 32 : 32;
     p.ldoA = a->out_ld; p.storeA = store; p.ldoB = out_ld_b;
     p.nchunks = a->in_c / 64;
     p.tiles_x = ceil_div(a->in_w, 16); p.tiles_y = ceil_div(a->in_h, 16);

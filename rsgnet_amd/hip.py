@@ -11,6 +11,7 @@ from typing import Optional
 from . import build as _build
 
 RSG_F16, RSG_BF16 = 0, 1
+RSG_LAYOUT_OUT_PLANES, RSG_LAYOUT_RES_PLANES, RSG_LAYOUT_IN_PLANES = 1, 2, 4      # rsg_conv_desc.layout
 DTYPES = {"fp16": RSG_F16, "bf16": RSG_BF16}
 
 
@@ -24,7 +25,7 @@ class ConvDesc(C.Structure):
         ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad_y", C.c_int32), ("pad_x", C.c_int32),
         ("up", C.c_int32), ("up_y", C.c_int32), ("up_x", C.c_int32), ("phys_h", C.c_int32), ("phys_w", C.c_int32),
         ("relu", C.c_int32), ("dtype", C.c_int32), ("tile_hint", C.c_int32), ("relu_tile_mask", C.c_int32),
-        ("out_c_store", C.c_int32), ("reserved", C.c_int32),
+        ("out_c_store", C.c_int32), ("layout", C.c_int32),
         ("residual2", C.c_void_p), ("residual3", C.c_void_p), ("res2_ld", C.c_int32), ("res3_ld", C.c_int32),
     ]
 

@@ -39,11 +39,14 @@ class HandoffTimeout(RuntimeError):
 class VT:
     """Virtual NHWC 16-bit activation [B,H,W,ld]; ``view(c0, c)`` addresses a channel slice of it."""
 
-    __slots__ = ("H", "W", "C", "ld", "coff", "base", "pinned", "first", "last", "storage", "name")
+    __slots__ = ("H", "W", "C", "ld", "coff", "base", "pinned", "first", "last", "storage", "name", "planes")
 
-    def __init__(self, H, W, C_, ld=None, pinned=False, name=""):
+    def __init__(self, H, W, C_, ld=None, pinned=False, name="", planes=False):
         self.H, self.W, self.C = H, W, C_
         self.ld = ld if ld is not None else C_
+        # planes: the map is stored as channel-tile planes [C/32][B*H*W][32] (include/rsgnet_hip.h, RSG_LAYOUT_*): only
+        # conv_pair tails write / add it and conv_dual reads it; `ld` keeps the dense value (it sizes the buffer)
+        self.planes = planes
         self.coff = 0
         self.base: "VT" = self
         self.pinned = pinned
@@ -65,6 +68,9 @@ class VT:
 
     def tensor(self, batch: int) -> torch.Tensor:
         """[B,H,W,C] view of the live buffer (debug / tests)."""
+        if self.planes:
+            t = self.base.storage[: batch * self.H * self.W * self.C].view(self.C // 32, batch, self.H, self.W, 32)
+            return t.permute(1, 2, 3, 0, 4).reshape(batch, self.H, self.W, self.C)
         t = self.base.storage[: batch * self.H * self.W * self.ld].view(batch, self.H, self.W, self.ld)
         return t[..., self.coff: self.coff + self.C]
 
@@ -187,8 +193,8 @@ class Plan:
         return idx
 
     # ------------------------------------------------------------------ recording
-    def new(self, H, W, C_, ld=None, pinned=False, name="") -> VT:
-        vt = VT(H, W, C_, ld, pinned, name)
+    def new(self, H, W, C_, ld=None, pinned=False, name="", planes=False) -> VT:
+        vt = VT(H, W, C_, ld, pinned, name, planes)
         self._vts.append(vt)
         return vt
 
@@ -305,7 +311,7 @@ class Plan:
         return out
 
     def conv_pair(self, x: VT, conv_a, bn_a, conv_b, bn_b, residual: Optional[VT], name="", next_unit=None,
-                  tail=None, cat_x: Optional[VT] = None):
+                  tail=None, cat_x: Optional[VT] = None, planes: bool = False):
         """Record Bottleneck conv2 (3x3, 64 outputs, BN, ReLU) + conv3 (1x1, BN, + residual, ReLU) as ONE launch
         (rsg_conv_pair): the 64-channel map between them stays in LDS.  next_unit = (conv1, bn1) of the FOLLOWING
         Bottleneck: its 1x1 conv runs in the same launch on the block output (rsg_conv_pair_next) and the call returns
@@ -317,7 +323,7 @@ class Plan:
         else:
             sb, hb = self.bn_fold(bn_b)
             wpb, bob, Ib, Ob = self.pack_conv(conv_b.weight, sb, hb, conv_b.bias)
-        out = self.new(x.H, x.W, _round_up(Ob, 32), name=name)
+        out = self.new(x.H, x.W, _round_up(Ob, 32), name=name, planes=planes)     # planes: the block output as [C/32][pixel][32]
         rec = dict(kind="conv_pair", x=x, wp=wpa, bias=boa, wp2=wpb, bias2=bob, res=residual, out=out, cat_x=cat_x,
                    out_f32=None, I=self.lib.rsg_conv_padded_cin(Ia), O=Oa, O2=Ob, kh=3, kw=3, stride=1, pad=(1, 1),
                    up=(1, 0, 0), out_hw=(x.H, x.W), phys_hw=(x.H, x.W), relu=True, name=name)
@@ -563,6 +569,9 @@ class Plan:
     def _conv_desc(self, r, fake_ptrs=False) -> "hip.ConvDesc":
         d = hip.ConvDesc()
         x: VT = r["x"]
+        for v in (x, r.get("res"), r.get("out"), *(r.get("res_more") or [])):
+            if v is not None and v.planes and r["kind"] != "conv_pair":
+                raise RuntimeError(f"{r.get('name')}: {v.name} is stored as channel-tile planes; only conv_pair and conv_dual take it")
         fake = 0x10000
         d.inp = fake if fake_ptrs else x.ptr()
         d.w_packed = r["wp"].data_ptr()
@@ -623,8 +632,10 @@ class Plan:
         d.out_ld = 64
         self._keep.append(d)
         out, res = r["out"], r["res"]
+        d.layout = (hip.RSG_LAYOUT_OUT_PLANES if out.planes else 0) | (hip.RSG_LAYOUT_RES_PLANES if res is not None and res.planes else 0)
+        old, rld = (32 if out.planes else out.ld), (0 if res is None else 32 if res.planes else res.ld)
         args = (C.byref(d), r["wp2"].data_ptr(), r["bias2"].data_ptr(), r["O2"], res.ptr() if res is not None else None,
-                res.ld if res is not None else 0, out.ptr(), out.ld, 1)
+                rld, out.ptr(), old, 1)
         fn, nm = self.lib.rsg_conv_pair, r["name"]
         entry = dict(name=nm, cin=r["I"], cout=r["O2"], k=3, s=1, hw=r["out_hw"], pair=True)
         if r.get("out3") is not None:          # + the next Bottleneck's conv1 in the same launch
@@ -632,7 +643,7 @@ class Plan:
             fn = self.lib.rsg_conv_pair_next
             cx = r.get("cat_x")
             args = (C.byref(d), r["wp2"].data_ptr(), r["bias2"].data_ptr(), res.ptr() if res is not None else None,
-                    res.ld if res is not None else 0, out.ptr(), out.ld, r["wp3"].data_ptr(), r["bias3"].data_ptr(), t3.ptr(), t3.ld,
+                    rld, out.ptr(), old, r["wp3"].data_ptr(), r["bias3"].data_ptr(), t3.ptr(), t3.ld,
                     cx.ptr() if cx is not None else None, cx.ld if cx is not None else 0)
             entry = dict(name=nm, flops=float(2 * self.batch * r["out_hw"][0] * r["out_hw"][1] *
                                              (r["I"] * 64 * 9 + (128 if cx is not None else 64) * r["O2"] + r["O2"] * r["O3"])))
@@ -1141,7 +1152,8 @@ class _BackboneMixin:
         def make():
             d = hip.ConvDesc()
             d.inp, d.w_packed, d.bias, d.out16 = x.ptr(), wa.data_ptr(), ba.data_ptr(), oa.ptr()
-            d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, x.H, x.W, x.C, x.ld
+            d.batch, d.in_h, d.in_w, d.in_c, d.in_ld = B, x.H, x.W, x.C, (32 if x.planes else x.ld)
+            d.layout = hip.RSG_LAYOUT_IN_PLANES if x.planes else 0
             d.out_h, d.out_w, d.out_c, d.out_ld = x.H, x.W, Oa, oa.ld
             d.kh = d.kw = 3
             d.stride, d.pad_y, d.pad_x = 1, 1, 1
@@ -1404,6 +1416,11 @@ class _BackboneMixin:
             and os.environ.get("RSGNET_HIP_BOTTLENECK", "0") != "1"
         t_pre = None                # conv1 output of the NEXT block, already computed by the previous block's launch
         l1 = list(m.layer1)
+        # layer1's 256-channel maps as channel-tile planes (rsgnet_hip.h, RSG_LAYOUT_*): when every one of them is written by
+        # a conv_pair tail and read only as the next tail's residual or by transition1's conv_dual
+        planes = os.environ.get("RSGNET_HIP_L1_PLANES", "1") != "0" and fold and use_next and len(l1) > 1 \
+            and all(self._plain_bottleneck(b) for b in l1[1:]) and os.environ.get("RSGNET_HIP_PAIR_CAT", "1") != "0" \
+            and self._transition1_dual([VT(H // 4, W // 4, 256)], m.transition1) and b0.conv3.out_channels == 256
         if fold and use_next and len(l1) > 1 and self._plain_bottleneck(l1[1]) and b0.conv2.kernel_size == (3, 3) \
                 and b0.conv2.in_channels == 64 and b0.conv2.out_channels == 64 and b0.conv3.out_channels == 256 \
                 and m.conv2.out_channels == 64 and os.environ.get("RSGNET_HIP_PAIR_CAT", "1") != "0":
@@ -1416,7 +1433,8 @@ class _BackboneMixin:
             w3 = b0.conv3.weight.detach().float().cpu() * s3.view(-1, 1, 1, 1)
             wd = b0.downsample[0].weight.detach().float().cpu() * sd.view(-1, 1, 1, 1)
             x, t_pre = self.conv_pair(t, b0.conv2, b0.bn2, None, None, None, name="layer1.0.conv2+conv3+downsample+next.conv1",
-                                      next_unit=(l1[1].conv1, l1[1].bn1), tail=(torch.cat([w3, wd], dim=1), h3 + hd), cat_x=xs)
+                                      next_unit=(l1[1].conv1, l1[1].bn1), tail=(torch.cat([w3, wd], dim=1), h3 + hd), cat_x=xs,
+                                      planes=planes)
             rest, k0 = l1[1:], 1
         elif fold:
             # layer1.0: relu(bn3(conv3(t)) + bn_d(conv_d(x))) is ONE 1x1 conv over the channel concat [t | x]
@@ -1455,10 +1473,10 @@ class _BackboneMixin:
                 t_pre = None
                 for j, blk in enumerate(run):
                     if j + 1 < len(run):
-                        x, t = self.conv_pair(t, blk.conv2, blk.bn2, blk.conv3, blk.bn3, x,
+                        x, t = self.conv_pair(t, blk.conv2, blk.bn2, blk.conv3, blk.bn3, x, planes=x.planes,
                                               name=f"{blk._rsg_name}.conv2+conv3+next.conv1", next_unit=(run[j + 1].conv1, run[j + 1].bn1))
                     else:
-                        x = self.conv_pair(t, blk.conv2, blk.bn2, blk.conv3, blk.bn3, x, name=f"{blk._rsg_name}.conv2+conv3")
+                        x = self.conv_pair(t, blk.conv2, blk.bn2, blk.conv3, blk.bn3, x, planes=x.planes, name=f"{blk._rsg_name}.conv2+conv3")
                 k += len(run)
             else:
                 x = self._residual_block(x, rest[k], f"layer1.{k0 + k}")

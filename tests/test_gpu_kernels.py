@@ -108,6 +108,16 @@ CONV_CASES = [
 ]
 
 
+def _to_planes(t_nhwc: torch.Tensor) -> torch.Tensor:
+    """dense [B,H,W,C] -> channel-tile planes [C/32][B,H,W][32] (include/rsgnet_hip.h, RSG_LAYOUT_*), flat."""
+    B, H, W, Cc = t_nhwc.shape
+    return t_nhwc.reshape(B, H, W, Cc // 32, 32).permute(3, 0, 1, 2, 4).contiguous()
+
+
+def _from_planes(t: torch.Tensor, B, H, W, Cc) -> torch.Tensor:
+    return t.reshape(Cc // 32, B, H, W, 32).permute(1, 2, 3, 0, 4).reshape(B, H, W, Cc)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_igemm_matches_cpu(case):
     B, Cin, Cout, H, W, k, stride, relu, use_res = case
@@ -522,6 +532,14 @@ def test_conv_dual_equals_two_convs(shape):
     torch.cuda.synchronize()
     assert torch.equal(oa.float().cpu().permute(0, 3, 1, 2), ref_a)
     assert torch.equal(ob.float().cpu().permute(0, 3, 1, 2), ref_b)
+    # the input as channel-tile planes (RSG_LAYOUT_IN_PLANES): the same bits
+    xin_p = _to_planes(xin)
+    oa2, ob2 = torch.full_like(oa, float("nan")), torch.full_like(ob, float("nan"))
+    d.inp, d.in_ld, d.out16, d.layout = xin_p.data_ptr(), 32, oa2.data_ptr(), hip.RSG_LAYOUT_IN_PLANES
+    hip.check(lib.rsg_conv_dual(C.byref(d), wpb.data_ptr(), bob.data_ptr(), ob2.data_ptr(), Ob, Ob, 1, _stream()), "conv_dual(planes)")
+    torch.cuda.synchronize()
+    assert torch.equal(oa2, oa) and torch.equal(ob2, ob)
+    d.inp, d.in_ld, d.out16, d.layout = xin.data_ptr(), Cin, oa.data_ptr(), 0
     d.stride = 2
     assert lib.rsg_conv_dual(C.byref(d), wpb.data_ptr(), bob.data_ptr(), ob.data_ptr(), Ob, Ob, 1, _stream()) != 0
 
@@ -569,6 +587,14 @@ def test_conv_pair_equals_two_convs(shape):
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     assert torch.equal(got, want[:, :C2])
+    # output and residual as channel-tile planes (RSG_LAYOUT_*): the same bits
+    out_p = torch.full((C2 // 32, B, H, W, 32), float("nan"), dtype=torch.float16, device=DEV)
+    rin_p = _to_planes(rin[..., :C2].contiguous())
+    d.layout = hip.RSG_LAYOUT_OUT_PLANES | hip.RSG_LAYOUT_RES_PLANES
+    hip.check(lib.rsg_conv_pair(C.byref(d), wp2.data_ptr(), b2.data_ptr(), C2, rin_p.data_ptr(), 32, out_p.data_ptr(), 32, 1,
+                                _stream()), "conv_pair(planes)")
+    torch.cuda.synchronize()
+    assert torch.equal(_from_planes(out_p, B, H, W, C2), out)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 48), (3, 13, 9), (1, 96, 72), (1, 5, 70)], ids=str)
@@ -627,6 +653,25 @@ def test_conv_pair_next_equals_pair_plus_conv1(shape):
     err = (got_t - want_t).abs().max().item()
     assert err <= 2 ** -9 * want_t.abs().max().item(), (err, want_t.abs().max().item())
     assert (got_t != want_t).float().mean().item() < 0.05           # and only the odd last bit at that
+    # the same launch with the block output and the residual stored as channel-tile planes (RSG_LAYOUT_*): same bits
+    out_p = torch.full((256 // 32, B, H, W, 32), float("nan"), dtype=torch.float16, device=DEV)
+    tn_p = torch.full((B, H, W, 64), float("nan"), dtype=torch.float16, device=DEV)
+    rin_p = _to_planes(rin)
+    d.layout = hip.RSG_LAYOUT_OUT_PLANES | hip.RSG_LAYOUT_RES_PLANES
+    hip.check(lib.rsg_conv_pair_next(C.byref(d), wp2.data_ptr(), b2.data_ptr(), rin_p.data_ptr(), 32, out_p.data_ptr(), 32,
+                                     wp3.data_ptr(), b3.data_ptr(), tn_p.data_ptr(), 64, None, 0, _stream()), "conv_pair_next(planes)")
+    torch.cuda.synchronize()
+    assert torch.equal(_from_planes(out_p, B, H, W, 256), out) and torch.equal(tn_p, tn)
+    # mixed: dense residual, output in planes
+    out_p.fill_(float("nan"))
+    d.layout = hip.RSG_LAYOUT_OUT_PLANES
+    hip.check(lib.rsg_conv_pair_next(C.byref(d), wp2.data_ptr(), b2.data_ptr(), rin.data_ptr(), 256, out_p.data_ptr(), 32,
+                                     wp3.data_ptr(), b3.data_ptr(), tn_p.data_ptr(), 64, None, 0, _stream()), "conv_pair_next(planes out)")
+    torch.cuda.synchronize()
+    assert torch.equal(_from_planes(out_p, B, H, W, 256), out)
+    # a planes map has a pixel stride of 32: anything else is refused
+    assert lib.rsg_conv_pair_next(C.byref(d), wp2.data_ptr(), b2.data_ptr(), rin.data_ptr(), 256, out_p.data_ptr(), 256,
+                                  wp3.data_ptr(), b3.data_ptr(), tn_p.data_ptr(), 64, None, 0, _stream()) != 0
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 48), (3, 13, 9), (1, 5, 70)], ids=str)
