@@ -93,13 +93,19 @@ class FusedAdam(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         active: List[bool] = []
+        ptrs = getattr(self, "_grad_ptrs", None)
+        if ptrs is None or self._grad_ptrs_base != self.flat_grad.data_ptr():      # address of every parameter's slice of the
+            base = self.flat_grad.data_ptr()                                        # flat gradient buffer, computed once
+            ptrs = self._grad_ptrs = [base + 4 * o for o in self._offsets]
+            self._grad_ptrs_base = base
         for i, p in enumerate(self._params):
-            view = self._view(self.flat_grad, i)
-            if p.grad is None:                          # torch.optim.Adam skips it: so do we
+            gr = p.grad
+            if gr is None:                              # torch.optim.Adam skips it: so do we
                 active.append(False)
                 continue
-            if p.grad.data_ptr() != view.data_ptr():    # a backward replaced .grad by a fresh tensor: fold it back in
-                view.copy_(p.grad)
+            if gr.data_ptr() != ptrs[i]:                # a backward replaced .grad by a fresh tensor: fold it back in
+                view = self._view(self.flat_grad, i)
+                view.copy_(gr)
                 p.grad = view
             active.append(True)
         lib = hip.lib()
