@@ -91,6 +91,13 @@ int rsg_conv_igemm(const rsg_conv_desc* d, void* stream);
  * out16: [batch, h/4, w/4, out_ld] 16-bit NHWC, 64 channels written; h, w = input picture size (multiples of 4). */
 int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1, const void* w2_packed, const float* bias2,
                    void* out16, int32_t out_ld, int32_t batch, int32_t h, int32_t w, int32_t dtype, void* stream);
+/* rsg_stem_fused + conv1 of the first Bottleneck (pose_hrnet.py:85-87 of layer1.0: 1x1, 64 -> 64, BatchNorm folded, ReLU) on the
+ * stem's output in the same launch (its input pixel is complete in the workgroup that produced it: the 64-channel map is
+ * not read back and one launch goes).  w3/bias3 from rsg_pack_conv_weights_host(cin 64, cout 64, 1x1); out3: [batch, h/4,
+ * w/4, out3_ld] 16-bit.  Bit-identical to rsg_stem_fused followed by rsg_conv_igemm. */
+int rsg_stem_fused_conv1(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1, const void* w2_packed,
+                         const float* bias2, void* out16, int32_t out_ld, const void* w3_packed, const float* bias3, void* out3,
+                         int32_t out3_ld, int32_t batch, int32_t h, int32_t w, int32_t dtype, void* stream);
 /* Bottleneck conv2 -> conv3 (pose_hrnet.py:93-101) in one launch: `inner` = the 3x3 stride-1 conv with 64 output
  * channels (BatchNorm folded, ReLU; its out16 / residual / relu fields are ignored), then a 1x1 conv to tail_out_c
  * channels (weights from rsg_pack_conv_weights_host with kh = kw = 1, cin = 64) + residual + optional ReLU.  The

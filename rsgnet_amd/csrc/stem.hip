@@ -19,6 +19,12 @@ struct StemArgs {
     char* out;                 // NHWC16 [B, H2, W2, ldo] (+ channel offset folded into the pointer)
     int B, H1, W1, H2, W2, ldo;
     int tiles_x, tiles_y;
+    // optional tail: a 1x1 conv 64 -> 64 (+BN, ReLU) on the stem's output in the same launch (layer1.0.conv1,
+    // pose_hrnet.py:85-87): its input pixel is complete in this workgroup, so the 25 MB map is not read back
+    const uint4* w3;           // packed (CINB 64: KS = 4), or null
+    const float* b3;
+    char* out3;                // NHWC16 [B, H2, W2, ldo3]
+    int ldo3;
 };
 
 template <class DT, int TH2, int TW2>
@@ -189,17 +195,55 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
         for (int g = 0; g < NT2; ++g) acc2[g] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks % NB][g]), acc2[g]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    // the s2d window is dead since the barrier behind conv1: its space takes the output tile for the tail, [pixel slot][64 ch]
+    char* const sT = sS;
+    static_assert(2 * NT2 * 32 * PS1 <= RS * RPS, "the tail's tile fits the s2d window");
 #pragma unroll
     for (int g = 0; g < NT2; ++g) {
         const int q = (wn * NT2 + g) * 32 + n;
         const int py = q / TW2, px = q - py * TW2;
-        if (q >= TH2 * TW2 || y2 + py >= p.H2 || x2 + px >= p.W2) continue;
+        const bool ok = q < TH2 * TW2 && y2 + py < p.H2 && x2 + px < p.W2;
         char* dst = p.out + ((((size_t)b * p.H2 + y2 + py) * p.W2 + x2 + px) * p.ldo + cbase) * 2;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             f32x8 f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = acc2[g][k * 8 + e];
+            const uint4 v = __builtin_bit_cast(uint4, DT::relu_pack(f));
+            if (ok) *reinterpret_cast<uint4*>(dst + k * 16) = v;
+            if (p.w3) *reinterpret_cast<uint4*>(sT + q * PS1 + (cbase + k * 8) * 2) = v;
+        }
+    }
+    if (!p.w3) return;
+    // ---- tail: 1x1 conv over the 64 channels of the tile's pixels (K = 64: 4 k-steps), BN folded, ReLU -------------------
+    uint4 a3[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a3[k] = p.w3[((size_t)wm * 4 + k) * 64 + lane];
+    float4 bv3[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) bv3[r4] = *reinterpret_cast<const float4*>(p.b3 + cbase + r4 * 4);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NT2; ++g) {
+        const int q = (wn * NT2 + g) * 32 + n;
+        f32x16 acc3;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            acc3[r4 * 4 + 0] = bv3[r4].x; acc3[r4 * 4 + 1] = bv3[r4].y; acc3[r4 * 4 + 2] = bv3[r4].z; acc3[r4 * 4 + 3] = bv3[r4].w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 bq3 = *reinterpret_cast<const uint4*>(sT + q * PS1 + k * 32 + hh * 16);
+            acc3 = DT::mfma(__builtin_bit_cast(typename DT::vec8, a3[k]), __builtin_bit_cast(typename DT::vec8, bq3), acc3);
+        }
+        const int py = q / TW2, px = q - py * TW2;
+        if (q >= TH2 * TW2 || y2 + py >= p.H2 || x2 + px >= p.W2) continue;
+        char* dst = p.out3 + ((((size_t)b * p.H2 + y2 + py) * p.W2 + x2 + px) * p.ldo3 + cbase) * 2;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x8 f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = acc3[k * 8 + e];
             *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, DT::relu_pack(f));
         }
     }
@@ -209,10 +253,12 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
 // [batch, 3, h, w] itself (then the layout conversion happens while staging and needs no launch); w1/b1: the 2x2 s2d form of conv1 packed with
 // rsg_pack_conv_weights_host(cin 16, cout 64, 2x2); w2/b2: conv2 packed (cin 64, cout 64, 3x3); out16: [batch, h/4,
 // w/4, out_ld] 16-bit NHWC (64 channels written).  h, w: the INPUT picture size (multiples of 4).
-extern "C" int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1, const void* w2_packed,
-                              const float* bias2, void* out16, int32_t out_ld, int32_t batch, int32_t h, int32_t w,
-                              int32_t dtype, void* stream) {
+static int stem_launch(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1, const void* w2_packed,
+                       const float* bias2, void* out16, int32_t out_ld, const void* w3_packed, const float* bias3, void* out3,
+                       int32_t out3_ld, int32_t batch, int32_t h, int32_t w, int32_t dtype, void* stream) {
     if ((!xs && !x_nchw_f32) || !w1_packed || !bias1 || !w2_packed || !bias2 || !out16) RSG_FAIL("stem_fused: null pointer");
+    if (w3_packed && (!bias3 || !out3 || out3_ld < 64 || (out3_ld & 7) || (((uintptr_t)w3_packed | (uintptr_t)bias3 | (uintptr_t)out3) & 15)))
+        RSG_FAIL("stem_fused: the tail needs bias, a 16-byte aligned output and out3_ld >= 64");
     if ((uintptr_t)x_nchw_f32 & 7) RSG_FAIL("stem_fused: the picture must be 8-byte aligned");
     if (batch < 1 || h < 4 || w < 4 || (h & 3) || (w & 3) || out_ld < 64 || (out_ld & 7)) RSG_FAIL("stem_fused: bad shape");
     if (((uintptr_t)xs | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)out16) & 15) RSG_FAIL("stem_fused: alignment");
@@ -220,6 +266,7 @@ extern "C" int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const voi
     StemArgs a;
     a.xs = (const char*)xs; a.x32 = xs ? nullptr : x_nchw_f32; a.w1 = (const uint4*)w1_packed; a.b1 = bias1; a.w2 = (const uint4*)w2_packed; a.b2 = bias2;
     a.out = (char*)out16; a.B = batch; a.H1 = h / 2; a.W1 = w / 2; a.H2 = h / 4; a.W2 = w / 4; a.ldo = out_ld;
+    a.w3 = (const uint4*)w3_packed; a.b3 = bias3; a.out3 = (char*)out3; a.ldo3 = out3_ld;
     a.tiles_x = ceil_div(a.W2, TW2); a.tiles_y = ceil_div(a.H2, TH2);
     const int lds = (2 * TH2 + 2) * (2 * TW2 + 2) * 48 + (2 * TH2 + 1) * (2 * TW2 + 1) * 144;
     const dim3 grid(batch * a.tiles_x * a.tiles_y);
@@ -227,4 +274,23 @@ extern "C" int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const voi
     else RSG_LAUNCH((stem_kernel<F16, TH2, TW2>), grid, dim3(256), lds, (hipStream_t)stream, a);
     RSG_CHECK_LAUNCH("stem_fused");
     return 0;
+}
+
+extern "C" int rsg_stem_fused(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1, const void* w2_packed,
+                              const float* bias2, void* out16, int32_t out_ld, int32_t batch, int32_t h, int32_t w,
+                              int32_t dtype, void* stream) {
+    return stem_launch(xs, x_nchw_f32, w1_packed, bias1, w2_packed, bias2, out16, out_ld, nullptr, nullptr, nullptr, 0, batch, h, w,
+                       dtype, stream);
+}
+
+// rsg_stem_fused + the first Bottleneck's conv1 (pose_hrnet.py:85-87 of layer1.0: 1x1, 64 -> 64, BatchNorm folded, ReLU) on the
+// stem's output in the same launch; w3/b3 from rsg_pack_conv_weights_host(cin 64, cout 64, 1x1); out3: [batch, h/4, w/4, out3_ld].
+// Bit-identical to rsg_stem_fused followed by rsg_conv_igemm.
+extern "C" int rsg_stem_fused_conv1(const void* xs, const float* x_nchw_f32, const void* w1_packed, const float* bias1,
+                                    const void* w2_packed, const float* bias2, void* out16, int32_t out_ld, const void* w3_packed,
+                                    const float* bias3, void* out3, int32_t out3_ld, int32_t batch, int32_t h, int32_t w,
+                                    int32_t dtype, void* stream) {
+    if (!w3_packed) RSG_FAIL("stem_fused_conv1: null pointer");
+    return stem_launch(xs, x_nchw_f32, w1_packed, bias1, w2_packed, bias2, out16, out_ld, w3_packed, bias3, out3, out3_ld, batch, h, w,
+                       dtype, stream);
 }

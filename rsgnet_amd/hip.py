@@ -86,6 +86,7 @@ SYMBOLS = {
     "rsg_tune": (C.c_int, [C.c_char_p, _i]),
     "rsg_conv_igemm": (C.c_int, [C.POINTER(ConvDesc), _vp]),
     "rsg_stem_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsg_stem_fused_conv1": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_conv_dual": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsg_conv_pair": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     "rsg_conv_pair_next_perm": (C.c_int32, [_i]),

@@ -1104,28 +1104,40 @@ class _BackboneMixin:
         return self.conv(xs, w2, m.bn1, m.conv1.bias, relu=True, pad=(1, 1), out_hw=(H // 2, W // 2),
                          name="conv1(s2d 2x2)")
 
-    def stem_to(self: Plan, m, out: Optional[VT]) -> VT:
-        """Record the fused stem (rsg_stem_fused) writing conv2's output into ``out`` (a 64-channel view) or a new map."""
+    def stem_to(self: Plan, m, out: Optional[VT], tail=None):
+        """Record the fused stem (rsg_stem_fused) writing conv2's output into ``out`` (a 64-channel view) or a new map.
+        tail = (conv, bn): the first Bottleneck's 1x1 conv1 (64 -> 64, BN, ReLU) on that output in the same launch
+        (rsg_stem_fused_conv1); returns (stem output, conv1 output) then."""
         xs, (wp1, b1), H, W = self._stem
         s2, h2 = self.bn_fold(m.bn2)
         wp2, b2 = self.pack_conv(m.conv2.weight, s2, h2, m.conv2.bias)[:2]
         if out is None:
             out = self.new(H // 4, W // 4, 64, name="stem")
         lib, B, dt = self.lib, self.batch, self.dtype
+        t3 = None
+        if tail is not None:
+            s3, h3 = self.bn_fold(tail[1])
+            wp3, b3 = self.pack_conv(tail[0].weight, s3, h3, tail[0].bias)[:2]
+            t3 = self.new(H // 4, W // 4, 64, name="layer1.0.conv1")
+        name = "stem(conv1+conv2)" + ("+layer1.0.conv1" if tail is not None else "")
 
         def make():
-            args = (wp1.data_ptr(), b1.data_ptr(), wp2.data_ptr(), b2.data_ptr(), out.ptr(), out.ld, B, H, W, dt)
+            args = (wp1.data_ptr(), b1.data_ptr(), wp2.data_ptr(), b2.data_ptr(), out.ptr(), out.ld)
+            if t3 is not None:
+                args += (wp3.data_ptr(), b3.data_ptr(), t3.ptr(), t3.ld)
+            args += (B, H, W, dt)
+            fn = lib.rsg_stem_fused_conv1 if t3 is not None else lib.rsg_stem_fused
             src = xs.ptr() if xs is not None else None
 
             def launch(stream):       # without an s2d map the kernel reads the CALLER's picture (self._x_src)
-                hip.check(lib.rsg_stem_fused(src, None if src else self._x_src, *args, stream), "stem_fused")
+                hip.check(fn(src, None if src else self._x_src, *args, stream), "stem_fused")
             return launch
 
-        self.custom("stem(conv1+conv2)", [xs] if xs is not None else [], [out], make)
-        fl = 2 * B * ((H // 2) * (W // 2) * 64 * 27 + (H // 4) * (W // 4) * 64 * 64 * 9)
+        self.custom(name, [xs] if xs is not None else [], [out, t3], make)
+        fl = 2 * B * ((H // 2) * (W // 2) * 64 * 27 + (H // 4) * (W // 4) * 64 * 64 * (9 + (1 if tail is not None else 0)))
         self.flops += fl
-        self.conv_log.append(dict(name="stem(conv1+conv2)", flops=float(fl)))
-        return out
+        self.conv_log.append(dict(name=name, flops=float(fl)))
+        return out if tail is None else (out, t3)
 
     def _transition1_dual(self: Plan, ys: List[VT], trans) -> bool:
         """transition1 as ONE launch (rsg_conv_dual): both new branches start with a 3x3 conv of the same 256-channel map."""
@@ -1426,8 +1438,13 @@ class _BackboneMixin:
                 and m.conv2.out_channels == 64 and os.environ.get("RSGNET_HIP_PAIR_CAT", "1") != "0":
             # layer1.0 in TWO launches: conv1, then conv2 -> [conv3 | projected residual] as one K = 128 contraction over
             # [conv2 output | x] -> conv1 of layer1.1, all from LDS (rsg_conv_pair_next with cat_x)
-            xs = self.stem_to(m, None) if x is None else self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
-            t = self._unit(xs, b0.conv1, b0.bn1, relu=True, name="layer1.0.conv1")
+            stem_tail = x is None and os.environ.get("RSGNET_HIP_STEM_TAIL", "1") != "0" and b0.conv1.kernel_size == (1, 1) \
+                and b0.conv1.in_channels == 64 and b0.conv1.out_channels == 64 and b0.conv1.bias is None
+            if stem_tail:      # layer1.0.conv1 rides on the stem's launch
+                xs, t = self.stem_to(m, None, tail=(b0.conv1, b0.bn1))
+            else:
+                xs = self.stem_to(m, None) if x is None else self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
+                t = self._unit(xs, b0.conv1, b0.bn1, relu=True, name="layer1.0.conv1")
             s3, h3 = self.bn_fold(b0.bn3)
             sd, hd = self.bn_fold(b0.downsample[1])
             w3 = b0.conv3.weight.detach().float().cpu() * s3.view(-1, 1, 1, 1)

@@ -800,10 +800,34 @@ def test_stem_fused_equals_two_convs():
             with torch.no_grad():
                 outs[flag] = model(x.cuda()).cpu()
             names = [n for n, _ in list(model._plans.values())[0].ops]
-            assert ("stem(conv1+conv2)" in names) == (flag == "1")
+            assert any(n.startswith("stem(conv1+conv2)") for n in names) == (flag == "1")
         finally:
             os.environ.pop("RSGNET_HIP_STEM", None)
     assert torch.equal(outs["0"], outs["1"])
+
+
+def test_stem_tail_equals_stem_plus_conv1():
+    """rsg_stem_fused_conv1 (layer1.0's 1x1 conv1 on the stem's output in the stem's launch) against the stem launch followed
+    by the rsg_conv_igemm launch, bit for bit, through the model plan: RSGNET_HIP_STEM_TAIL=0/1 on the same weights and
+    input; the default plan has one launch fewer."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import load_case
+    outs, nops = {}, {}
+    for flag in ("0", "1"):
+        os.environ["RSGNET_HIP_STEM_TAIL"] = flag
+        try:
+            cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+            model = model.cuda()
+            with torch.no_grad():
+                outs[flag] = model(x.cuda()).cpu()
+            names = [n for n, _ in list(model._plans.values())[0].ops]
+            nops[flag] = len(names)
+            assert ("stem(conv1+conv2)+layer1.0.conv1" in names) == (flag == "1") and ("layer1.0.conv1" in names) == (flag == "0")
+        finally:
+            os.environ.pop("RSGNET_HIP_STEM_TAIL", None)
+    assert torch.equal(outs["0"], outs["1"]) and nops["1"] == nops["0"] - 1
 
 
 def test_bottleneck_fused_through_the_plan():
