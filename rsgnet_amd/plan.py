@@ -1218,8 +1218,11 @@ class _BackboneMixin:
             return self._unit(y, blk.conv3, blk.bn3, relu=True, residual=res, name=name + ".conv3")
         return self._unit(y, blk.conv2, blk.bn2, relu=True, residual=res, name=name + ".conv2")
 
-    def _hr_module(self: Plan, xs: List[VT], mod, name: str) -> List[VT]:
-        """HighResolutionModule.forward (pose_hrnet.py:250-268)."""
+    def _hr_module(self: Plan, xs: List[VT], mod, name: str, rider=None) -> List[VT]:
+        """HighResolutionModule.forward (pose_hrnet.py:250-268).  rider(y_last): records ops that read only the module's
+        LAST output; when that output is finished one fuse level before the module's final launch (its sum rides on a conv of
+        the previous level), they are recorded INTO that final launch and the result is kept in self._rider_out."""
+        self._rider_out = None
         xs = list(xs)
         # branches: LDS-resident chains, grouped so that ONE launch runs every branch of the module
         # (longest chain first); a branch that needs row tiles contributes its blocks slice by slice
@@ -1410,6 +1413,9 @@ class _BackboneMixin:
                     same = [cur[(i, j)] for j in range(i)] + [xs[i]]
                     low = [(cur[(i, j)], j - i) for j in range(i + 1, len(xs))]
                     outs[i] = self.fuse(same, low, name=f"{name}.fuse.{i}")
+            if rider is not None and self._rider_out is None and outs[last] is not None and fold_into is not None \
+                    and level > depth[fold_into] - 1 and os.environ.get("RSGNET_HIP_TRANS_RIDE", "1") != "0":
+                self._rider_out = rider(outs[last])       # y_last was finished by an EARLIER launch: independent of this one
             self.end_group(f"{name}.fuse.level{level}")
         return outs
 
@@ -1499,6 +1505,7 @@ class _BackboneMixin:
                 x = self._residual_block(x, rest[k], f"layer1.{k0 + k}")
                 k += 1
         ys = [x]
+        ridden = None               # a transition conv already recorded inside the previous stage's last fuse launch
         for s in (2, 3, 4):
             trans = getattr(m, f"transition{s - 1}")
             xs = []
@@ -1509,14 +1516,25 @@ class _BackboneMixin:
                 if i < len(ys):
                     xs.append(ys[i] if tr is None else self._unit(ys[i], tr[0], tr[1], relu=True,
                                                                   name=f"transition{s - 1}.{i}"))
+                elif ridden is not None and i == len(ys) and len(tr) == 1:
+                    xs.append(ridden)                  # already recorded inside the previous module's last fuse launch
                 else:
                     t = ys[-1]
                     with self.on_lane(i):
                         for j, step in enumerate(tr):
                             t = self._unit(t, step[0], step[1], relu=True, name=f"transition{s - 1}.{i}.{j}")
                     xs.append(t)
-            for k, mod in enumerate(getattr(m, f"stage{s}")):
-                xs = self._hr_module(xs, mod, f"stage{s}.{k}")
+            mods = list(getattr(m, f"stage{s}"))
+            ridden = None
+            for k, mod in enumerate(mods):
+                rider = None
+                nxt = getattr(m, f"transition{s}", None) if k == len(mods) - 1 and s < 4 else None
+                if nxt is not None and len(nxt) == len(xs) + 1 and nxt[-1] is not None and len(nxt[-1]) == 1 \
+                        and all(t is None for t in list(nxt)[:-1]):
+                    step = nxt[-1][0]                  # the next stage's new branch: ONE strided conv of this stage's last output
+                    rider = lambda y, step=step, s=s, nb=len(xs): self._unit(y, step[0], step[1], relu=True, name=f"transition{s}.{nb}.0")
+                xs = self._hr_module(xs, mod, f"stage{s}.{k}", rider=rider)
+                ridden = self._rider_out
             ys = xs
         return ys
 
