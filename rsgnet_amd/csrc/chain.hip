@@ -643,23 +643,18 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
             if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6>(g.a[i], bid, smem, pf);
-            else chain_body<DT, 32, 1, 8, 7, false, std::is_same<DT, F16>::value ? RSG_CHAIN_HELD32 : 0>(g.a[i], bid, smem, pf);
+            else chain_body<DT, 32, 1, 8, 7, false, RSG_CHAIN_HELD32>(g.a[i], bid, smem, pf);
             break;
-        case 64:     // bf16 has no packed max: its ReLU epilogue needs the registers the held block input would take
-            chain_body<DT, 64, 2, 4, 6, false, std::is_same<DT, F16>::value ? RSG_CHAIN_HELD64 : 0>(g.a[i], bid, smem, pf);
+        case 64:
+            chain_body<DT, 64, 2, 4, 6, false, RSG_CHAIN_HELD64>(g.a[i], bid, smem, pf);
             break;
         case 128:  // 16x12 maps: one image = 6 pixel groups over 2 wave columns; two images per workgroup = 12
-            // fp16: FOUR waves (one per SIMD, six pixel groups each; waves 4-7 leave at once) -- half the weight-fragment
-            // loads, one wave per matrix pipe; same-visit A/B 1.774 -> 1.743 ms (profiles/r02m_ab_w4_c128.txt).  bf16
-            // (fp32 ReLU epilogue) does not fit six groups in 256 registers and keeps 8 waves x 3 groups.
-            if constexpr (std::is_same<DT, F16>::value) {
-                if (threadIdx.x >= 256) return;
-                if (g.a[i].dual) chain_body<DT, 128, 4, 1, 6, true>(g.a[i], bid, smem, pf);
-                else chain_body<DT, 128, 4, 1, 6>(g.a[i], bid, smem, pf);
-            } else {
-                if (g.a[i].dual) chain_body<DT, 128, 4, 2, 3, true>(g.a[i], bid, smem, pf);
-                else chain_body<DT, 128, 4, 2, 3>(g.a[i], bid, smem, pf);
-            }
+            // FOUR waves (one per SIMD, six pixel groups each; waves 4-7 leave at once) -- half the weight-fragment
+            // loads, one wave per matrix pipe; same-visit A/B 1.774 -> 1.743 ms (profiles/r02m_ab_w4_c128.txt).  bf16 too
+            // since its ReLU epilogue is packed (BF16::relu_pack; with the fp32 ReLU six groups did not fit 256 registers).
+            if (threadIdx.x >= 256) return;
+            if (g.a[i].dual) chain_body<DT, 128, 4, 1, 6, true>(g.a[i], bid, smem, pf);
+            else chain_body<DT, 128, 4, 1, 6>(g.a[i], bid, smem, pf);
             break;
         case 256:   // NT follows the pixels a workgroup owns (1 image = 48 px = 2 groups, 2 images = 3 groups)
             if (g.a[i].NI * g.a[i].R * g.a[i].W <= 64) {

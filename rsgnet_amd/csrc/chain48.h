@@ -33,10 +33,10 @@ template <> struct Mfma16<F16> {
 };
 template <> struct Mfma16<BF16> {
     static __device__ __forceinline__ f32x4 run(b8_t a, b8_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ uint2 relu_pack(f32x4 v) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        return __builtin_bit_cast(uint2, __builtin_convertvector(v, b4_t));
+    static __device__ __forceinline__ uint2 relu_pack(f32x4 v) {       // see BF16::relu_pack (common.h)
+        typedef short s4_t __attribute__((ext_vector_type(4)));
+        const s4_t z = {0, 0, 0, 0};
+        return __builtin_bit_cast(uint2, __builtin_elementwise_max(__builtin_bit_cast(s4_t, __builtin_convertvector(v, b4_t)), z));
     }
     static __device__ __forceinline__ f32x4 widen(uint2 v) { return __builtin_convertvector(__builtin_bit_cast(b4_t, v), f32x4); }
 };

@@ -76,10 +76,13 @@ struct BF16 {
     }
     static __device__ __host__ __forceinline__ float to_f32(elem v) { return (float)v; }
     static __device__ __host__ __forceinline__ elem from_f32(float v) { return (elem)v; }
-    static __device__ __forceinline__ vec8 relu_pack(f32x8 v) {      // no packed bf16 max on gfx950: ReLU in fp32
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        return __builtin_convertvector(v, vec8);
+    // ReLU of 8 fp32 values as bf16: round first (v_cvt_pk_bf16_f32), then v_pk_max_i16 with 0 on the bit patterns -- a
+    // negative bf16 is a negative int16 (sign bit), a non-negative one keeps its pattern; gfx950 has no packed bf16 max, but
+    // this costs what F16's v_pk_max_f16 costs.  max(round(x), 0) == round(max(x, 0)); -0 becomes +0 either way.
+    static __device__ __forceinline__ vec8 relu_pack(f32x8 v) {
+        typedef short s8_t __attribute__((ext_vector_type(8)));
+        const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        return __builtin_bit_cast(vec8, __builtin_elementwise_max(__builtin_bit_cast(s8_t, __builtin_convertvector(v, vec8)), z));
     }
 };
 
