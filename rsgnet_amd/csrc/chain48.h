@@ -218,7 +218,7 @@ __device__ __forceinline__ void chain48_body(const ChainArgs& p, const int block
                     rv[g][m] = make_uint2(t[0], t[1]);
                 }
             };
-            constexpr int LEAD = std::is_same<DT, F16>::value ? 2 : 1;      // bf16's fp32 ReLU epilogue has fewer registers to spare
+            constexpr int LEAD = 2;
 #pragma unroll
             for (int g = 0; g < LEAD; ++g) fetch(g);
 #pragma unroll
