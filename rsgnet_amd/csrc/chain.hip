@@ -28,6 +28,9 @@
 #ifndef RSG_CHAIN_HELD64
 #define RSG_CHAIN_HELD64 6
 #endif
+#ifndef RSG_CHAIN_HELD32_NT6
+#define RSG_CHAIN_HELD32_NT6 6     // the 32-row tiles (six pixel groups per wave): all of them
+#endif
 #ifndef RSG_CHAIN_HELD32
 #define RSG_CHAIN_HELD32 4
 #endif
@@ -642,7 +645,7 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     const int bid = rsg_xcd_tile(blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);   // an item's row bands of one image on one XCD
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
-            if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6>(g.a[i], bid, smem, pf);
+            if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6, false, RSG_CHAIN_HELD32_NT6>(g.a[i], bid, smem, pf);
             else chain_body<DT, 32, 1, 8, 7, false, RSG_CHAIN_HELD32>(g.a[i], bid, smem, pf);
             break;
         case 64:
