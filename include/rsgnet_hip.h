@@ -254,6 +254,13 @@ int rsg_nchw_f32_to_s2d_nhwc16(const float* in, void* out, int32_t batch, int32_
 int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const void* const* low,
                     const int32_t* low_shift, int32_t n_low, void* out, int32_t batch, int32_t h,
                     int32_t w, int32_t c, int32_t dtype, void* stream);
+/* The fuse sum of the highest-resolution output (as rsg_hr_fuse_sum: 32 channels, operand strides same_ld / low_ld in
+ * elements, 0 = dense) and the 1x1 classifier on it (pose_hrnet.py:326-332,461) in one launch: the summed map goes through
+ * LDS into the classifier's MFMAs and is never stored.  w_packed / bias: rsg_pack_conv_weights_host(cin 32, cout <= 32, 1x1)
+ * with the classifier's bias; out: fp32 [batch, cout, h, w].  Bit-identical to the sum followed by rsg_conv_igemm. */
+int rsg_fuse_classifier(const void* const* same, const int32_t* same_ld, int32_t n_same, const void* const* low,
+                        const int32_t* low_shift, const int32_t* low_ld, int32_t n_low, const void* w_packed, const float* bias,
+                        float* out_nchw_f32, int32_t batch, int32_t h, int32_t w, int32_t cout, int32_t dtype, void* stream);
 
 /* One launch for several INDEPENDENT ops of a module's fuse layers (pose_hrnet.py:190-268): up to 12
  * convolutions (descriptors as for rsg_conv_igemm; rsg_conv_groupable tells whether one can join a

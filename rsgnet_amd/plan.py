@@ -1412,6 +1412,10 @@ class _BackboneMixin:
                 if ready[i] == level:                    # every addend was finished by the previous level
                     same = [cur[(i, j)] for j in range(i)] + [xs[i]]
                     low = [(cur[(i, j)], j - i) for j in range(i + 1, len(xs))]
+                    if i == 0 and getattr(self, "_defer_sum0", None) == name and same[0].C == 32 and len(same) == 1:
+                        self._deferred_sum0 = (same, low)     # HRNetPlan: summed inside the classifier's launch
+                        outs[i] = xs[i]                       # (placeholder: the caller does not read it)
+                        continue
                     outs[i] = self.fuse(same, low, name=f"{name}.fuse.{i}")
             if rider is not None and self._rider_out is None and outs[last] is not None and fold_into is not None \
                     and level > depth[fold_into] - 1 and os.environ.get("RSGNET_HIP_TRANS_RIDE", "1") != "0":
@@ -1547,15 +1551,50 @@ class HRNetPlan(Plan, _BackboneMixin):
         W, H = model.cfg.MODEL.IMAGE_SIZE
         self.H, self.W = H, W
         J = model.cfg.MODEL.NUM_JOINTS
-        ys = self._record_backbone(model, H, W)
-        self.heat = torch.zeros(batch, J, H // 4, W // 4, dtype=torch.float32, device=device)
         fl = model.final_layer
         if fl.kernel_size != (1, 1):
             raise NotImplementedError("FINAL_CONV_KERNEL=3")
+        # the last module's only fuse sum (multi_scale_output = False) is evaluated inside the classifier's launch
+        # (rsg_fuse_classifier) when the highest-resolution branch has 32 channels: y0 is never stored
+        self._deferred_sum0 = None
+        n4 = len(model.stage4)
+        if os.environ.get("RSGNET_HIP_FUSE_CLASSIFIER", "1") != "0" and J <= 32 and fl.in_channels == 32 \
+                and model.stage4[n4 - 1].fuse_layers is not None and len(model.stage4[n4 - 1].fuse_layers) == 1:
+            self._defer_sum0 = f"stage4.{n4 - 1}"
+        ys = self._record_backbone(model, H, W)
+        self.heat = torch.zeros(batch, J, H // 4, W // 4, dtype=torch.float32, device=device)
         self.heat_slot = OutSlot(self.heat)
-        self.conv(ys[0], fl.weight, None, fl.bias, out_f32=self.heat_slot, want16=False, name="final_layer")
+        if self._deferred_sum0 is not None:
+            self._fuse_classifier(self._deferred_sum0, fl, J, H // 4, W // 4)
+        else:
+            self.conv(ys[0], fl.weight, None, fl.bias, out_f32=self.heat_slot, want16=False, name="final_layer")
         self.n_tail = 1
         self.finalize()
+
+    def _fuse_classifier(self, pending, fl, J: int, h: int, w: int):
+        same, low = pending
+        wp, bo = self.pack_conv(fl.weight, None, None, fl.bias)[:2]
+        lib, B, dt, slot = self.lib, self.batch, self.dtype, self.heat_slot
+
+        def make():
+            ns, nl = len(same), len(low)
+            sp = (C.c_void_p * 4)(*[v.ptr() for v in same])
+            sld = (C.c_int32 * 4)(*[v.ld for v in same])
+            lp = (C.c_void_p * 3)(*[v.ptr() for v, _ in low])
+            lsh = (C.c_int32 * 3)(*[sh for _, sh in low])
+            lld = (C.c_int32 * 3)(*[v.ld for v, _ in low])
+            self._keep += [sp, sld, lp, lsh, lld]
+
+            def launch(stream):
+                rc = lib.rsg_fuse_classifier(sp, sld, ns, lp, lsh, lld, nl, wp.data_ptr(), bo.data_ptr(), slot.ptr, B, h, w, J, dt, stream)
+                if rc:
+                    hip.check(rc, "final_layer")
+            return launch
+
+        self.custom("stage4.fuse.0+final_layer", list(same) + [v for v, _ in low], [], make)
+        fl_ops = 2 * B * h * w * J * 32
+        self.flops += fl_ops
+        self.conv_log.append(dict(name="stage4.fuse.0+final_layer", flops=float(fl_ops)))
 
     def run(self, x: torch.Tensor, clone: bool = True) -> torch.Tensor:
         if x.shape != self.x_static.shape:

@@ -1096,3 +1096,28 @@ def test_trp_relation_function_matches_materialised_autograd():
     print("  TrpRelation vs fp64:", {k: f"{v:.2e}" for k, v in errs.items()})
     assert errs["E"] < 3e-3 and errs["mse"] < 1e-4
     assert errs["dX"] < 2 ** -6 and errs["dW"] < 2 ** -6 and errs["db"] < 2 ** -6
+
+
+def test_fuse_classifier_equals_sum_then_conv():
+    """rsg_fuse_classifier (the last module's fuse sum inside the classifier's launch) against the fuse launch followed by
+    the rsg_conv_igemm launch, bit for bit, through the model plan: RSGNET_HIP_FUSE_CLASSIFIER=0/1 on the same weights and
+    input (batch 3: the last workgroup's pixels run past the map); one launch fewer."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import load_case
+    outs, nops = {}, {}
+    for flag in ("0", "1"):
+        os.environ["RSGNET_HIP_FUSE_CLASSIFIER"] = flag
+        try:
+            cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+            model = model.cuda()
+            x3 = torch.cat((x, x[:1] * 0.5)).cuda()
+            with torch.no_grad():
+                outs[flag] = model(x3).cpu()
+            names = [n for n, _ in list(model._plans.values())[0].ops]
+            nops[flag] = len(names)
+            assert ("stage4.fuse.0+final_layer" in names) == (flag == "1") and ("final_layer" in names) == (flag == "0")
+        finally:
+            os.environ.pop("RSGNET_HIP_FUSE_CLASSIFIER", None)
+    assert torch.isfinite(outs["1"]).all() and torch.equal(outs["0"], outs["1"]) and nops["1"] == nops["0"] - 1
