@@ -261,6 +261,15 @@ int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const void* const* 
 int rsg_fuse_classifier(const void* const* same, const int32_t* same_ld, int32_t n_same, const void* const* low,
                         const int32_t* low_shift, const int32_t* low_ld, int32_t n_low, const void* w_packed, const float* bias,
                         float* out_nchw_f32, int32_t batch, int32_t h, int32_t w, int32_t cout, int32_t dtype, void* stream);
+/* The whole fuse of the LAST HighResolutionModule (pose_hrnet.py:190-213,259-266 with multi_scale_output = False) and the
+ * classifier (:326-332,461) in one launch: the 1x1 convs (+BatchNorm) of the three lower branches on the rows a workgroup
+ * needs, the sum with x0, ReLU, the classifier.  x0: [batch,h,w,ld0], 32 channels; lows[j]: [batch, h>>(j+1), w>>(j+1),
+ * low_ld[j]], 64<<j channels; w_low / b_low: rsg_pack_conv_weights_host(cin 64<<j, cout 32, 1x1) with the BatchNorm folded;
+ * w_cls / b_cls: the classifier (cin 32, cout <= 32); out: fp32 [batch,cout,h,w].  h, w multiples of 8.  Bit-identical to
+ * rsg_conv_igemm x n_low + rsg_fuse_classifier. */
+int rsg_fuse_head4(const void* x0, int32_t ld0, const void* const* lows, const int32_t* low_ld, int32_t n_low,
+                   const void* const* w_low, const float* const* b_low, const void* w_cls, const float* b_cls,
+                   float* out_nchw_f32, int32_t batch, int32_t h, int32_t w, int32_t cout, int32_t dtype, void* stream);
 
 /* One launch for several INDEPENDENT ops of a module's fuse layers (pose_hrnet.py:190-268): up to 12
  * convolutions (descriptors as for rsg_conv_igemm; rsg_conv_groupable tells whether one can join a

@@ -1346,6 +1346,13 @@ class _BackboneMixin:
                         xs[b] = self.chain(xs[b], blks, f"{name}.branches.{b}.chain{k}")
         if mod.fuse_layers is None:
             return xs
+        # the LAST module of pose_hrnet (one output): its 1x1 convs, the sum and the classifier in one launch (HRNetPlan)
+        if getattr(self, "_defer_sum0", None) == name and os.environ.get("RSGNET_HIP_FUSE_HEAD4", "1") != "0" and not pre \
+                and len(mod.fuse_layers) == 1 and 2 <= len(xs) <= 4 and all(xs[j].C == 32 << j for j in range(len(xs))) \
+                and all(xs[j].coff == 0 for j in range(len(xs))) and xs[0].H % 8 == 0 and xs[0].W % 8 == 0 \
+                and all(mod.fuse_layers[0][j][0].kernel_size == (1, 1) and mod.fuse_layers[0][j][0].bias is None for j in range(1, len(xs))):
+            self._deferred_head4 = (list(xs), mod.fuse_layers[0])
+            return [xs[0]]
         # fuse layers, level by level: level k holds the k-th conv of every path (all 1x1 "up" convs and
         # the first strided conv of every "down" chain are level 0); the sum of output i can run once
         # its longest chain (i convs, from branch 0) is done.  One grouped launch per level.
@@ -1557,6 +1564,7 @@ class HRNetPlan(Plan, _BackboneMixin):
         # the last module's only fuse sum (multi_scale_output = False) is evaluated inside the classifier's launch
         # (rsg_fuse_classifier) when the highest-resolution branch has 32 channels: y0 is never stored
         self._deferred_sum0 = None
+        self._deferred_head4 = None
         n4 = len(model.stage4)
         if os.environ.get("RSGNET_HIP_FUSE_CLASSIFIER", "1") != "0" and J <= 32 and fl.in_channels == 32 \
                 and model.stage4[n4 - 1].fuse_layers is not None and len(model.stage4[n4 - 1].fuse_layers) == 1:
@@ -1564,12 +1572,43 @@ class HRNetPlan(Plan, _BackboneMixin):
         ys = self._record_backbone(model, H, W)
         self.heat = torch.zeros(batch, J, H // 4, W // 4, dtype=torch.float32, device=device)
         self.heat_slot = OutSlot(self.heat)
-        if self._deferred_sum0 is not None:
+        if self._deferred_head4 is not None:
+            self._fuse_head4(self._deferred_head4, fl, J)
+        elif self._deferred_sum0 is not None:
             self._fuse_classifier(self._deferred_sum0, fl, J, H // 4, W // 4)
         else:
             self.conv(ys[0], fl.weight, None, fl.bias, out_f32=self.heat_slot, want16=False, name="final_layer")
         self.n_tail = 1
         self.finalize()
+
+    def _fuse_head4(self, pending, fl, J: int):
+        """The last module's three 1x1 convs (+BatchNorm), its fuse sum and the classifier: rsg_fuse_head4."""
+        xs, row = pending
+        packs = []
+        for j in range(1, len(xs)):
+            sc, sh = self.bn_fold(row[j][1])
+            packs.append(self.pack_conv(row[j][0].weight, sc, sh, None)[:2])
+        wpc, boc = self.pack_conv(fl.weight, None, None, fl.bias)[:2]
+        lib, B, dt, slot = self.lib, self.batch, self.dtype, self.heat_slot
+        x0, h, w, nl = xs[0], xs[0].H, xs[0].W, len(xs) - 1
+
+        def make():
+            lp = (C.c_void_p * 3)(*[v.ptr() for v in xs[1:]])
+            lld = (C.c_int32 * 3)(*[v.ld for v in xs[1:]])
+            wl = (C.c_void_p * 3)(*[wp.data_ptr() for wp, _ in packs])
+            bl = (C.c_void_p * 3)(*[bo.data_ptr() for _, bo in packs])
+            self._keep += [lp, lld, wl, bl]
+
+            def launch(stream):
+                rc = lib.rsg_fuse_head4(x0.ptr(), x0.ld, lp, lld, nl, wl, bl, wpc.data_ptr(), boc.data_ptr(), slot.ptr, B, h, w, J, dt, stream)
+                if rc:
+                    hip.check(rc, "final_layer")
+            return launch
+
+        self.custom("stage4.fuse+final_layer", list(xs), [], make)
+        fl_ops = 2 * B * (h * w * J * 32 + sum((h >> j) * (w >> j) * 32 * (32 << j) for j in range(1, len(xs))))
+        self.flops += fl_ops
+        self.conv_log.append(dict(name="stage4.fuse+final_layer", flops=float(fl_ops)))
 
     def _fuse_classifier(self, pending, fl, J: int, h: int, w: int):
         same, low = pending

@@ -1098,26 +1098,31 @@ def test_trp_relation_function_matches_materialised_autograd():
     assert errs["dX"] < 2 ** -6 and errs["dW"] < 2 ** -6 and errs["db"] < 2 ** -6
 
 
-def test_fuse_classifier_equals_sum_then_conv():
-    """rsg_fuse_classifier (the last module's fuse sum inside the classifier's launch) against the fuse launch followed by
-    the rsg_conv_igemm launch, bit for bit, through the model plan: RSGNET_HIP_FUSE_CLASSIFIER=0/1 on the same weights and
-    input (batch 3: the last workgroup's pixels run past the map); one launch fewer."""
+def test_fuse_classifier_and_head4_equal_the_separate_launches():
+    """rsg_fuse_classifier (the last module's fuse sum inside the classifier's launch) and rsg_fuse_head4 (that module's 1x1
+    convs as well) against the separate launches (grouped 1x1 convs, fuse sum, rsg_conv_igemm classifier), bit for bit,
+    through the model plan on the same weights and input (batch 3: the last workgroup of the first form runs past the map)."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
     from util import load_case
     outs, nops = {}, {}
-    for flag in ("0", "1"):
-        os.environ["RSGNET_HIP_FUSE_CLASSIFIER"] = flag
+    forms = {"separate": ("0", "0", "final_layer"), "sum+classifier": ("1", "0", "stage4.fuse.0+final_layer"),
+             "module+classifier": ("1", "1", "stage4.fuse+final_layer")}
+    for form, (fc, h4, last) in forms.items():
+        os.environ["RSGNET_HIP_FUSE_CLASSIFIER"], os.environ["RSGNET_HIP_FUSE_HEAD4"] = fc, h4
         try:
             cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
             model = model.cuda()
             x3 = torch.cat((x, x[:1] * 0.5)).cuda()
             with torch.no_grad():
-                outs[flag] = model(x3).cpu()
+                outs[form] = model(x3).cpu()
             names = [n for n, _ in list(model._plans.values())[0].ops]
-            nops[flag] = len(names)
-            assert ("stage4.fuse.0+final_layer" in names) == (flag == "1") and ("final_layer" in names) == (flag == "0")
+            nops[form] = len(names)
+            assert names[-1] == last, (form, names[-3:])
         finally:
             os.environ.pop("RSGNET_HIP_FUSE_CLASSIFIER", None)
-    assert torch.isfinite(outs["1"]).all() and torch.equal(outs["0"], outs["1"]) and nops["1"] == nops["0"] - 1
+            os.environ.pop("RSGNET_HIP_FUSE_HEAD4", None)
+    assert torch.isfinite(outs["separate"]).all()
+    assert torch.equal(outs["separate"], outs["sum+classifier"]) and torch.equal(outs["separate"], outs["module+classifier"])
+    assert nops["sum+classifier"] == nops["separate"] - 1 and nops["module+classifier"] == nops["separate"] - 2
