@@ -27,7 +27,10 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
     constexpr int NTAPS = TAPH * TAPW;
     constexpr int PS = 2 * CINB + 16;    // LDS bytes per pixel (odd number of 16-B slots)
     constexpr int CPP = CINB / 8;        // 16-byte chunks per pixel
-    constexpr int NLD = 8;               // staging loads in flight per thread
+#ifndef RSG_CONV_NLD
+#define RSG_CONV_NLD 8
+#endif
+    constexpr int NLD = RSG_CONV_NLD;    // staging loads in flight per thread
     constexpr int KSB = NTAPS * KPT;     // k-steps per channel block
     constexpr int NPF = KSB < 6 ? KSB : 6;   // A-operand prefetch depth
 
