@@ -8,6 +8,8 @@ the *parameters*; every per-crop operation runs in librsgnet_hip.so.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -187,22 +189,29 @@ def record_rsgnet(p: Plan, model) -> None:
 
         p.custom("trp_tail", [p.e32], [rel], make_tail)
 
-    # ---- joints-of-target branch (:991-1000)
+    # ---- joints-of-target branch (:991-1000); the limbs branch = SGM (:1003-1005) is independent of it and of the TRP, so
+    # its two convs ride in this branch's launches (limbs_net beside kpt_net, the limb classifier beside the deconv phases)
+    ride = os.environ.get("RSGNET_HIP_LIMBS_RIDE", "1") != "0"
+    p.limbs_lo = torch.zeros(B, L, H4, W4, **f32)
+    p.begin_group()
     k = p._unit(cat2, model.kpt_net[0], model.kpt_net[1], relu=True, name="kpt_net")
+    lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net") if ride else None
+    p.end_group("kpt_net+limbs_net")
     dc, dbn = model.predict_convtranspose[0], model.predict_convtranspose[1]
     k2 = p.new(2 * H4, 2 * W4, c0, name="deconv")       # the four phases store exactly c0 channels
     p.begin_group()                                      # four independent sub-pixel convs: one launch
     for py, px, pad_y, pad_x, wph in deconv_phase_weights(dc.weight):
         p.conv(k, wph, dbn, None, relu=True, out=k2, pad=(pad_y, pad_x), up=(2, py, px),
                out_hw=(H4, W4), phys_hw=(2 * H4, 2 * W4), name=f"deconv.phase{py}{px}")
-    p.end_group("deconv")
+    if ride:
+        p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
+    p.end_group("deconv+limbs(sgm)" if ride else "deconv")
     k3 = p._unit(k2, model.predict_net[0], model.predict_net[1], relu=True, name="predict_net")
 
     # ---- limbs branch = SGM (:1003-1013)
     p.kpt = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
     p.multi_up = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
     p.limbs = torch.zeros(B, L, 2 * H4, 2 * W4, **f32)
-    p.limbs_lo = torch.zeros(B, L, H4, W4, **f32)
     from .plan import OutSlot
     p.kpt_slot, p.multi_slot, p.limbs_slot = OutSlot(p.kpt), OutSlot(p.multi_up), OutSlot(p.limbs)
 
@@ -210,9 +219,10 @@ def record_rsgnet(p: Plan, model) -> None:
         a = (src.data_ptr(), planes, H4, W4, sig)
         return lambda: (lambda s: hip.check(lib.rsg_bilinear2x_nchw_f32(a[0], slot.ptr, *a[1:], s), "bilinear2x"))
 
-    with p.on_lane(1):      # independent of TRP and the joints-of-target branch: its own stream
-        lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net")
-        p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
+    if not ride:
+        with p.on_lane(1):      # independent of TRP and the joints-of-target branch: its own stream
+            lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net")
+            p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
     # the three ops that write the model's outputs come last: they run eagerly behind the captured graph and write
     # straight into the tensors a forward hands out (Plan.n_tail, OutSlot)
     fl = model.final_layer
