@@ -270,6 +270,16 @@ int rsg_fuse_classifier(const void* const* same, const int32_t* same_ld, int32_t
 int rsg_fuse_head4(const void* x0, int32_t ld0, const void* const* lows, const int32_t* low_ld, int32_t n_low,
                    const void* const* w_low, const float* const* b_low, const void* w_cls, const float* b_cls,
                    float* out_nchw_f32, int32_t batch, int32_t h, int32_t w, int32_t cout, int32_t dtype, void* stream);
+/* The two highest-resolution outputs of a HighResolutionModule's fuse (pose_hrnet.py:190-268) in one launch:
+ *   y0 = ReLU(x0 + up(bn(conv1x1(x_j))), j >= 1),   y1 = ReLU(bn(conv3x3 s2(x0)) + x1 + up(bn(conv1x1(x_j))), j >= 2),
+ * row bands of 8 y0 rows with everything between the branch maps and the outputs in LDS.  xs[j]: branch j, [batch, h>>j,
+ * w>>j, ld[j]], 32<<j channels, j = 0..n_low (1..3); w_a0/b_a0 [n_low]: convs j -> 0 (cout 32); w_d10/b_d10: the strided
+ * conv 0 -> 1 (cout 64); w_a1/b_a1 [n_low-1]: convs j -> 1, j >= 2 (cout 64); packed by rsg_pack_conv_weights_host with the
+ * BatchNorm folded.  y0: [batch,h,w,ld_y0], y1: [batch,h/2,w/2,ld_y1].  h, w multiples of 8.  Bit-identical to the grouped
+ * conv launches + fuse sums it replaces. */
+int rsg_fuse_band(const void* const* xs, const int32_t* ld, int32_t n_low, const void* const* w_a0, const float* const* b_a0,
+                  const void* w_d10, const float* b_d10, const void* const* w_a1, const float* const* b_a1, void* y0,
+                  int32_t ld_y0, void* y1, int32_t ld_y1, int32_t batch, int32_t h, int32_t w, int32_t dtype, void* stream);
 
 /* One launch for several INDEPENDENT ops of a module's fuse layers (pose_hrnet.py:190-268): up to 12
  * convolutions (descriptors as for rsg_conv_igemm; rsg_conv_groupable tells whether one can join a

@@ -3,6 +3,7 @@
 // its 128 pixels (the operand order and the 16-bit rounding of rsg_hr_fuse_sum / fuse_body), goes to LDS and is the B
 // operand of the classifier's two k-steps; the heat maps leave as fp32 NCHW.  The 12.6 MB map y0 is neither written nor
 // read back, and one launch goes.  Bit-identical to rsg_conv_fuse_group_run (the sum) followed by rsg_conv_igemm.
+#include <type_traits>
 #include "fuse_body.h"
 
 struct FuseHeadArgs {
@@ -277,10 +278,294 @@ extern "C" int rsg_fuse_head4(const void* x0, int32_t ld0, const void* const* lo
     }
     if (lds > 150 * 1024) RSG_FAIL("fuse_head4: a %d-pixel-wide map needs %d B of LDS", w, lds);
     const void* fn = dtype == RSG_BF16 ? (const void*)fuse_head4_kernel<BF16> : (const void*)fuse_head4_kernel<F16>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) RSG_FAIL("fuse_head4: cannot reserve %d B of LDS", lds);
+    static int lds_set[2] = {0, 0};
+    if (lds_set[dtype == RSG_BF16] < lds) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) RSG_FAIL("fuse_head4: cannot reserve %d B of LDS", lds);
+        lds_set[dtype == RSG_BF16] = lds;
+    }
     const dim3 grid(batch * (h / 8));
     if (dtype == RSG_BF16) RSG_LAUNCH(fuse_head4_kernel<BF16>, grid, dim3(256), lds, (hipStream_t)stream, p);
     else RSG_LAUNCH(fuse_head4_kernel<F16>, grid, dim3(256), lds, (hipStream_t)stream, p);
     RSG_CHECK_LAUNCH("fuse_head4");
+    return 0;
+}
+
+// ---- the two highest-resolution outputs of ANY HighResolutionModule in one launch (pose_hrnet.py:190-268) -----------------
+//   y0 = ReLU(x0 + up2(a01) + up4(a02) + up8(a03)),            a0j = bn(conv1x1(x_j)), 32 channels
+//   y1 = ReLU(d10 + x1 + up2(a12) + up4(a13)),                 d10 = bn(conv3x3 stride 2 (x0)), a1j = bn(conv1x1(x_j)), 64 channels
+// These paths hold 90 % of a module's fuse bytes and 6 of its up to 12 convs (half of the grouped launches' workgroups),
+// but only 57 k weights, so a row band can afford to re-read them: a workgroup owns 8 rows of y0 = 4 rows of y1 and
+// stages 9 rows of x0 (one halo row above, a zero column left), 4 / 2 / 1 rows of x1 / x2 / x3.  The grouped launches keep
+// the deep paths (whose weights want whole batches per workgroup).  Arithmetic, operand order and the 16-bit rounding
+// points are those of the grouped convs and of fuse_body: bit-identical.
+struct FuseBandArgs {
+    const char* x[4]; int ld[4];              // x0 (32 ch) .. x3 (256 ch)
+    const uint4* w0[3]; const float* b0[3];   // a0j, j = 1..3: cin 64 << (j-1) -> 32
+    const uint4* wd; const float* bd;         // d10: 3x3 stride 2, 32 -> 64
+    const uint4* w1[2]; const float* b1[2];   // a1j, j = 2..3: cin 64 << (j-1) -> 64
+    char* y0; int ldy0;
+    char* y1; int ldy1;
+    int B, H, W, n_low;
+};
+
+template <class DT>
+__global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PS0 = 80, PS1 = 144;                          // LDS pixel pitch of 32- / 64-channel maps
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hh = lane >> 5;
+    const int tiles = p.H >> 3;
+    const int b = blockIdx.x / tiles, ty = blockIdx.x - b * tiles;
+    const int W = p.W, W1 = W >> 1, H1 = p.H >> 1;
+    // LDS map
+    const int RP0 = (W + 1) * PS0;                              // x0 rows: one zero pixel in front
+    char* const sx0 = smem;                                     // 9 rows: image rows 8 ty - 1 .. 8 ty + 7
+    int off = 9 * RP0;
+    int off_x[3], npx[3], psx[3], off_a0[3], off_a1[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        npx[j] = (8 >> (j + 1)) * (W >> (j + 1));
+        psx[j] = (64 << j) * 2 + 16;
+        off_x[j] = off;
+        if (j < p.n_low) off += npx[j] * psx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { off_a0[j] = off; if (j < p.n_low) off += npx[j] * PS0; }
+#pragma unroll
+    for (int j = 1; j < 3; ++j) { off_a1[j - 1] = off; if (j < p.n_low) off += npx[j] * PS1; }
+    // ---- 1. stage: x0 band (+ halo row, zero border) and the lower maps' rows ------------------------------------------
+    {
+        // loads in batches of 8 per thread, then the LDS writes (a load and its LDS write in one loop iteration serialise
+        // the iterations on the memory latency)
+        const int y_lo = ty * 8 - 1;
+        const int total0 = 9 * (W + 1) * 4;
+        for (int base = 0; base < total0; base += 256 * 8) {
+            uint4 v[8];
+            int lo[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int id = base + u * 256 + tid;
+                v[u] = make_uint4(0, 0, 0, 0);
+                lo[u] = -1;
+                if (id < total0) {
+                    const int cg = id & 3, pc = id >> 2;
+                    const int r = pc / (W + 1), c = pc - r * (W + 1);   // c = 0: the zero pixel at x = -1
+                    const int y = y_lo + r, x = c - 1;
+                    lo[u] = r * RP0 + c * PS0 + cg * 16;
+                    if (y >= 0 && x >= 0) v[u] = *reinterpret_cast<const uint4*>(p.x[0] + (((size_t)(b * p.H + y) * W + x) * p.ld[0] + cg * 8) * 2);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (lo[u] >= 0) *reinterpret_cast<uint4*>(sx0 + lo[u]) = v[u];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= p.n_low) break;
+            const int cpp = (64 << j) / 8;
+            const int rows = 8 >> (j + 1), wl = W >> (j + 1), hl = p.H >> (j + 1);
+            const char* src = p.x[j + 1] + ((size_t)(b * hl + ty * rows) * wl) * p.ld[j + 1] * 2;
+            const int total = npx[j] * cpp;
+            for (int base = 0; base < total; base += 256 * 4) {
+                uint4 v[4];
+                int lo[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int id = base + u * 256 + tid;
+                    lo[u] = -1;
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    if (id < total) {
+                        const int px = id / cpp, cg = id - px * cpp;
+                        lo[u] = off_x[j] + px * psx[j] + cg * 16;
+                        v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)px * p.ld[j + 1] + cg * 8) * 2);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lo[u] >= 0) *reinterpret_cast<uint4*>(smem + lo[u]) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2. the 1x1 convs on the staged lower maps: a0j (32 outputs) and a1j (64 outputs: two channel tiles) --------------
+    // one job = (conv, 32-pixel group, 32-channel tile); the jobs of ALL 1x1 convs go round the four waves together, and a
+    // job's weight fragments are all requested before its first MFMA (fetched one k-step at a time the 9 short jobs of
+    // a 4-branch module took 12 us of L2 latency per workgroup)
+    auto job1x1 = [&](auto ksn, const char* src, int ps, int np, const uint4* wpk, const float* bias, int g, int ct, char* dst, int psd) {
+        constexpr int KSN = decltype(ksn)::value;
+        const int q = g * 32 + n;
+        const char* px = src + (q < np ? q : 0) * ps + hh * 16;
+        uint4 a[KSN];
+        const uint4* wp = wpk + (size_t)ct * KSN * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) a[ks] = wp[ks * 64];
+        f32x16 acc;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + ct * 32 + hh * 16 + r4 * 4);
+            acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+            acc = DT::mfma(__builtin_bit_cast(typename DT::vec8, a[ks]),
+                           __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(px + ks * 32)), acc);
+        if (q < np) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = acc[k * 8 + e];
+                *reinterpret_cast<uint4*>(dst + q * psd + (ct * 32 + hh * 16 + k * 8) * 2) =
+                    __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+            }
+        }
+    };
+    {
+        int job = 0;                                            // running job number over all convs (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= p.n_low) break;
+            const int ng = (npx[j] + 31) >> 5;
+            for (int t = 0; t < ng * (j >= 1 ? 3 : 1); ++t, ++job) {
+                if ((job & 3) != wave) continue;
+                const bool to1 = t >= ng;                       // the conv j -> 1 (two channel tiles) after the conv j -> 0
+                const int g = to1 ? (t - ng) >> 1 : t, ct = to1 ? (t - ng) & 1 : 0;
+                const uint4* wpk = to1 ? p.w1[j - 1] : p.w0[j];
+                const float* bias = to1 ? p.b1[j - 1] : p.b0[j];
+                char* dst = smem + (to1 ? off_a1[j - 1] : off_a0[j]);
+                const int psd = to1 ? PS1 : PS0;
+                if (j == 0) job1x1(std::integral_constant<int, 4>{}, smem + off_x[0], psx[0], npx[0], wpk, bias, g, ct, dst, psd);
+                else if (j == 1) job1x1(std::integral_constant<int, 8>{}, smem + off_x[1], psx[1], npx[1], wpk, bias, g, ct, dst, psd);
+                else job1x1(std::integral_constant<int, 16>{}, smem + off_x[2], psx[2], npx[2], wpk, bias, g, ct, dst, psd);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 3. d10 (3x3, stride 2, pad 1, 32 -> 64) on the x0 band; epilogue = the fuse sum of output 1 ------------------------
+    {
+        const int np1 = 4 * W1;                                 // y1 pixels of the band
+        for (int job = wave; job < ((np1 + 31) >> 5) * 2; job += 4) {
+            const int g = job >> 1, ct = job & 1;
+            const int q = g * 32 + n;
+            const int qq = q < np1 ? q : 0;
+            const int py = qq / W1, px = qq - py * W1;
+            // input pixel of tap (ky, kx): image (8 ty + 2 py + ky - 1, 2 px + kx - 1) = tile (2 py + ky, 2 px + kx)
+            const char* src = sx0 + (2 * py) * RP0 + (2 * px) * PS0 + hh * 16;
+            f32x16 acc;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bd + ct * 32 + hh * 16 + r4 * 4);
+                acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
+            }
+            const uint4* wp = p.wd + (size_t)ct * 18 * 64 + lane;
+            uint4 ad[18];
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) ad[ks] = wp[ks * 64];
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) {                   // k order of the packed weights: tap-major, 16 channels per step
+                const int t = ks >> 1, c = ks & 1;
+                acc = DT::mfma(__builtin_bit_cast(typename DT::vec8, ad[ks]),
+                               __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(src + (t / 3) * RP0 + (t % 3) * PS0 + c * 32)), acc);
+            }
+            if (q >= np1) continue;
+            const int cb = ct * 32 + hh * 16;
+            const size_t opix = (size_t)(b * H1 + ty * 4 + py) * W1 + px;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = acc[k * 8 + e];
+                // the conv's own 16-bit result (what the grouped launch stores), then fuse_body's sum: same operands first
+                const typename DT::vec8 d16 = __builtin_convertvector(f, typename DT::vec8);
+                const typename DT::vec8 x1v = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(smem + off_x[0] + qq * psx[0] + (cb + k * 8) * 2));
+                // a module with two branches: output 1 is the LAST output, whose sum the grouped launch folds into the conv's
+                // epilogue (acc + x1 in fp32, no 16-bit stop in between: plan.py fold_into) -- the same here
+                float s[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] = p.n_low == 1 ? f[e] + (float)x1v[e] : (0.f + (float)d16[e]) + (float)x1v[e];
+#pragma unroll
+                for (int j = 1; j < 3; ++j) {
+                    if (j >= p.n_low) break;
+                    const typename DT::vec8 av = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(
+                        smem + off_a1[j - 1] + ((py >> j) * (W1 >> j) + (px >> j)) * PS1 + (cb + k * 8) * 2));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s[e] += (float)av[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = s[e];
+                *reinterpret_cast<uint4*>(p.y1 + (opix * p.ldy1 + cb + k * 8) * 2) = __builtin_bit_cast(uint4, DT::relu_pack(f));
+            }
+        }
+    }
+    // ---- 4. output 0: x0 + the up-sampled a0j (fuse_body) ----------------------------------------------------------------
+    for (int id = tid; id < 8 * W * 4; id += 256) {
+        const int pl = id >> 2, cg = id & 3;
+        const int y = pl / W, x = pl - y * W;
+        float acc[8];
+        {
+            const typename DT::vec8 v = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(sx0 + (y + 1) * RP0 + (x + 1) * PS0 + cg * 16));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f + (float)v[e];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= p.n_low) break;
+            const int s = j + 1;
+            const typename DT::vec8 v = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(
+                smem + off_a0[j] + ((y >> s) * (W >> s) + (x >> s)) * PS0 + cg * 16));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+        f32x8 f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = acc[e];
+        *reinterpret_cast<uint4*>(p.y0 + (((size_t)(b * p.H + ty * 8) * W + pl) * p.ldy0 + cg * 8) * 2) = __builtin_bit_cast(uint4, DT::relu_pack(f));
+    }
+}
+
+// xs[j] / ld[j]: branch j's map, [batch, h >> j, w >> j, ld[j]], 32 << j channels, j = 0 .. n_low.  w_a0 / b_a0 [n_low]: the 1x1
+// convs j -> 0 (cout 32); w_d10 / b_d10: the 3x3 stride-2 conv 0 -> 1 (cout 64); w_a1 / b_a1 [n_low - 1]: the 1x1 convs
+// j -> 1, j >= 2 (cout 64); all from rsg_pack_conv_weights_host with the BatchNorm folded.  y0: [batch,h,w,ld_y0] 32 channels,
+// y1: [batch,h/2,w/2,ld_y1] 64 channels.  h, w multiples of 8.
+extern "C" int rsg_fuse_band(const void* const* xs, const int32_t* ld, int32_t n_low, const void* const* w_a0, const float* const* b_a0,
+                             const void* w_d10, const float* b_d10, const void* const* w_a1, const float* const* b_a1, void* y0,
+                             int32_t ld_y0, void* y1, int32_t ld_y1, int32_t batch, int32_t h, int32_t w, int32_t dtype, void* stream) {
+    if (!xs || !ld || !w_a0 || !b_a0 || !w_d10 || !b_d10 || !y0 || !y1 || n_low < 1 || n_low > 3 || batch < 1) RSG_FAIL("fuse_band: bad arguments");
+    if ((h & 7) || (w & 7) || ld_y0 < 32 || (ld_y0 & 7) || ld_y1 < 64 || (ld_y1 & 7) || (((uintptr_t)y0 | (uintptr_t)y1 | (uintptr_t)w_d10 | (uintptr_t)b_d10) & 15))
+        RSG_FAIL("fuse_band: shape / alignment");
+    if ((long long)batch * h * w * ld[0] * 2 >= (1LL << 31)) RSG_FAIL("fuse_band: map too large");
+    FuseBandArgs p;
+    memset(&p, 0, sizeof(p));
+    p.B = batch; p.H = h; p.W = w; p.n_low = n_low; p.y0 = (char*)y0; p.ldy0 = ld_y0; p.y1 = (char*)y1; p.ldy1 = ld_y1;
+    p.wd = (const uint4*)w_d10; p.bd = b_d10;
+    int lds = 9 * (w + 1) * 80;
+    for (int j = 0; j <= n_low; ++j) {
+        const int c = 32 << j;
+        if (!xs[j] || ld[j] < c || (ld[j] & 7) || ((uintptr_t)xs[j] & 15)) RSG_FAIL("fuse_band: operand %d", j);
+        p.x[j] = (const char*)xs[j]; p.ld[j] = ld[j];
+    }
+    for (int j = 0; j < n_low; ++j) {
+        if (!w_a0[j] || !b_a0[j] || (((uintptr_t)w_a0[j] | (uintptr_t)b_a0[j]) & 15)) RSG_FAIL("fuse_band: weights of the 1x1 conv %d -> 0", j + 1);
+        p.w0[j] = (const uint4*)w_a0[j]; p.b0[j] = b_a0[j];
+        const int npx = (8 >> (j + 1)) * (w >> (j + 1));
+        lds += npx * ((64 << j) * 2 + 16) + npx * 80;
+        if (j >= 1) {
+            if (!w_a1 || !b_a1 || !w_a1[j - 1] || !b_a1[j - 1] || (((uintptr_t)w_a1[j - 1] | (uintptr_t)b_a1[j - 1]) & 15))
+                RSG_FAIL("fuse_band: weights of the 1x1 conv %d -> 1", j + 1);
+            p.w1[j - 1] = (const uint4*)w_a1[j - 1]; p.b1[j - 1] = b_a1[j - 1];
+            lds += npx * 144;
+        }
+    }
+    if (lds > 150 * 1024) RSG_FAIL("fuse_band: a %d-pixel-wide map needs %d B of LDS", w, lds);
+    const void* fn = dtype == RSG_BF16 ? (const void*)fuse_band_kernel<BF16> : (const void*)fuse_band_kernel<F16>;
+    static int lds_set[2] = {0, 0};                            // per dtype: the attribute call is host work on every launch otherwise
+    if (lds_set[dtype == RSG_BF16] < lds) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) RSG_FAIL("fuse_band: cannot reserve %d B of LDS", lds);
+        lds_set[dtype == RSG_BF16] = lds;
+    }
+    const dim3 grid(batch * (h / 8));
+    if (dtype == RSG_BF16) RSG_LAUNCH(fuse_band_kernel<BF16>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    else RSG_LAUNCH(fuse_band_kernel<F16>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    RSG_CHECK_LAUNCH("fuse_band");
     return 0;
 }

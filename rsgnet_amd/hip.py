@@ -128,6 +128,7 @@ SYMBOLS = {
     "rsg_hr_fuse_sum": (C.c_int, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _vp,
                                   _i, _i, _i, _i, _i, _vp]),
     "rsg_fuse_classifier": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "rsg_fuse_band": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_fuse_head4": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_flip_merge_nchw_f32": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_decode_heatmaps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

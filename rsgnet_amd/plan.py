@@ -1218,6 +1218,40 @@ class _BackboneMixin:
             return self._unit(y, blk.conv3, blk.bn3, relu=True, residual=res, name=name + ".conv3")
         return self._unit(y, blk.conv2, blk.bn2, relu=True, residual=res, name=name + ".conv2")
 
+    def _fuse_band(self: Plan, xs: List[VT], rows, name: str):
+        """Record rsg_fuse_band for a module: returns the new maps (y0, y1)."""
+        n_low = len(xs) - 1
+        a0 = [self.pack_conv(rows[0][j][0].weight, *self.bn_fold(rows[0][j][1]), None)[:2] for j in range(1, n_low + 1)]
+        d10 = self.pack_conv(rows[1][0][0][0].weight, *self.bn_fold(rows[1][0][0][1]), None)[:2]
+        a1 = [self.pack_conv(rows[1][j][0].weight, *self.bn_fold(rows[1][j][1]), None)[:2] for j in range(2, n_low + 1)]
+        y0 = self.new(xs[0].H, xs[0].W, 32, name=f"{name}.fuse.0")
+        y1 = self.new(xs[1].H, xs[1].W, 64, name=f"{name}.fuse.1")
+        lib, B, dt = self.lib, self.batch, self.dtype
+        h, w = xs[0].H, xs[0].W
+
+        def make():
+            xp = (C.c_void_p * 4)(*[v.ptr() for v in xs])
+            xl = (C.c_int32 * 4)(*[v.ld for v in xs])
+            w0 = (C.c_void_p * 3)(*[wp.data_ptr() for wp, _ in a0])
+            b0 = (C.c_void_p * 3)(*[bo.data_ptr() for _, bo in a0])
+            w1 = (C.c_void_p * 2)(*[wp.data_ptr() for wp, _ in a1])
+            b1 = (C.c_void_p * 2)(*[bo.data_ptr() for _, bo in a1])
+            self._keep += [xp, xl, w0, b0, w1, b1]
+            args = (xp, xl, n_low, w0, b0, d10[0].data_ptr(), d10[1].data_ptr(), w1, b1, y0.ptr(), y0.ld, y1.ptr(), y1.ld, B, h, w, dt)
+
+            def launch(stream):
+                rc = lib.rsg_fuse_band(*args, stream)
+                if rc:
+                    hip.check(rc, f"{name}.fuse.band")
+            return launch
+
+        self.custom(f"{name}.fuse.band", list(xs), [y0, y1], make)
+        fl = 2 * B * (sum((h >> j) * (w >> j) * (32 << j) * 32 for j in range(1, n_low + 1)) + (h // 2) * (w // 2) * 64 * 32 * 9
+                      + sum((h >> j) * (w >> j) * (32 << j) * 64 for j in range(2, n_low + 1)))
+        self.flops += fl
+        self.conv_log.append(dict(name=f"{name}.fuse.band", flops=float(fl)))
+        return y0, y1
+
     def _hr_module(self: Plan, xs: List[VT], mod, name: str, rider=None) -> List[VT]:
         """HighResolutionModule.forward (pose_hrnet.py:250-268).  rider(y_last): records ops that read only the module's
         LAST output; when that output is finished one fuse level before the module's final launch (its sum rides on a conv of
@@ -1367,9 +1401,30 @@ class _BackboneMixin:
                     done[(i, j)] = 1 if (i, j) in pre else 0
                     depth[(i, j)] = (1 if j > i else len(fl)) - done[(i, j)]
                     cur[(i, j)] = pre.get((i, j), xs[j])
-        max_depth = max(depth.values()) if depth else 0
         outs: List[Optional[VT]] = [None] * n_out
+        # OPT-IN (RSGNET_HIP_FUSE_BAND=1; measured SLOWER, profiles/r03_ab_fuse_band.txt): outputs 0 and 1 in ONE launch of their
+        # own (rsg_fuse_band: row bands through the 1x1 convs j -> 0, the strided conv 0 -> 1, the 1x1 convs j -> 1 and both
+        # sums) -- those paths hold 90 % of the fuse bytes and half of the grouped launches' workgroups but few weights; the
+        # grouped launches below keep the deeper paths.  Bit-identical (tests/test_gpu_kernels.py).
+        band = os.environ.get("RSGNET_HIP_FUSE_BAND", "0") == "1" and self.use_group and not pre and not self.use_fanout \
+            and n_out >= 2 and n_out == len(xs) and 2 <= len(xs) <= 4 and all(xs[j].C == 32 << j and xs[j].coff == 0 for j in range(len(xs))) \
+            and xs[0].H % 8 == 0 and xs[0].W % 8 == 0 and os.environ.get("RSGNET_HIP_FOLD_SUM", "1") != "0" \
+            and all(rows[0][j][0].kernel_size == (1, 1) and rows[0][j][0].bias is None for j in range(1, len(xs))) \
+            and all(rows[1][j][0].kernel_size == (1, 1) and rows[1][j][0].bias is None for j in range(2, len(xs))) \
+            and len(rows[1][0]) == 1 and rows[1][0][0][0].kernel_size == (3, 3) and rows[1][0][0][0].stride == (2, 2) \
+            and rows[1][0][0][0].bias is None
+        if band:
+            outs[0], outs[1] = self._fuse_band(xs, rows, name)
+            for key in [k for k in depth if k[0] in (0, 1)]:
+                del depth[key]
+            if not depth:                                 # a module with two branches: everything is done
+                if rider is not None:
+                    self._rider_out = rider(outs[n_out - 1]) if os.environ.get("RSGNET_HIP_TRANS_RIDE", "1") != "0" else None
+                return outs
+        max_depth = max(depth.values()) if depth else 0
         ready = {i: max([d for (ii, _), d in depth.items() if ii == i], default=0) for i in range(n_out)}
+        if band:
+            ready[0] = ready[1] = -1                      # no sums left for them
         # output n_out-1 has no up-sampled addends and at most three others besides its longest chain: fold its sum
         fold_into = None
         last = n_out - 1

@@ -1126,3 +1126,31 @@ def test_fuse_classifier_and_head4_equal_the_separate_launches():
     assert torch.isfinite(outs["separate"]).all()
     assert torch.equal(outs["separate"], outs["sum+classifier"]) and torch.equal(outs["separate"], outs["module+classifier"])
     assert nops["sum+classifier"] == nops["separate"] - 1 and nops["module+classifier"] == nops["separate"] - 2
+
+
+def test_fuse_band_equals_the_grouped_launches():
+    """rsg_fuse_band (outputs 0 and 1 of every HighResolutionModule's fuse in one launch of row bands: the 1x1 convs j -> 0,
+    the strided conv 0 -> 1, the 1x1 convs j -> 1, both sums) against the grouped conv launches and fuse sums it replaces,
+    bit for bit, through the model plans of HRNet-W32 (2-, 3- and 4-branch modules, the folded sum of stage 2) and
+    RSGNet-W32: RSGNET_HIP_FUSE_BAND=0/1 on the same weights and input."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import load_case
+    for tag in ("hrnet_w32_256x192", "rsgnet_w32_256x192_coco"):
+        outs, names = {}, {}
+        for flag in ("0", "1"):
+            os.environ["RSGNET_HIP_FUSE_BAND"] = flag
+            try:
+                cfg, model, sd, x, gold = load_case(tag)
+                model = model.cuda()
+                x3 = torch.cat((x, x[:1] * 0.5)).cuda()
+                with torch.no_grad():
+                    o = model(x3)
+                outs[flag] = [t.cpu() for t in (o if isinstance(o, tuple) else (o,)) if torch.is_tensor(t)]
+                names[flag] = [n for n, _ in list(model._plans.values())[0].ops]
+            finally:
+                os.environ.pop("RSGNET_HIP_FUSE_BAND", None)
+        assert sum(n.endswith(".fuse.band") for n in names["1"]) == 7 and not any(n.endswith(".fuse.band") for n in names["0"])
+        for a, b in zip(outs["0"], outs["1"]):
+            assert torch.isfinite(a).all() and torch.equal(a, b), tag
