@@ -298,6 +298,27 @@ extern "C" int rsg_fuse_head4(const void* x0, int32_t ld0, const void* const* lo
 // stages 9 rows of x0 (one halo row above, a zero column left), 4 / 2 / 1 rows of x1 / x2 / x3.  The grouped launches keep
 // the deep paths (whose weights want whole batches per workgroup).  Arithmetic, operand order and the 16-bit rounding
 // points are those of the grouped convs and of fuse_body: bit-identical.
+// Diagnostic build (-DRSG_BAND_STAMPS, tools/band_stamps.py): thread 0 of every band workgroup records the shader clock at
+// the phase boundaries; the production build contains none of this.
+#ifdef RSG_BAND_STAMPS
+static __device__ unsigned long long* g_band_stamps = nullptr;       // [blocks][8]
+extern "C" int rsg_band_set_stamp_buffer(void* dev_ptr) {
+    unsigned long long* q = (unsigned long long*)dev_ptr;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_band_stamps), &q, sizeof(q)) != hipSuccess) RSG_FAIL("band stamps: memcpy failed");
+    return 0;
+}
+#define RSG_BSTAMP(slot)                                                                                   \
+    do {                                                                                                   \
+        if (g_band_stamps && threadIdx.x == 0) {                                                           \
+            unsigned long long t__;                                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                 \
+            g_band_stamps[(size_t)blockIdx.x * 8 + (slot)] = t__;                                          \
+        }                                                                                                  \
+    } while (0)
+#else
+#define RSG_BSTAMP(slot) do {} while (0)
+#endif
+
 struct FuseBandArgs {
     const char* x[4]; int ld[4];              // x0 (32 ch) .. x3 (256 ch)
     const uint4* w0[3]; const float* b0[3];   // a0j, j = 1..3: cin 64 << (j-1) -> 32
@@ -314,6 +335,7 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
     constexpr int PS0 = 80, PS1 = 144;                          // LDS pixel pitch of 32- / 64-channel maps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 31, hh = lane >> 5;
+    RSG_BSTAMP(0);
     const int tiles = p.H >> 3;
     const int b = blockIdx.x / tiles, ty = blockIdx.x - b * tiles;
     const int W = p.W, W1 = W >> 1, H1 = p.H >> 1;
@@ -387,6 +409,7 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
         }
     }
     __syncthreads();
+    RSG_BSTAMP(1);
     // ---- 2. the 1x1 convs on the staged lower maps: a0j (32 outputs) and a1j (64 outputs: two channel tiles) --------------
     // one job = (conv, 32-pixel group, 32-channel tile); the jobs of ALL 1x1 convs go round the four waves together, and a
     // job's weight fragments are all requested before its first MFMA (fetched one k-step at a time the 9 short jobs of
@@ -441,6 +464,7 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
         }
     }
     __syncthreads();
+    RSG_BSTAMP(2);
     // ---- 3. d10 (3x3, stride 2, pad 1, 32 -> 64) on the x0 band; epilogue = the fuse sum of output 1 ------------------------
     {
         const int np1 = 4 * W1;                                 // y1 pixels of the band
@@ -497,6 +521,7 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
             }
         }
     }
+    RSG_BSTAMP(3);
     // ---- 4. output 0: x0 + the up-sampled a0j (fuse_body) ----------------------------------------------------------------
     for (int id = tid; id < 8 * W * 4; id += 256) {
         const int pl = id >> 2, cg = id & 3;
@@ -521,6 +546,7 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
         for (int e = 0; e < 8; ++e) f[e] = acc[e];
         *reinterpret_cast<uint4*>(p.y0 + (((size_t)(b * p.H + ty * 8) * W + pl) * p.ldy0 + cg * 8) * 2) = __builtin_bit_cast(uint4, DT::relu_pack(f));
     }
+    RSG_BSTAMP(4);
 }
 
 // xs[j] / ld[j]: branch j's map, [batch, h >> j, w >> j, ld[j]], 32 << j channels, j = 0 .. n_low.  w_a0 / b_a0 [n_low]: the 1x1
