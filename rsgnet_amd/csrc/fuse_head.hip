@@ -166,35 +166,46 @@ __global__ void __launch_bounds__(256) fuse_head4_kernel(const FuseHead4Args p) 
         }
     }
     __syncthreads();
-    // ---- 2. the three 1x1 convs on the staged pixels, 32 pixels per wave step --------------------------------------------
+    // ---- 2. the three 1x1 convs on the staged pixels: one job = (conv, 32-pixel group); the jobs go round the four waves and a
+    // job's weight fragments are all requested before its first MFMA ------------------------------------------------------
+    auto job = [&](auto ksn, int j, int g) {
+        constexpr int KSN = decltype(ksn)::value;
+        const int q = g * 32 + n;
+        const char* px = smem + off_x[j] + (q < npx[j] ? q : 0) * psx[j] + hh * 16;
+        uint4 a[KSN];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (j >= p.n_low) break;
-        const int ks_n = (64 << j) / 16;
-        float bias[16];
+        for (int ks = 0; ks < KSN; ++ks) a[ks] = p.wl[j][ks * 64 + lane];
+        f32x16 acc;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const float4 bv = *reinterpret_cast<const float4*>(p.bl[j] + hh * 16 + r4 * 4);
-            bias[r4 * 4 + 0] = bv.x; bias[r4 * 4 + 1] = bv.y; bias[r4 * 4 + 2] = bv.z; bias[r4 * 4 + 3] = bv.w;
+            acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
         }
-        for (int g = wave; g * 32 < npx[j]; g += 4) {
-            const int q = g * 32 + n;
-            const char* px = smem + off_x[j] + (q < npx[j] ? q : 0) * psx[j] + hh * 16;
-            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bias[r];
-            for (int ks = 0; ks < ks_n; ++ks)
-                acc = DT::mfma(__builtin_bit_cast(typename DT::vec8, p.wl[j][ks * 64 + lane]),
-                               __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(px + ks * 32)), acc);
-            if (q < npx[j]) {
+        for (int ks = 0; ks < KSN; ++ks)
+            acc = DT::mfma(__builtin_bit_cast(typename DT::vec8, a[ks]),
+                           __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(px + ks * 32)), acc);
+        if (q < npx[j]) {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    f32x8 f;
+            for (int k = 0; k < 2; ++k) {
+                f32x8 f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = acc[k * 8 + e];
-                    *reinterpret_cast<uint4*>(smem + off_a[j] + q * PSA + (hh * 16 + k * 8) * 2) =
-                        __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
-                }
+                for (int e = 0; e < 8; ++e) f[e] = acc[k * 8 + e];
+                *reinterpret_cast<uint4*>(smem + off_a[j] + q * PSA + (hh * 16 + k * 8) * 2) =
+                    __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+            }
+        }
+    };
+    {
+        int jn = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (j >= p.n_low) break;
+            for (int g = 0; g * 32 < npx[j]; ++g, ++jn) {
+                if ((jn & 3) != wave) continue;
+                if (j == 0) job(std::integral_constant<int, 4>{}, 0, g);
+                else if (j == 1) job(std::integral_constant<int, 8>{}, 1, g);
+                else job(std::integral_constant<int, 16>{}, 2, g);
             }
         }
     }
