@@ -344,12 +344,17 @@ template <class DT>
 __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PS0 = 80, PS1 = 144;                          // LDS pixel pitch of 32- / 64-channel maps
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hh = lane >> 5;
     RSG_BSTAMP(0);
     const int tiles = p.H >> 3;
     const int b = blockIdx.x / tiles, ty = blockIdx.x - b * tiles;
     const int W = p.W, W1 = W >> 1, H1 = p.H >> 1;
+    // A workgroup is a chain of latencies (rows arriving, a weight round trip per conv job, dependent MFMAs): the weights of
+    // the strided conv are requested at entry, every job's successor's weights under its own MFMAs, and a wave runs its
+    // two pixel groups of the strided conv interleaved.
+    const int d_ct = wave & 1;                                  // strided conv: waves 0/2 take channel tile 0, 1/3 tile 1
     // LDS map
     const int RP0 = (W + 1) * PS0;                              // x0 rows: one zero pixel in front
     char* const sx0 = smem;                                     // 9 rows: image rows 8 ty - 1 .. 8 ty + 7
@@ -366,10 +371,80 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
     for (int j = 0; j < 3; ++j) { off_a0[j] = off; if (j < p.n_low) off += npx[j] * PS0; }
 #pragma unroll
     for (int j = 1; j < 3; ++j) { off_a1[j - 1] = off; if (j < p.n_low) off += npx[j] * PS1; }
-    // ---- 1. stage: x0 band (+ halo row, zero border) and the lower maps' rows ------------------------------------------
+    // ---- the 1x1 conv jobs of this wave: job k = (conv, 32-pixel group, channel tile), k = wave, wave + 4, ...; order: for every
+    // lower map j its conv j -> 0 (groups), then its conv j -> 1 (groups x 2 tiles, j >= 1) ---------------------------------
+    int ng[3], jfirst[4];
+    jfirst[0] = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ng[j] = j < p.n_low ? (npx[j] + 31) >> 5 : 0;
+        jfirst[j + 1] = jfirst[j] + ng[j] * (j >= 1 ? 3 : 1);
+    }
+    const int njobs = jfirst[3];
+    struct Job { const uint4* w; const float* bias; int src, ps, np, ksn, g, ct, dst, psd; };
+    // (offsets and sizes as arithmetic in j: a select chain over the small per-map arrays is turned into a table in scratch)
+    const int npx0 = 4 * (W >> 1), npx1 = 2 * (W >> 2), npx2 = W >> 3;
+    const int base_x = 9 * RP0;
+    const int base_a0 = off_a0[0], base_a1 = off_a1[0];
+    auto job_of = [&](int k) -> Job {
+        Job r;
+        const int j = (k >= jfirst[1] ? 1 : 0) + (k >= jfirst[2] ? 1 : 0);
+        const int t = k - (j >= 1 ? jfirst[1] : 0) - (j >= 2 ? jfirst[2] - jfirst[1] : 0);
+        r.np = (8 >> (j + 1)) * (W >> (j + 1));
+        const int ngj = (r.np + 31) >> 5;
+        const bool to1 = t >= ngj;
+        r.g = to1 ? (t - ngj) >> 1 : t;
+        r.ct = to1 ? (t - ngj) & 1 : 0;
+        r.ksn = 4 << j;
+        r.ps = (128 << j) + 16;
+        r.src = base_x + (j >= 1 ? npx0 * 144 : 0) + (j >= 2 ? npx1 * 272 : 0);
+        r.dst = to1 ? base_a1 + (j >= 2 ? npx1 * PS1 : 0) : base_a0 + (j >= 1 ? npx0 * PS0 : 0) + (j >= 2 ? npx1 * PS0 : 0);
+        r.psd = to1 ? PS1 : PS0;
+        const uint4* w = to1 ? p.w1[0] : p.w0[0];
+        const float* bs = to1 ? p.b1[0] : p.b0[0];
+        if (to1 && j == 2) { w = p.w1[1]; bs = p.b1[1]; }
+        if (!to1 && j == 1) { w = p.w0[1]; bs = p.b0[1]; }
+        if (!to1 && j == 2) { w = p.w0[2]; bs = p.b0[2]; }
+        r.w = w + (size_t)r.ct * r.ksn * 64 + lane;
+        r.bias = bs;
+        return r;
+    };
+    auto fetch_w = [&](const Job jb, bool live, uint4 (&a)[16]) {
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            if (live && ks < jb.ksn) a[ks] = jb.w[ks * 64];
+    };
+    Job j0 = job_of(wave < njobs ? wave : 0);
+    uint4 wa[16], wb[16];
+    fetch_w(j0, wave < njobs, wa);                              // the first job's weights travel with the staged rows
+    // ---- 1. stage: the lower maps' rows (loads, then LDS writes), then the x0 band in rounds of 8 loads per thread -----------
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j >= p.n_low) break;
+        const int cpp = (64 << j) / 8;
+        const int rows = 8 >> (j + 1), wl = W >> (j + 1), hl = p.H >> (j + 1);
+        const char* src = p.x[j + 1] + ((size_t)(b * hl + ty * rows) * wl) * p.ld[j + 1] * 2;
+        const int total = npx[j] * cpp;
+        for (int b2 = 0; b2 < total; b2 += 256 * 4) {
+            uint4 v2[4];
+            int lo2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int id = b2 + u * 256 + tid;
+                lo2[u] = -1;
+                v2[u] = make_uint4(0, 0, 0, 0);
+                if (id < total) {
+                    const int px = id / cpp, cg = id - px * cpp;
+                    lo2[u] = off_x[j] + px * psx[j] + cg * 16;
+                    v2[u] = *reinterpret_cast<const uint4*>(src + ((size_t)px * p.ld[j + 1] + cg * 8) * 2);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (lo2[u] >= 0) *reinterpret_cast<uint4*>(smem + lo2[u]) = v2[u];
+        }
+    }
     {
-        // loads in batches of 8 per thread, then the LDS writes (a load and its LDS write in one loop iteration serialise
-        // the iterations on the memory latency)
         const int y_lo = ty * 8 - 1;
         const int total0 = 9 * (W + 1) * 4;
         for (int base = 0; base < total0; base += 256 * 8) {
@@ -392,143 +467,115 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
             for (int u = 0; u < 8; ++u)
                 if (lo[u] >= 0) *reinterpret_cast<uint4*>(sx0 + lo[u]) = v[u];
         }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (j >= p.n_low) break;
-            const int cpp = (64 << j) / 8;
-            const int rows = 8 >> (j + 1), wl = W >> (j + 1), hl = p.H >> (j + 1);
-            const char* src = p.x[j + 1] + ((size_t)(b * hl + ty * rows) * wl) * p.ld[j + 1] * 2;
-            const int total = npx[j] * cpp;
-            for (int base = 0; base < total; base += 256 * 4) {
-                uint4 v[4];
-                int lo[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int id = base + u * 256 + tid;
-                    lo[u] = -1;
-                    v[u] = make_uint4(0, 0, 0, 0);
-                    if (id < total) {
-                        const int px = id / cpp, cg = id - px * cpp;
-                        lo[u] = off_x[j] + px * psx[j] + cg * 16;
-                        v[u] = *reinterpret_cast<const uint4*>(src + ((size_t)px * p.ld[j + 1] + cg * 8) * 2);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (lo[u] >= 0) *reinterpret_cast<uint4*>(smem + lo[u]) = v[u];
-            }
-        }
     }
     __syncthreads();
     RSG_BSTAMP(1);
-    // ---- 2. the 1x1 convs on the staged lower maps: a0j (32 outputs) and a1j (64 outputs: two channel tiles) --------------
-    // one job = (conv, 32-pixel group, 32-channel tile); the jobs of ALL 1x1 convs go round the four waves together, and a
-    // job's weight fragments are all requested before its first MFMA (fetched one k-step at a time the 9 short jobs of
-    // a 4-branch module took 12 us of L2 latency per workgroup)
-    auto job1x1 = [&](auto ksn, const char* src, int ps, int np, const uint4* wpk, const float* bias, int g, int ct, char* dst, int psd) {
-        constexpr int KSN = decltype(ksn)::value;
-        const int q = g * 32 + n;
-        const char* px = src + (q < np ? q : 0) * ps + hh * 16;
-        uint4 a[KSN];
-        const uint4* wp = wpk + (size_t)ct * KSN * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < KSN; ++ks) a[ks] = wp[ks * 64];
+    // ---- 2. the 1x1 convs: this wave's jobs, two per round so that the weight buffers alternate with static indices ---------
+    auto run_job = [&](const Job jb, const uint4 (&a)[16]) {
+        const int q = jb.g * 32 + n;
+        const char* px = smem + jb.src + (q < jb.np ? q : 0) * jb.ps + hh * 16;
         f32x16 acc;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const float4 bv = *reinterpret_cast<const float4*>(bias + ct * 32 + hh * 16 + r4 * 4);
+            const float4 bv = *reinterpret_cast<const float4*>(jb.bias + jb.ct * 32 + hh * 16 + r4 * 4);
             acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
         }
 #pragma unroll
-        for (int ks = 0; ks < KSN; ++ks)
-            acc = DT::mfma(__builtin_bit_cast(typename DT::vec8, a[ks]),
-                           __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(px + ks * 32)), acc);
-        if (q < np) {
+        for (int ks = 0; ks < 16; ++ks)
+            if (ks < jb.ksn)                                    // wave-uniform
+                acc = DT::mfma(__builtin_bit_cast(typename DT::vec8, a[ks]),
+                               __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(px + ks * 32)), acc);
+        if (q < jb.np) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 f32x8 f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = acc[k * 8 + e];
-                *reinterpret_cast<uint4*>(dst + q * psd + (ct * 32 + hh * 16 + k * 8) * 2) =
+                *reinterpret_cast<uint4*>(smem + jb.dst + q * jb.psd + (jb.ct * 32 + hh * 16 + k * 8) * 2) =
                     __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
             }
         }
     };
+    for (int k = wave; k < njobs; k += 8) {
+        const bool has1 = k + 4 < njobs, has2 = k + 8 < njobs;
+        const Job j1 = job_of(has1 ? k + 4 : 0);
+        fetch_w(j1, has1, wb);
+        run_job(j0, wa);
+        j0 = job_of(has2 ? k + 8 : 0);
+        fetch_w(j0, has2, wa);
+        if (has1) run_job(j1, wb);
+    }
+    uint4 ad[18];                                               // the strided conv's weights: requested in front of the barrier
     {
-        int job = 0;                                            // running job number over all convs (wave-uniform)
+        const uint4* wp = p.wd + (size_t)d_ct * 18 * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (j >= p.n_low) break;
-            const int ng = (npx[j] + 31) >> 5;
-            for (int t = 0; t < ng * (j >= 1 ? 3 : 1); ++t, ++job) {
-                if ((job & 3) != wave) continue;
-                const bool to1 = t >= ng;                       // the conv j -> 1 (two channel tiles) after the conv j -> 0
-                const int g = to1 ? (t - ng) >> 1 : t, ct = to1 ? (t - ng) & 1 : 0;
-                const uint4* wpk = to1 ? p.w1[j - 1] : p.w0[j];
-                const float* bias = to1 ? p.b1[j - 1] : p.b0[j];
-                char* dst = smem + (to1 ? off_a1[j - 1] : off_a0[j]);
-                const int psd = to1 ? PS1 : PS0;
-                if (j == 0) job1x1(std::integral_constant<int, 4>{}, smem + off_x[0], psx[0], npx[0], wpk, bias, g, ct, dst, psd);
-                else if (j == 1) job1x1(std::integral_constant<int, 8>{}, smem + off_x[1], psx[1], npx[1], wpk, bias, g, ct, dst, psd);
-                else job1x1(std::integral_constant<int, 16>{}, smem + off_x[2], psx[2], npx[2], wpk, bias, g, ct, dst, psd);
-            }
-        }
+        for (int ks = 0; ks < 18; ++ks) ad[ks] = wp[ks * 64];
     }
     __syncthreads();
     RSG_BSTAMP(2);
-    // ---- 3. d10 (3x3, stride 2, pad 1, 32 -> 64) on the x0 band; epilogue = the fuse sum of output 1 ------------------------
+    // ---- 3. d10 (3x3, stride 2, pad 1, 32 -> 64) on the x0 band: waves 0/1 own pixel groups 0 and 2 (interleaved), waves 2/3
+    // group 1; epilogue = the fuse sum of output 1 ---------------------------------------------------------------------------
     {
         const int np1 = 4 * W1;                                 // y1 pixels of the band
-        for (int job = wave; job < ((np1 + 31) >> 5) * 2; job += 4) {
-            const int g = job >> 1, ct = job & 1;
-            const int q = g * 32 + n;
-            const int qq = q < np1 ? q : 0;
-            const int py = qq / W1, px = qq - py * W1;
-            // input pixel of tap (ky, kx): image (8 ty + 2 py + ky - 1, 2 px + kx - 1) = tile (2 py + ky, 2 px + kx)
-            const char* src = sx0 + (2 * py) * RP0 + (2 * px) * PS0 + hh * 16;
-            f32x16 acc;
+        const int ngd = (np1 + 31) >> 5;
+        for (int g0 = wave >> 1; g0 < ngd; g0 += 4) {           // groups g0 and g0 + 2 (when it exists) together
+            const bool two = g0 + 2 < ngd;
+            int qv[2], pyv[2], pxv[2];
+            const char* src[2];
+            f32x16 acc[2];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bd + ct * 32 + hh * 16 + r4 * 4);
-                acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
+            for (int u = 0; u < 2; ++u) {
+                qv[u] = (g0 + 2 * u) * 32 + n;
+                const int qq = qv[u] < np1 ? qv[u] : 0;
+                pyv[u] = qq / W1; pxv[u] = qq - pyv[u] * W1;
+                // input pixel of tap (ky, kx): image (8 ty + 2 py + ky - 1, 2 px + kx - 1) = tile (2 py + ky, 2 px + kx)
+                src[u] = sx0 + (2 * pyv[u]) * RP0 + (2 * pxv[u]) * PS0 + hh * 16;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bd + d_ct * 32 + hh * 16 + r4 * 4);
+                    acc[u][r4 * 4 + 0] = bv.x; acc[u][r4 * 4 + 1] = bv.y; acc[u][r4 * 4 + 2] = bv.z; acc[u][r4 * 4 + 3] = bv.w;
+                }
             }
-            const uint4* wp = p.wd + (size_t)ct * 18 * 64 + lane;
-            uint4 ad[18];
-#pragma unroll
-            for (int ks = 0; ks < 18; ++ks) ad[ks] = wp[ks * 64];
 #pragma unroll
             for (int ks = 0; ks < 18; ++ks) {                   // k order of the packed weights: tap-major, 16 channels per step
                 const int t = ks >> 1, c = ks & 1;
-                acc = DT::mfma(__builtin_bit_cast(typename DT::vec8, ad[ks]),
-                               __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(src + (t / 3) * RP0 + (t % 3) * PS0 + c * 32)), acc);
+                const int o = (t / 3) * RP0 + (t % 3) * PS0 + c * 32;
+                acc[0] = DT::mfma(__builtin_bit_cast(typename DT::vec8, ad[ks]),
+                                  __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(src[0] + o)), acc[0]);
+                if (two)
+                    acc[1] = DT::mfma(__builtin_bit_cast(typename DT::vec8, ad[ks]),
+                                      __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(src[1] + o)), acc[1]);
             }
-            if (q >= np1) continue;
-            const int cb = ct * 32 + hh * 16;
-            const size_t opix = (size_t)(b * H1 + ty * 4 + py) * W1 + px;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                f32x8 f;
+            for (int u = 0; u < 2; ++u) {
+                if ((u == 1 && !two) || qv[u] >= np1) continue;
+                const int cb = d_ct * 32 + hh * 16, py = pyv[u], px = pxv[u], qq = qv[u];
+                const size_t opix = (size_t)(b * H1 + ty * 4 + py) * W1 + px;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = acc[k * 8 + e];
-                // the conv's own 16-bit result (what the grouped launch stores), then fuse_body's sum: same operands first
-                const typename DT::vec8 d16 = __builtin_convertvector(f, typename DT::vec8);
-                const typename DT::vec8 x1v = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(smem + off_x[0] + qq * psx[0] + (cb + k * 8) * 2));
-                // a module with two branches: output 1 is the LAST output, whose sum the grouped launch folds into the conv's
-                // epilogue (acc + x1 in fp32, no 16-bit stop in between: plan.py fold_into) -- the same here
-                float s[8];
+                for (int k = 0; k < 2; ++k) {
+                    f32x8 f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s[e] = p.n_low == 1 ? f[e] + (float)x1v[e] : (0.f + (float)d16[e]) + (float)x1v[e];
+                    for (int e = 0; e < 8; ++e) f[e] = acc[u][k * 8 + e];
+                    // the conv's own 16-bit result (what the grouped launch stores), then fuse_body's sum: same operands first
+                    const typename DT::vec8 d16 = __builtin_convertvector(f, typename DT::vec8);
+                    const typename DT::vec8 x1v = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(smem + off_x[0] + qq * psx[0] + (cb + k * 8) * 2));
+                    // a module with two branches: output 1 is the LAST output, whose sum the grouped launch folds into the conv's
+                    // epilogue (acc + x1 in fp32, no 16-bit stop in between: plan.py fold_into) -- the same here
+                    float s[8];
 #pragma unroll
-                for (int j = 1; j < 3; ++j) {
-                    if (j >= p.n_low) break;
-                    const typename DT::vec8 av = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(
-                        smem + off_a1[j - 1] + ((py >> j) * (W1 >> j) + (px >> j)) * PS1 + (cb + k * 8) * 2));
+                    for (int e = 0; e < 8; ++e) s[e] = p.n_low == 1 ? f[e] + (float)x1v[e] : (0.f + (float)d16[e]) + (float)x1v[e];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) s[e] += (float)av[e];
+                    for (int j = 1; j < 3; ++j) {
+                        if (j >= p.n_low) break;
+                        const typename DT::vec8 av = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(
+                            smem + off_a1[j - 1] + ((py >> j) * (W1 >> j) + (px >> j)) * PS1 + (cb + k * 8) * 2));
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s[e] += (float)av[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = s[e];
+                    *reinterpret_cast<uint4*>(p.y1 + (opix * p.ldy1 + cb + k * 8) * 2) = __builtin_bit_cast(uint4, DT::relu_pack(f));
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = s[e];
-                *reinterpret_cast<uint4*>(p.y1 + (opix * p.ldy1 + cb + k * 8) * 2) = __builtin_bit_cast(uint4, DT::relu_pack(f));
             }
         }
     }
