@@ -409,42 +409,38 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
         r.bias = bs;
         return r;
     };
-    auto fetch_w = [&](const Job jb, bool live, uint4 (&a)[16]) {
+    // always 16 loads (a short job re-reads its last fragment): a fixed count lets the compiler wait for exactly one job's
+    // weights (s_waitcnt vmcnt(16)) while the next job's are still in flight; predicated loads made it wait for everything
+    auto fetch_w = [&](const Job jb, bool, uint4 (&a)[16]) {
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks)
-            if (live && ks < jb.ksn) a[ks] = jb.w[ks * 64];
+        for (int ks = 0; ks < 16; ++ks) a[ks] = jb.w[(ks < jb.ksn ? ks : jb.ksn - 1) * 64];
     };
     Job j0 = job_of(wave < njobs ? wave : 0);
     uint4 wa[16], wb[16];
     fetch_w(j0, wave < njobs, wa);                              // the first job's weights travel with the staged rows
-    // ---- 1. stage: the lower maps' rows (loads, then LDS writes), then the x0 band in rounds of 8 loads per thread -----------
+    // ---- 1. stage: ONE round trip -- the lower maps' rows (up to 4 loads per thread and map) and the first 8 x0 loads per thread
+    // are all requested before the first LDS write (wider maps: further x0 rounds of 8) ---------------------------------------
+    {
+        uint4 v2[3][4];
+        int lo2[3][4];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        if (j >= p.n_low) break;
-        const int cpp = (64 << j) / 8;
-        const int rows = 8 >> (j + 1), wl = W >> (j + 1), hl = p.H >> (j + 1);
-        const char* src = p.x[j + 1] + ((size_t)(b * hl + ty * rows) * wl) * p.ld[j + 1] * 2;
-        const int total = npx[j] * cpp;
-        for (int b2 = 0; b2 < total; b2 += 256 * 4) {
-            uint4 v2[4];
-            int lo2[4];
+        for (int j = 0; j < 3; ++j) {
+            const int cpp = (64 << j) / 8;
+            const int rows = 8 >> (j + 1), wl = W >> (j + 1), hl = p.H >> (j + 1);
+            const char* src = j < p.n_low ? p.x[j + 1] + ((size_t)(b * hl + ty * rows) * wl) * p.ld[j + 1] * 2 : nullptr;
+            const int total = j < p.n_low ? npx[j] * cpp : 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int id = b2 + u * 256 + tid;
-                lo2[u] = -1;
-                v2[u] = make_uint4(0, 0, 0, 0);
+                const int id = u * 256 + tid;
+                lo2[j][u] = -1;
+                v2[j][u] = make_uint4(0, 0, 0, 0);
                 if (id < total) {
                     const int px = id / cpp, cg = id - px * cpp;
-                    lo2[u] = off_x[j] + px * psx[j] + cg * 16;
-                    v2[u] = *reinterpret_cast<const uint4*>(src + ((size_t)px * p.ld[j + 1] + cg * 8) * 2);
+                    lo2[j][u] = off_x[j] + px * psx[j] + cg * 16;
+                    v2[j][u] = *reinterpret_cast<const uint4*>(src + ((size_t)px * p.ld[j + 1] + cg * 8) * 2);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (lo2[u] >= 0) *reinterpret_cast<uint4*>(smem + lo2[u]) = v2[u];
         }
-    }
-    {
         const int y_lo = ty * 8 - 1;
         const int total0 = 9 * (W + 1) * 4;
         for (int base = 0; base < total0; base += 256 * 8) {
@@ -462,6 +458,13 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
                     lo[u] = r * RP0 + c * PS0 + cg * 16;
                     if (y >= 0 && x >= 0) v[u] = *reinterpret_cast<const uint4*>(p.x[0] + (((size_t)(b * p.H + y) * W + x) * p.ld[0] + cg * 8) * 2);
                 }
+            }
+            if (base == 0) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (lo2[j][u] >= 0) *reinterpret_cast<uint4*>(smem + lo2[j][u]) = v2[j][u];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
@@ -496,6 +499,12 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
             }
         }
     };
+    uint4 ad[18];                                               // the strided conv's weights travel under the 1x1 jobs
+    {
+        const uint4* wp = p.wd + (size_t)d_ct * 18 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) ad[ks] = wp[ks * 64];
+    }
     for (int k = wave; k < njobs; k += 8) {
         const bool has1 = k + 4 < njobs, has2 = k + 8 < njobs;
         const Job j1 = job_of(has1 ? k + 4 : 0);
@@ -504,12 +513,6 @@ __global__ void __launch_bounds__(256, 2) fuse_band_kernel(const FuseBandArgs p)
         j0 = job_of(has2 ? k + 8 : 0);
         fetch_w(j0, has2, wa);
         if (has1) run_job(j1, wb);
-    }
-    uint4 ad[18];                                               // the strided conv's weights: requested in front of the barrier
-    {
-        const uint4* wp = p.wd + (size_t)d_ct * 18 * 64 + lane;
-#pragma unroll
-        for (int ks = 0; ks < 18; ++ks) ad[ks] = wp[ks * 64];
     }
     __syncthreads();
     RSG_BSTAMP(2);
