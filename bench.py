@@ -137,6 +137,46 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0, gpu_model=None):
     return out
 
 
+def settle_clocks(step, warmup, steps, dist, dev, max_seconds, block=20, patience=5):
+    """Untimed, in front of the contract's warm-up: run the step until its time stops improving.  A freshly started process
+    finds the card's clocks low: the same step measures 1.69 ms in a region that starts 10 ms after the first launch and
+    1.46-1.48 ms from about 0.5 s on (tools/gpu_warmup_probe.sh, profiles/r03m_clock_ramp.txt); rounds 1-2 timed that first
+    region.  Blocks of `block` steps, each timed on the host around a synchronize; stops after `patience` blocks in a row
+    without a new best (0.5 % margin) or after max_seconds; with several ranks, when EVERY rank says so (one 4-byte all-reduce
+    per block keeps them in step, so that none waits cold at the timed region's barrier).  Returns what goes into the line's
+    config.cold_start: the {warm-up, steps} region timed the old way first, and the blocks run since."""
+    if max_seconds <= 0:
+        return None
+    on_gpu = dev is not None and dev.type == "cuda"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    for _ in range(max(warmup, 1)):
+        step()
+    sync()
+    wall, _ = timed_steps(step, steps, dist, dev)
+    best, since, hist, t_start = float("inf"), 0, [], time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(block):
+            step()
+        sync()
+        dt = (time.perf_counter() - t0) / block
+        hist.append(dt)
+        if dt < best * 0.995:
+            best, since = dt, 0
+        else:
+            since += 1
+        go_on = since < patience and time.perf_counter() - t_start < max_seconds
+        if dist is not None:
+            flag = torch.tensor([1.0 if go_on else 0.0], device=dev if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            go_on = bool(flag.item() > 0)
+        if not go_on:
+            break
+    return {"ms_per_step": round(wall / steps * 1e3, 4), "settle_blocks": len(hist), "steps_per_block": block,
+            "settle_block_ms_per_step": {"first": round(hist[0] * 1e3, 4), "best": round(min(hist) * 1e3, 4),
+                                         "last": round(hist[-1] * 1e3, 4)}}
+
+
 def timed_steps(step, steps, dist, dev):
     """The contract's timed region: barrier + synchronize on both sides of EXACTLY `steps` steps; returns
     (max wall seconds over ranks, this rank's device ms between HIP events on the launch stream)."""
@@ -267,7 +307,7 @@ def train_bench(a, rank, world, local, dev, dist):
             loss, _ = step_fn(x, target, tw)
             losses.append(loss)
 
-    for _ in range(max(a.warmup, 1)):
+    for _ in range(max(a.warmup, 1)):              # (no settle_clocks here: the 13 ms step measures the same cold and settled)
         step()
     torch.cuda.synchronize()
     wall, dev_ms = timed_steps(step, a.steps, dist, dev)
@@ -359,6 +399,10 @@ def main():
     ap.add_argument("--workload", default="hrnet_w32_256x192", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the metric's 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle-seconds", type=float, default=2.0,
+                    help="inference: at most this long, untimed steps of the same workload in front of the warm-up until "
+                         "the step time stops improving (settle_clocks; 0: time the cold region, as rounds 1-2 did)")
+    ap.add_argument("--no-other-dtype", action="store_true", help="skip the bf16 (fp16 with --dtype bf16) leg of the line (--no-cpu-baseline skips it too)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
                     help="16-bit storage / MFMA operand type of the inference plan (fp32 accumulation either way).  fp16 is the "
                          "default because the 1e-3 heat-map bar needs its mantissa (DESIGN.md section 6); bf16 runs the same kernels")
@@ -437,6 +481,7 @@ def main():
                 return forward_flip_test(model, x, FLIP_PAIRS[joints])
             return model(x)
 
+    cold = settle_clocks(step, a.warmup, a.steps, dist, dev, a.settle_seconds)
     for _ in range(max(a.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
@@ -455,7 +500,7 @@ def main():
     fam = None
     if rank == 0:
         st = torch.cuda.current_stream(dev).cuda_stream
-        reps = 5
+        reps = 10
         for _, op in plan.ops:
             op(st)
         evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in plan.ops]
@@ -492,7 +537,10 @@ def main():
             "config": {"workload": a.workload, "per_gpu_batch": batch, "global_batch": batch * world,
                        "image": f"{wh[1]}x{wh[0]}", "parallelism": f"dp{world} (independent shards)",
                        "weights": "synthetic name-keyed rule + calibrated BN stats", "graph": plan.graph_mode,
-                       "launches_per_step": len(plan.ops)},
+                       "launches_per_step": len(plan.ops),
+                       # the figures of the same {warm-up, steps} region timed cold, as rounds 1-2 timed `value`, and the
+                       # untimed steps run since (settle_clocks)
+                       "cold_start": cold},
             # dominant kernel family: algorithmic FLOPs of its launches / their summed durations (HIP events
             # on the launch stream, per-launch pass after the timed region)
             "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -509,6 +557,22 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh, gpu_model=model)
+        if world == 1 and not (a.no_other_dtype or a.no_cpu_baseline) and not (a.flip_test or a.pipeline or a.from_host):
+            # BASELINE.json configs[1]/[2] name bf16: the same workload, steps and timing on the other 16-bit format (a second
+            # plan of the same model, measured AFTER and outside the timed region above; `value` stays the --dtype run)
+            other = "bf16" if a.dtype == "fp16" else "fp16"
+            ref = out.float() if torch.is_tensor(out) else None
+            model.compute_dtype = other
+            for _ in range(max(a.warmup, 1)):
+                out2 = step()
+            torch.cuda.synchronize()
+            wall2, dev2 = timed_steps(step, a.steps, None, dev)
+            model.compute_dtype = a.dtype
+            line["other_dtype"] = {"dtype": other, "value": round(batch * a.steps / wall2, 1), "unit": "images/s",
+                                   "ms_per_step": round(wall2 / a.steps * 1e3, 4),
+                                   "whole_step_frac": round(gflop * batch / (dev2 / a.steps) / PEAK_TFLOPS, 4)}
+            if ref is not None and torch.is_tensor(out2):
+                line["other_dtype"]["max_abs_vs_" + a.dtype] = float((out2.float() - ref).abs().max())
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

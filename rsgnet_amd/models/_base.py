@@ -39,6 +39,7 @@ class HipPoseModule(nn.Module):
     def invalidate_plan(self) -> None:
         self._plans = {}
         self._train_plans = {}
+        self.__dict__.pop("_sig_modules", None)
 
     def _apply(self, fn, *a, **kw):
         self.invalidate_plan()
@@ -71,17 +72,30 @@ class HipPoseModule(nn.Module):
     def _build_plan(self, batch: int, device: torch.device):  # pragma: no cover - overridden
         raise NotImplementedError
 
-    def _param_signature(self) -> int:
+    def _param_signature(self):
         """Changes whenever a parameter or buffer was written in place (torch bumps `_version` on every in-place op:
-        `p.data.copy_`, torch optimizers' updates) or FusedAdam stepped (its kernel writes through raw pointers and
-        bumps `optim.PARAM_EPOCH` instead): the folded/packed weights of a cached plan are then stale."""
+        `p.data.copy_`, torch optimizers' updates), was replaced by another tensor object, or FusedAdam stepped (its kernel
+        writes through raw pointers and bumps `optim.PARAM_EPOCH` instead): the folded/packed weights of a cached plan are
+        then stale.  Runs in front of EVERY forward, so it walks a cached list of the modules that own tensors and reads
+        their `_parameters` / `_buffers` dicts directly: `self.parameters()` + `self.buffers()` (two generator walks over
+        the ~1 000 modules of the tree) took 1.4 ms of host time per forward - as long as the forward itself takes on the
+        GPU (profiles/r03m_host_time_per_forward.txt).  The module list is rebuilt after `.to()` / `load_state_dict` /
+        `invalidate_plan()`; sub-modules are not added to a built model."""
         from .. import optim
-        sig = optim.PARAM_EPOCH
-        for t in self.parameters():
-            sig += t._version
-        for t in self.buffers():
-            sig += t._version
-        return sig
+        mods = self.__dict__.get("_sig_modules")
+        if mods is None:
+            mods = self.__dict__["_sig_modules"] = [m for m in self.modules() if m._parameters or m._buffers]
+        sig, ids = optim.PARAM_EPOCH, 0
+        for m in mods:
+            for t in m._parameters.values():
+                if t is not None:
+                    sig += t._version
+                    ids ^= id(t)
+            for t in m._buffers.values():
+                if t is not None:
+                    sig += t._version
+                    ids ^= id(t)
+        return sig, ids
 
     def run_plan(self, x: torch.Tensor):
         """forward's way into the plan: everything (plan build, launches, output allocation) happens with the INPUT's

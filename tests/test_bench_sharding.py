@@ -28,7 +28,14 @@ def _worker(rank, world, port, out):
         time.sleep(delay)
 
     wall, dev_ms = bench.timed_steps(step, 5, dist, None)
-    out[rank] = (wall, float(x.sum()))
+    count = [0]
+
+    def counted():
+        count[0] += 1
+        step()
+
+    cold = bench.settle_clocks(counted, 1, 3, dist, None, 5.0, block=2, patience=1 + rank)
+    out[rank] = (wall, float(x.sum()), count[0], cold["settle_blocks"])
     dist.destroy_process_group()
 
 
@@ -37,7 +44,10 @@ def test_two_rank_protocol_reports_max_over_ranks():
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-        (w0, s0), (w1, s1) = out[0], out[1]
+        (w0, s0, n0, c0), (w1, s1, n1, c1) = out[0], out[1]
+    # the untimed clock-settling blocks: the ranks stop TOGETHER (rank 1 is the patient one here), so that none of them waits,
+    # cooling down, at the barrier of the timed region
+    assert c0 == c1 >= 2 and n0 == n1 == 1 + 3 + 2 * c0
     assert abs(w0 - w1) < 1e-9            # every rank ends up with the same (max) time
     assert w0 >= 5 * 0.02 * 0.95          # ... which is the slow rank's
     assert s0 != s1                        # shards differ (seed = rank)

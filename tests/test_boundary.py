@@ -66,6 +66,37 @@ def test_forward_off_gpu_fails_loudly():
         m(torch.zeros(1, 3, 256, 192))
 
 
+def test_param_signature_sees_every_way_the_weights_can_change():
+    """The check in front of every forward (models/_base.py): cheap (no generator walk over the module tree), and it
+    moves on an in-place write to a parameter or a buffer, on a parameter OBJECT swapped for another, on load_state_dict
+    and on a FusedAdam step; it stands still otherwise."""
+    from rsgnet_amd import optim
+    m = models.pose_hrnet.get_pose_net(make_cfg(), False).eval()
+    s0 = m._param_signature()
+    assert m._param_signature() == s0
+    with torch.no_grad():
+        m.final_layer.weight.mul_(0.5)
+    s1 = m._param_signature()
+    assert s1 != s0
+    m.bn1.running_mean.add_(1.0)
+    s2 = m._param_signature()
+    assert s2 != s1
+    m.final_layer.weight = torch.nn.Parameter(m.final_layer.weight.detach().clone())     # same values and version, other object
+    s3 = m._param_signature()
+    assert s3 != s2
+    m.load_state_dict(m.state_dict())
+    s4 = m._param_signature()
+    assert s4 != s3
+    optim.PARAM_EPOCH += 1                     # what FusedAdam.step does after its kernel wrote through raw pointers
+    assert m._param_signature() != s4
+    optim.PARAM_EPOCH -= 1
+    assert m._param_signature() == s4
+    n_tensors = len(list(m.parameters())) + len(list(m.buffers()))
+    seen = sum(len([t for t in mod._parameters.values() if t is not None]) + len([t for t in mod._buffers.values() if t is not None])
+               for mod in m.__dict__["_sig_modules"])
+    assert seen == n_tensors                   # the cached module list covers every tensor of the model
+
+
 def test_library_exports_every_declared_symbol():
     lib = hip.lib()
     header = open(os.path.join(ROOT, "include", "rsgnet_hip.h")).read()

@@ -513,3 +513,36 @@ def test_dataparallel_wrap_and_module_state_dict():
         assert list(msd.keys()) == list(manifest(tag)["state_dict"].keys())
         assert all(torch.equal(msd[k].cpu(), sd[k]) for k in sd)
         assert all(k.startswith("module.") for k in dp.state_dict())
+
+
+def test_forward_follows_in_place_weight_updates_and_its_host_time_stays_small():
+    """model(x) checks its parameters in front of every forward (models/_base.py `_param_signature`): an in-place update or a
+    swapped parameter object rebuilds the plan; and the check must not cost what the forward costs on the GPU (it did:
+    1.4 ms of generator walks per call, profiles/r03m_host_time_per_forward.txt)."""
+    import time
+    cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+    model = model.cuda().eval()
+    xc = x.cuda()
+    with torch.no_grad():
+        y0 = model(xc).clone()
+        model.final_layer.weight.mul_(2.0)
+        model.final_layer.bias.mul_(2.0)
+        y1 = model(xc).clone()
+        assert maxabs(y1, 2.0 * y0) < 2e-3 * float(y0.abs().max())           # the classifier is linear: doubled
+        model.final_layer.weight = torch.nn.Parameter(0.5 * model.final_layer.weight.detach())
+        model.final_layer.bias = torch.nn.Parameter(0.5 * model.final_layer.bias.detach())
+        y2 = model(xc).clone()
+        assert maxabs(y2, y0) < 2e-3 * float(y0.abs().max())
+        for _ in range(5):
+            model(xc)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model(xc)
+            ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+    host_ms = sorted(ts)[len(ts) // 2] * 1e3
+    print(f"host time of one forward call (enqueue only, batch {xc.shape[0]}): {host_ms:.3f} ms")
+    assert host_ms < 0.7
