@@ -138,13 +138,14 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0, gpu_model=None):
 
 
 def settle_clocks(step, warmup, steps, dist, dev, max_seconds, block=20, patience=5):
-    """Untimed, in front of the contract's warm-up: run the step until its time stops improving.  A freshly started process
-    finds the card's clocks low: the same step measures 1.69 ms in a region that starts 10 ms after the first launch and
-    1.46-1.48 ms from about 0.5 s on (tools/gpu_warmup_probe.sh, profiles/r03m_clock_ramp.txt); rounds 1-2 timed that first
-    region.  Blocks of `block` steps, each timed on the host around a synchronize; stops after `patience` blocks in a row
+    """Untimed, in front of the contract's warm-up: run the step until its time stops improving.  A card that has sat idle
+    (model building, a host-side check, even 5 ms of nothing) comes back slowly: the first 20-step window after 3 s of idle
+    time measures 1.64 ms per step against 1.48 ms for every later one, and 5 / 20 / 100 ms of idle time in front of a
+    20-step region cost it 1.0 / 1.8 / 2.4 ms (profiles/r03m_step_time_along_a_run.txt).  Five warm-up steps (7 ms) do not
+    cover that.  Blocks of `block` steps, each timed on the host around a synchronize; stops after `patience` blocks in a row
     without a new best (0.5 % margin) or after max_seconds; with several ranks, when EVERY rank says so (one 4-byte all-reduce
-    per block keeps them in step, so that none waits cold at the timed region's barrier).  Returns what goes into the line's
-    config.cold_start: the {warm-up, steps} region timed the old way first, and the blocks run since."""
+    per block keeps them in step, so that none waits, idle, at the timed region's barrier).  Returns what goes into the line's
+    config.cold_start: the {warm-up, steps} region timed first, the way rounds 1-2 timed `value`, and the blocks run since."""
     if max_seconds <= 0:
         return None
     on_gpu = dev is not None and dev.type == "cuda"
@@ -484,11 +485,11 @@ def main():
     cold = settle_clocks(step, a.warmup, a.steps, dist, dev, a.settle_seconds)
     for _ in range(max(a.warmup, 1)):
         out = step()
-    torch.cuda.synchronize()
+    # nothing between the warm-up and the timed region: the finiteness check (first use: tens of ms of host time with the
+    # card idle) sat here until round 3 and cost the 20-step region 2 ms (tools/region_cost.py)
+    wall, dev_ms = timed_steps(step, a.steps, dist, dev)
     o0 = out if torch.is_tensor(out) else out[1]
     assert torch.isfinite(o0).all(), "non-finite heatmaps"
-
-    wall, dev_ms = timed_steps(step, a.steps, dist, dev)
 
     plan = model.plan_for(torch.cat((x, x)) if a.flip_test else x)
     plan.check_handoff()        # the in-launch hand-off's error word, read back (raises if any poll gave up)
@@ -510,8 +511,16 @@ def main():
                 e0.record()
                 op(st)
                 e1.record()
+        # what an event pair measures with NOTHING between its two records (the markers' own processing, 5-7 us on this
+        # stack: 8 chain launches carried 50 us of it against rocprofv3's durations of the same kernels) is taken off
+        empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+        for z0, z1 in empty:
+            z0.record()
+            z1.record()
         torch.cuda.synchronize()
-        per_op = [{"op": name, "us": round(sum(evs[r][i][0].elapsed_time(evs[r][i][1]) for r in range(reps)) / reps * 1e3, 2)}
+        pair_us = sorted(z0.elapsed_time(z1) for z0, z1 in empty)[len(empty) // 2] * 1e3
+        per_op = [{"op": name, "us": round(max(0.0, sum(evs[r][i][0].elapsed_time(evs[r][i][1]) for r in range(reps)) / reps * 1e3
+                                               - pair_us), 2)}
                   for i, (name, _) in enumerate(plan.ops)]
         fam = family_table(plan, per_op)
         if a.per_op:
@@ -549,6 +558,7 @@ def main():
                          "mfma_util": pmc_mfma_busy("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel", a.workload),
                          "algorithmic_mb_per_launch": dom.get("alg_mb_per_launch"),
                          "kernel": dom_name, "launches": dom["launches"], "kernel_us_per_step": dom["us"],
+                         "empty_event_pair_us": round(pair_us, 2),      # already taken off every launch's figure
                          "kernel_gflop_per_step": dom["gflop"],
                          "whole_step": {"achieved": round(whole, 1), "frac": round(whole / PEAK_TFLOPS, 4),
                                         "device_ms_per_step": round(dev_ms / a.steps, 4),
@@ -563,9 +573,8 @@ def main():
             other = "bf16" if a.dtype == "fp16" else "fp16"
             ref = out.float() if torch.is_tensor(out) else None
             model.compute_dtype = other
-            for _ in range(max(a.warmup, 1)):
+            for _ in range(max(a.warmup, 1) + 100):                  # the plan build left the card idle (settle_clocks)
                 out2 = step()
-            torch.cuda.synchronize()
             wall2, dev2 = timed_steps(step, a.steps, None, dev)
             model.compute_dtype = a.dtype
             line["other_dtype"] = {"dtype": other, "value": round(batch * a.steps / wall2, 1), "unit": "images/s",
