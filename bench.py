@@ -137,7 +137,7 @@ def cpu_baseline(tag, cfg, sd, wh, budget_s=20.0, gpu_model=None):
     return out
 
 
-def settle_clocks(step, warmup, steps, dist, dev, max_seconds, block=20, patience=5):
+def settle_clocks(step, warmup, steps, dist, dev, max_seconds, block=20, patience=5, join=None):
     """Untimed, in front of the contract's warm-up: run the step until its time stops improving.  A card that has sat idle
     (model building, a host-side check, even 5 ms of nothing) comes back slowly: the first 20-step window after 3 s of idle
     time measures 1.64 ms per step against 1.48 ms for every later one, and 5 / 20 / 100 ms of idle time in front of a
@@ -153,7 +153,7 @@ def settle_clocks(step, warmup, steps, dist, dev, max_seconds, block=20, patienc
     for _ in range(max(warmup, 1)):
         step()
     sync()
-    wall, _ = timed_steps(step, steps, dist, dev)
+    wall, _ = timed_steps(step, steps, dist, dev, join)
     best, since, hist, t_start = float("inf"), 0, [], time.perf_counter()
     while True:
         t0 = time.perf_counter()
@@ -178,7 +178,7 @@ def settle_clocks(step, warmup, steps, dist, dev, max_seconds, block=20, patienc
                                          "last": round(hist[-1] * 1e3, 4)}}
 
 
-def timed_steps(step, steps, dist, dev):
+def timed_steps(step, steps, dist, dev, join=None):
     """The contract's timed region: barrier + synchronize on both sides of EXACTLY `steps` steps; returns
     (max wall seconds over ranks, this rank's device ms between HIP events on the launch stream)."""
     on_gpu = dev is not None and dev.type == "cuda"
@@ -200,6 +200,8 @@ def timed_steps(step, steps, dist, dev):
     for _ in range(steps):
         step()
     if on_gpu:
+        if join is not None:
+            join()                      # steps issued on side streams: the timing stream waits for them
         e1.record(stream)
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -400,6 +402,10 @@ def main():
     ap.add_argument("--workload", default="hrnet_w32_256x192", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the metric's 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="issue consecutive batches on this many alternating HIP streams (each has its own plan: arena + graph), "
+                         "so that two batches in flight overlap on the GPU (same-visit: 1.54 -> 1.36 ms per batch of 64); the line "
+                         "carries the one-stream figure too (`single_stream`).  1 with --pipeline / --from-host (shared staging)")
     ap.add_argument("--settle-seconds", type=float, default=2.0,
                     help="inference: at most this long, untimed steps of the same workload in front of the warm-up until "
                          "the step time stops improving (settle_clocks; 0: time the cold region, as rounds 1-2 did)")
@@ -470,7 +476,24 @@ def main():
 
     x_host = x.cpu().pin_memory() if a.from_host else None
 
+    if a.pipeline or a.from_host:
+        a.streams = 1
+    side = [torch.cuda.Stream(dev) for _ in range(a.streams)] if a.streams > 1 else None
+    issued = [0]
+
+    def join():
+        cur = torch.cuda.current_stream(dev)
+        for s_ in side:
+            cur.wait_stream(s_)
+
     def step():
+        if side is None:
+            return step1()
+        issued[0] += 1
+        with torch.cuda.stream(side[issued[0] % len(side)]):      # consecutive batches on alternating streams: they may overlap
+            return step1()
+
+    def step1():
         with torch.no_grad():
             if a.from_host:
                 x.copy_(x_host, non_blocking=True)
@@ -482,15 +505,19 @@ def main():
                 return forward_flip_test(model, x, FLIP_PAIRS[joints])
             return model(x)
 
-    cold = settle_clocks(step, a.warmup, a.steps, dist, dev, a.settle_seconds)
+    jn = join if side is not None else None
+    cold = settle_clocks(step, a.warmup, a.steps, dist, dev, a.settle_seconds, join=jn)
     for _ in range(max(a.warmup, 1)):
         out = step()
     # nothing between the warm-up and the timed region: the finiteness check (first use: tens of ms of host time with the
     # card idle) sat here until round 3 and cost the 20-step region 2 ms (tools/region_cost.py)
-    wall, dev_ms = timed_steps(step, a.steps, dist, dev)
+    wall, dev_ms = timed_steps(step, a.steps, dist, dev, jn)
     o0 = out if torch.is_tensor(out) else out[1]
     assert torch.isfinite(o0).all(), "non-finite heatmaps"
 
+    if side is not None:                          # the per-launch pass below runs one of the side streams' plans, on its stream
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(side[0])
     plan = model.plan_for(torch.cat((x, x)) if a.flip_test else x)
     plan.check_handoff()        # the in-launch hand-off's error word, read back (raises if any poll gave up)
     # per-launch timing pass (outside the timed region, rank 0): the launch list runs IN ORDER, eagerly, with a HIP
@@ -544,9 +571,9 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": model.compute_dtype, "data": "synthetic",
             "config": {"workload": a.workload, "per_gpu_batch": batch, "global_batch": batch * world,
-                       "image": f"{wh[1]}x{wh[0]}", "parallelism": f"dp{world} (independent shards)",
+                       "image": f"{wh[1]}x{wh[0]}", "parallelism": f"dp{world} (independent shards)" + (f", {a.streams} batches in flight per GPU (alternating streams)" if side is not None else ""),
                        "weights": "synthetic name-keyed rule + calibrated BN stats", "graph": plan.graph_mode,
-                       "launches_per_step": len(plan.ops),
+                       "launches_per_step": len(plan.ops), "streams": a.streams,
                        # the figures of the same {warm-up, steps} region timed cold, as rounds 1-2 timed `value`, and the
                        # untimed steps run since (settle_clocks)
                        "cold_start": cold},
@@ -565,6 +592,16 @@ def main():
                                         "algorithmic_gflop_per_image": gflop},
                          "families": fam},
         }
+        if side is not None:
+            # the same K steps issued one after the other on ONE stream (rounds 1-3 measured `value` this way)
+            keep, side = side, None
+            for _ in range(max(a.warmup, 1) + 40):
+                step()
+            w1, d1 = timed_steps(step, a.steps, None, dev)
+            side = keep
+            line["single_stream"] = {"value": round(batch * a.steps / w1, 1), "unit": "images/s",
+                                     "ms_per_step": round(w1 / a.steps * 1e3, 4),
+                                     "whole_step_frac": round(gflop * fwd_imgs / (d1 / a.steps) / PEAK_TFLOPS, 4)}
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh, gpu_model=model)
         if world == 1 and not (a.no_other_dtype or a.no_cpu_baseline) and not (a.flip_test or a.pipeline or a.from_host):
@@ -575,7 +612,7 @@ def main():
             model.compute_dtype = other
             for _ in range(max(a.warmup, 1) + 100):                  # the plan build left the card idle (settle_clocks)
                 out2 = step()
-            wall2, dev2 = timed_steps(step, a.steps, None, dev)
+            wall2, dev2 = timed_steps(step, a.steps, None, dev, jn)
             model.compute_dtype = a.dtype
             line["other_dtype"] = {"dtype": other, "value": round(batch * a.steps / wall2, 1), "unit": "images/s",
                                    "ms_per_step": round(wall2 / a.steps * 1e3, 4),

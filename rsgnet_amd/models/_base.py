@@ -26,6 +26,8 @@ class HipPoseModule(nn.Module):
 
     #: storage/MFMA input type of the plan; accumulation is always fp32
     compute_dtype = "fp16"
+    #: plans kept for streams other than the default one, per (batch, device, dtype)
+    MAX_STREAM_PLANS = 4
 
     def __init__(self):
         super().__init__()
@@ -128,9 +130,17 @@ class HipPoseModule(nn.Module):
         if sig != getattr(self, "_plan_sig", None):
             self._plans = {}                  # parameters were updated in place since the plans were built
             self._plan_sig = sig
-        key = (int(x.shape[0]), x.device.index, self.compute_dtype)
+        # one plan (activation arena, captured graph) per STREAM: forwards issued on different streams may overlap on the
+        # GPU (torch.cuda.stream(s): two batches in flight fill each other's idle CUs), forwards on one stream are ordered
+        # and share theirs.  At most MAX_STREAM_PLANS side-stream plans per (batch, device, dtype); the oldest goes first.
+        base = (int(x.shape[0]), x.device.index, self.compute_dtype)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        key = base + (stream,)
         plan = self._plans.get(key)
         if plan is None:
+            mine = [k for k in self._plans if k[:3] == base and k[3] != 0]
+            if stream != 0 and len(mine) >= self.MAX_STREAM_PLANS:
+                del self._plans[mine[0]]          # dicts keep insertion order
             with torch.cuda.device(x.device):
                 plan = self._build_plan(int(x.shape[0]), x.device)
             self._plans[key] = plan

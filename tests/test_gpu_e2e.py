@@ -546,3 +546,45 @@ def test_forward_follows_in_place_weight_updates_and_its_host_time_stays_small()
     host_ms = sorted(ts)[len(ts) // 2] * 1e3
     print(f"host time of one forward call (enqueue only, batch {xc.shape[0]}): {host_ms:.3f} ms")
     assert host_ms < 0.7
+
+
+@pytest.mark.parametrize("tag", ["hrnet_w32_256x192", "rsgnet_w32_256x192_coco"])
+def test_forwards_on_alternating_streams_overlap_safely(tag):
+    """Each stream gets a plan of its own (models/_base.py plan_for): batches issued on two streams in turn may run at
+    the same time, and every one of them must come out bit-identical to the one-stream forward of the same input."""
+    cfg, model, sd, x, gold = load_case(tag)
+    model = model.cuda().eval()
+    xs = [x.cuda(), torch.flip(x, dims=[3]).contiguous().cuda(), (0.5 * x).cuda()]
+    as_tuple = (lambda o: (o,) if torch.is_tensor(o) else tuple(t for t in o if torch.is_tensor(t)))   # (RSGNet: the lazy relation handle is not a tensor)
+    with torch.no_grad():
+        want = [tuple(t.clone() for t in as_tuple(model(xi))) for xi in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream())
+        got = []
+        for k in range(12):
+            with torch.cuda.stream(streams[k % 2]):
+                got.append((k % 3, as_tuple(model(xs[k % 3]))))
+        torch.cuda.synchronize()
+    keys = [k for k in model._plans]
+    assert len({k[3] for k in keys}) == 3                       # the default stream's plan and one per side stream
+    for which, outs in got:
+        for a_, b_ in zip(outs, want[which]):
+            assert torch.equal(a_, b_)
+
+
+def test_side_stream_plans_are_bounded():
+    cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+    model = model.cuda().eval()
+    model.MAX_STREAM_PLANS = 2
+    xc = x.cuda()
+    with torch.no_grad():
+        y0 = model(xc).clone()
+        torch.cuda.synchronize()
+        for _ in range(4):
+            s_ = torch.cuda.Stream()
+            with torch.cuda.stream(s_):
+                assert torch.equal(model(xc), y0)
+            torch.cuda.synchronize()
+    assert len(model._plans) == 3                               # default stream + the two most recent side streams
