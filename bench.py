@@ -586,6 +586,10 @@ def main():
                          "algorithmic_mb_per_launch": dom.get("alg_mb_per_launch"),
                          "kernel": dom_name, "launches": dom["launches"], "kernel_us_per_step": dom["us"],
                          "empty_event_pair_us": round(pair_us, 2),      # already taken off every launch's figure
+                         # the kernel figures (achieved, frac, families) are a property of the kernels: measured with the
+                         # launch list running alone on one stream; with 2 batches in flight (whole_step, value) kernels of
+                         # both batches share the CUs and a profiler's per-kernel durations grow accordingly
+                         "kernel_figures_measured": "launch list alone on one stream (rocprofv3: profiles/r03m_*, --streams 1)",
                          "kernel_gflop_per_step": dom["gflop"],
                          "whole_step": {"achieved": round(whole, 1), "frac": round(whole / PEAK_TFLOPS, 4),
                                         "device_ms_per_step": round(dev_ms / a.steps, 4),
