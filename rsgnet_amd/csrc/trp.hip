@@ -379,9 +379,6 @@ __global__ void __launch_bounds__(256) trp_project_g_kernel(const char* __restri
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            char* __restrict__ gT, int S, long total) {
-    __shared__ float ws[C * C + C];
-    for (int i = threadIdx.x; i < C * C + C; i += 256) ws[i] = i < C * C ? w[i] : bias[i - C * C];
-    __syncthreads();
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long b = i / S;
@@ -400,9 +397,9 @@ __global__ void __launch_bounds__(256) trp_project_g_kernel(const char* __restri
     typename DT::elem* go = reinterpret_cast<typename DT::elem*>(gT) + (size_t)b * C * S + (s & ~15) + pos;
 #pragma unroll 4
     for (int co = 0; co < C; ++co) {
-        float acc = ws[C * C + co];
+        float acc = bias[co];                              // uniform addresses: SGPR operands (see trp_w_project_kernel)
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) acc = fmaf(ws[co * C + ci], xv[ci], acc);
+        for (int ci = 0; ci < C; ++ci) acc = fmaf(w[co * C + ci], xv[ci], acc);
         go[(size_t)co * S] = (typename DT::elem)acc;
     }
 }
@@ -444,10 +441,7 @@ __global__ void __launch_bounds__(256) trp_w_project_kernel(const void* __restri
                                                            const float* __restrict__ bias, float* __restrict__ y,
                                                            float* __restrict__ part, int S) {
     constexpr int G = 8, CG = C / G;
-    __shared__ float ws[C * C + C];
     __shared__ float red[4];
-    for (int i = threadIdx.x; i < C * C + C; i += 256) ws[i] = i < C * C ? w[i] : bias[i - C * C];
-    __syncthreads();
     const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
     const size_t row = ((size_t)b * S + s) * C;
     float xv[C], yv[C];
@@ -469,9 +463,12 @@ __global__ void __launch_bounds__(256) trp_w_project_kernel(const void* __restri
     }
 #pragma unroll
     for (int co = 0; co < C; ++co) {
-        float acc = ws[C * C + co];
+        // W and its bias are read through the scalar cache into SGPRs (uniform addresses).  They used to be staged in LDS and
+        // read back as broadcast ds_reads feeding v_pk_fma_f32: beside another stream's kernels that form dropped single FMA
+        // terms for 16 lanes at a time (profiles/r03n_trp_projection_under_contention.txt)
+        float acc = bias[co];
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) acc = fmaf(ws[co * C + ci], xv[ci], acc);
+        for (int ci = 0; ci < C; ++ci) acc = fmaf(w[co * C + ci], xv[ci], acc);
         yv[co] = acc;
     }
 #pragma unroll
@@ -498,10 +495,12 @@ __global__ void __launch_bounds__(256) trp_gn_apply_kernel(const float* __restri
                                                           const float* __restrict__ beta, char* __restrict__ out,
                                                           int out_ld, int S) {
     constexpr int G = 8, CG = C / G;
-    __shared__ float scale[C], shift[C];
+    // every thread merges the crop's partials itself (uniform addresses: scalar loads, the same operations in the same order
+    // in every thread); no LDS (see trp_w_project_kernel)
+    float scale[C], shift[C];
     const int b = blockIdx.y, nb = gridDim.x;
-    if (threadIdx.x < G) {
-        const int g = threadIdx.x;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
         const float* pi = part + ((size_t)b * nb * G + g) * 2;
         const float nk = 256.f * CG;
         float mean = 0.f;
@@ -520,7 +519,6 @@ __global__ void __launch_bounds__(256) trp_gn_apply_kernel(const float* __restri
             shift[g * CG + c] = beta[g * CG + c] - mean * ga;
         }
     }
-    __syncthreads();
     const int s = blockIdx.x * 256 + threadIdx.x;
     const float* yr = y + ((size_t)b * S + s) * C;
     typename DT::elem* orow = reinterpret_cast<typename DT::elem*>(out) + ((size_t)b * S + s) * out_ld;

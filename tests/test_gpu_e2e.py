@@ -551,9 +551,12 @@ def test_forward_follows_in_place_weight_updates_and_its_host_time_stays_small()
 @pytest.mark.parametrize("tag", ["hrnet_w32_256x192", "rsgnet_w32_256x192_coco"])
 def test_forwards_on_alternating_streams_overlap_safely(tag):
     """Each stream gets a plan of its own (models/_base.py plan_for): batches issued on two streams in turn may run at
-    the same time, and every one of them must come out bit-identical to the one-stream forward of the same input."""
+    the same time, and every one of them must come out bit-identical to the one-stream forward of the same input.
+    (Round 3: RSGNet's kpt maps failed this - the TRP's W projection dropped FMA terms beside another stream's kernels,
+    profiles/r03n_trp_projection_under_contention.txt; tools/stream_soak.py is the long form of this test.)"""
     cfg, model, sd, x, gold = load_case(tag)
     model = model.cuda().eval()
+    x = torch.cat([x] * 8)          # 16 crops: with 2 the TRP defect below showed in 1 forward of 10, with 16 in 6 of 10
     xs = [x.cuda(), torch.flip(x, dims=[3]).contiguous().cuda(), (0.5 * x).cuda()]
     as_tuple = (lambda o: (o,) if torch.is_tensor(o) else tuple(t for t in o if torch.is_tensor(t)))   # (RSGNet: the lazy relation handle is not a tensor)
     with torch.no_grad():
@@ -563,9 +566,9 @@ def test_forwards_on_alternating_streams_overlap_safely(tag):
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream())
         got = []
-        for k in range(12):
+        for k in range(48):
             with torch.cuda.stream(streams[k % 2]):
-                got.append((k % 3, as_tuple(model(xs[k % 3]))))
+                got.append((k % 3, tuple(t.clone() for t in as_tuple(model(xs[k % 3])))))
         torch.cuda.synchronize()
     keys = [k for k in model._plans]
     assert len({k[3] for k in keys}) == 3                       # the default stream's plan and one per side stream
