@@ -652,10 +652,8 @@ __global__ void __launch_bounds__(256) trp_tail_bwd_apply_kernel(const char* __r
                                                                 const float* __restrict__ w, const float* __restrict__ pg,
                                                                 float* __restrict__ dy, float* __restrict__ de, int S) {
     constexpr int G = 8, CG = C / G;
-    __shared__ float ws[C * C];
     __shared__ float mean_s[G], rstd_s[G], m1_s[G], m2_s[G];
     const int b = blockIdx.y, nb = gridDim.x;
-    for (int i = threadIdx.x; i < C * C; i += 256) ws[i] = w[i];
     gn_group_stats<C>(part, b, nb, mean_s, rstd_s);
     if (threadIdx.x < G) {
         float a1 = 0.f, a2 = 0.f;
@@ -683,7 +681,7 @@ __global__ void __launch_bounds__(256) trp_tail_bwd_apply_kernel(const char* __r
 #pragma unroll
     for (int co = 0; co < C; ++co)
 #pragma unroll
-        for (int ci = 0; ci < C; ++ci) dev[ci] = fmaf(ws[co * C + ci], dyv[co], dev[ci]);
+        for (int ci = 0; ci < C; ++ci) dev[ci] = fmaf(w[co * C + ci], dyv[co], dev[ci]);     // SGPR operands (see trp_w_project_kernel)
 #pragma unroll
     for (int k = 0; k < C / 4; ++k) {
         *reinterpret_cast<float4*>(dy + row + 4 * k) = make_float4(dyv[4 * k], dyv[4 * k + 1], dyv[4 * k + 2], dyv[4 * k + 3]);
