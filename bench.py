@@ -7,6 +7,16 @@
 A step = one forward of the drop-in ``models.pose_hrnet`` over one batch of synthetic crops that is
 already resident in HBM.  Crops are independent, so N GPUs run N independent shards (weak scaling, no
 collective on the data path).  Prints ONE JSON line on rank 0.
+
+How the timed region is run:
+  * consecutive steps are issued on two alternating HIP streams (--streams, default 2): the model keeps one plan per stream,
+    two batches are in flight and overlap on the GPU; `value` / `ms_per_step` / `roofline.whole_step` are of that region,
+    `single_stream` in the same line is the same K steps issued one after the other, `config.parallelism` says which;
+  * in front of the W warm-up steps the step runs untimed until its time stops improving (settle_clocks: a card that sat idle
+    comes back slowly); the {W, K} region timed first, cold, is kept as `config.cold_start`;
+  * nothing sits between the warm-up and the timed region (the finiteness check comes after it);
+  * the kernel figures (`roofline.achieved/frac`, `families`) come from a per-launch pass over the launch list running alone on
+    one stream, event pairs around every launch, the duration of an empty event pair taken off.
 """
 from __future__ import annotations
 
