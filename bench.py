@@ -612,7 +612,19 @@ def main():
             for _ in range(max(a.warmup, 1) + 40):
                 step()
             w1, d1 = timed_steps(step, a.steps, None, dev)
+            # ... and the overlapped forwards must be the one-stream forward bit for bit: 8 more steps on the alternating
+            # streams beside each other, every output against the one-stream result of the same input
+            ref1 = step()
+            ref1 = [t.clone() for t in ((ref1,) if torch.is_tensor(ref1) else ref1) if torch.is_tensor(t)]
+            torch.cuda.synchronize()
             side = keep
+            outs8 = []
+            for _ in range(8):
+                o_ = step()
+                outs8.append([t for t in ((o_,) if torch.is_tensor(o_) else o_) if torch.is_tensor(t)])
+            torch.cuda.synchronize()
+            line["overlapped_outputs_bit_identical"] = all(torch.equal(p_, q_) for o_ in outs8 for p_, q_ in zip(o_, ref1))
+            assert line["overlapped_outputs_bit_identical"], "forwards overlapping on two streams differ from the one-stream forward"
             line["single_stream"] = {"value": round(batch * a.steps / w1, 1), "unit": "images/s",
                                      "ms_per_step": round(w1 / a.steps * 1e3, 4),
                                      "whole_step_frac": round(gflop * fwd_imgs / (d1 / a.steps) / PEAK_TFLOPS, 4)}
