@@ -140,6 +140,7 @@ class HipPoseModule(nn.Module):
         if plan is None:
             mine = [k for k in self._plans if k[:3] == base and k[3] != 0]
             if stream != 0 and len(mine) >= self.MAX_STREAM_PLANS:
+                torch.cuda.synchronize(x.device)  # its last forward may still be running on its stream (rare path)
                 del self._plans[mine[0]]          # dicts keep insertion order
             with torch.cuda.device(x.device):
                 plan = self._build_plan(int(x.shape[0]), x.device)
