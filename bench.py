@@ -525,9 +525,12 @@ def main():
     o0 = out if torch.is_tensor(out) else out[1]
     assert torch.isfinite(o0).all(), "non-finite heatmaps"
 
-    if side is not None:                          # the per-launch pass below runs one of the side streams' plans, on its stream
+    if side is not None:        # the per-launch pass below runs the DEFAULT stream's plan (tuned for a forward running alone;
+        torch.cuda.synchronize()                  # the side streams' plans trade makespan for CU-time, plan.py CHAIN_PACK)
+        keep_side, side = side, None
+        step()                                    # builds / binds it
+        side = keep_side
         torch.cuda.synchronize()
-        torch.cuda.set_stream(side[0])
     plan = model.plan_for(torch.cat((x, x)) if a.flip_test else x)
     plan.check_handoff()        # the in-launch hand-off's error word, read back (raises if any poll gave up)
     # per-launch timing pass (outside the timed region, rank 0): the launch list runs IN ORDER, eagerly, with a HIP

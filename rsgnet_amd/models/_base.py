@@ -142,8 +142,12 @@ class HipPoseModule(nn.Module):
             if stream != 0 and len(mine) >= self.MAX_STREAM_PLANS:
                 torch.cuda.synchronize(x.device)  # its last forward may still be running on its stream (rare path)
                 del self._plans[mine[0]]          # dicts keep insertion order
-            with torch.cuda.device(x.device):
-                plan = self._build_plan(int(x.shape[0]), x.device)
+            self._plan_for_side_stream = stream != 0     # read by Plan.__init__ (throughput tuning of overlapping forwards)
+            try:
+                with torch.cuda.device(x.device):
+                    plan = self._build_plan(int(x.shape[0]), x.device)
+            finally:
+                self._plan_for_side_stream = False
             self._plans[key] = plan
         return plan
 

@@ -119,6 +119,8 @@ class Plan:
         self.flops = 0
         # lanes = HIP streams the launches are spread over (independent HRNet branches run concurrently);
         # cross-lane ordering comes from events derived from each op's buffer reads/writes
+        # a plan built for a side stream expects to share the GPU with another stream's forward: tuned for CU-time, not makespan
+        self.throughput = bool(getattr(model, "_plan_for_side_stream", False))
         self.n_lanes = max(1, min(4, int(os.environ.get("RSGNET_HIP_LANES", "4"))))
         self._lane = 0
         self._streams: List[torch.cuda.Stream] = []
@@ -801,9 +803,14 @@ class Plan:
                 self._ho_flags.append(flags)          # ... and again by _handoff_failed after a poll that gave up
                 prod.done_flags = flags.data_ptr()
                 items[k].wait_flags = flags.data_ptr()
-        # RSGNET_HIP_CHAIN_PACK=1 (experiment, off: measured neutral): when the grid has more workgroups than CUs,
-        # let the smallest whole-image maps take two images per workgroup until it fits in one round
-        if os.environ.get("RSGNET_HIP_CHAIN_PACK", "0") != "0":
+        # When the grid has more workgroups than CUs, let the smallest whole-image maps take two images per workgroup until
+        # it fits in one round.  Fewer, twice as long workgroups: a launch running ALONE gets slower (the longest workgroup
+        # sets its makespan: chain family 826 -> 913 us, step +4 %), a launch that shares the GPU with another stream's
+        # forward gets cheaper in CU-time (two streams: 1.340 -> 1.316, 1.342 -> 1.314 ms per batch of 64,
+        # profiles/r03n_ab_chain_pack_two_streams.txt).  RSGNET_HIP_CHAIN_PACK = auto (default): on for the plans of side
+        # streams (self.throughput, models/_base.py plan_for), off for the default stream's; 0 / 1 force it.
+        pack = os.environ.get("RSGNET_HIP_CHAIN_PACK", "auto")
+        if pack == "1" or (pack == "auto" and self.throughput):
             cus = torch.cuda.get_device_properties(self.device).multi_processor_count
             info = (C.c_int32 * 4)()
             blocks = []
