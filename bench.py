@@ -627,10 +627,18 @@ def main():
                 outs8.append([t for t in ((o_,) if torch.is_tensor(o_) else o_) if torch.is_tensor(t)])
             torch.cuda.synchronize()
             line["overlapped_outputs_bit_identical"] = all(torch.equal(p_, q_) for o_ in outs8 for p_, q_ in zip(o_, ref1))
-            assert line["overlapped_outputs_bit_identical"], "forwards overlapping on two streams differ from the one-stream forward"
             line["single_stream"] = {"value": round(batch * a.steps / w1, 1), "unit": "images/s",
                                      "ms_per_step": round(w1 / a.steps * 1e3, 4),
                                      "whole_step_frac": round(gflop * fwd_imgs / (d1 / a.steps) / PEAK_TFLOPS, 4)}
+            if not line["overlapped_outputs_bit_identical"]:
+                # never seen since the TRP fix (DESIGN 9b'); if it happens the overlapped figure is not a valid one: the line
+                # falls back to the one-stream region (world 1; with several ranks the max over ranks is not available here)
+                print("bench.py: forwards overlapping on two streams differ from the one-stream forward; reporting the one-stream "
+                      "figures", file=sys.stderr)
+                line["overlapped_rejected"] = {"value": line["value"], "ms_per_step": line["ms_per_step"]}
+                line["value"], line["ms_per_step"] = world * line["single_stream"]["value"], line["single_stream"]["ms_per_step"]
+                line["roofline"]["whole_step"]["frac"] = line["single_stream"]["whole_step_frac"]
+                line["config"]["streams"] = 1
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh, gpu_model=model)
         if world == 1 and not (a.no_other_dtype or a.no_cpu_baseline) and not (a.flip_test or a.pipeline or a.from_host):
