@@ -120,6 +120,10 @@ class TrainPlan:
         import os
         self.use_graph = os.environ.get("RSGNET_HIP_TRAIN_GRAPH", "1") != "0"
         self.use_lanes = os.environ.get("RSGNET_HIP_TRAIN_LANES", "1") != "0"
+        # OPT-IN, measured slower (13.81 / 13.69 against 13.11 / 13.11 ms per step, RSGNet 16.56 / 16.68 against 16.08 / 16.16;
+        # bit-identical gradients): the weight-gradient launches on a stream of their own beside the data-gradient chain
+        self.wgrad_stream_on = os.environ.get("RSGNET_HIP_TRAIN_WGRAD_STREAM", "0") == "1"
+        self._wgrad_stream: Optional[torch.cuda.Stream] = None
         self.flops_fwd = 0
         W, H = model.cfg.MODEL.IMAGE_SIZE
         self.H, self.W, self.J = H, W, model.cfg.MODEL.NUM_JOINTS
@@ -691,10 +695,39 @@ class TrainPlan:
         torch._foreach_add_(self._nbt, 1)            # num_batches_tracked of every BatchNorm, one launch
 
     def _run_backward(self, seg: Optional[int] = None):
-        s = torch.cuda.current_stream(self.device).cuda_stream
+        main = torch.cuda.current_stream(self.device)
+        s = main.cuda_stream
         lo, hi = (0, len(self.bwd)) if seg is None else self._bwd_segments[seg]
+        if not self.wgrad_stream_on:
+            for rec in self.bwd[lo:hi]:
+                rec[1](s)
+            return
+        # The weight-gradient launches on a stream of their own, beside the data-gradient / BatchNorm chain: a weight
+        # gradient reads a forward activation and the gradient its BatchNorm's backward wrote (both final by then and not
+        # written again in this pass) and writes only its parameter's gradient and the weight-gradient workspaces, whose
+        # order the side stream keeps.  It waits for the main stream's position it was recorded at; the main stream waits
+        # for the side stream where the segment ends (where grad_ready_hooks and the optimizer look).  Inside a graph
+        # capture the events become edges of the graph.
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(self.device)
+        side, keep, behind = self._wgrad_stream, [], False
+        self._bwd_events = keep                     # events of a capture must outlive it
         for rec in self.bwd[lo:hi]:
-            rec[1](s)
+            if isinstance(rec[1], _WgradLaunch):
+                if not behind:                      # one wait per run of weight-gradient launches
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    keep.append(ev)
+                    behind = True
+                rec[1](side.cuda_stream)
+            else:
+                rec[1](s)
+                behind = False
+        ev = torch.cuda.Event()
+        ev.record(side)
+        main.wait_event(ev)
+        keep.append(ev)
 
     def _prepare(self):
         """Before a forward: follow re-seated parameters / gradients, and (re)capture the two HIP graphs once the
