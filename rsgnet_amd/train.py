@@ -120,9 +120,17 @@ class TrainPlan:
         import os
         self.use_graph = os.environ.get("RSGNET_HIP_TRAIN_GRAPH", "1") != "0"
         self.use_lanes = os.environ.get("RSGNET_HIP_TRAIN_LANES", "1") != "0"
-        # OPT-IN, measured slower (13.81 / 13.69 against 13.11 / 13.11 ms per step, RSGNet 16.56 / 16.68 against 16.08 / 16.16;
-        # bit-identical gradients): the weight-gradient launches on a stream of their own beside the data-gradient chain
-        self.wgrad_stream_on = os.environ.get("RSGNET_HIP_TRAIN_WGRAD_STREAM", "0") == "1"
+        # RSGNET_HIP_TRAIN_WGRAD_STREAM (profiles/r03o_train_wgrad_stream.txt; gradients bit-identical in every form):
+        #   0  every launch of the backward pass on one stream (rounds 2-3: 13.11 ms per step of 32)
+        #   1  the weight-gradient launches on a stream of their own INSIDE the segment's graph (events as graph edges):
+        #      slower, 13.75 ms -- branches inside one graph cost more than they hide
+        #   2  (default) the weight gradients of a backward segment as a GRAPH OF THEIR OWN, replayed on the side stream once
+        #      the segment's data-gradient graph has been issued: it runs beside the NEXT segment's chain -- overlap between
+        #      graphs, the form that paid for inference.  12.47 ms with the three data-parallel segments, 11.95 ms with one
+        #      segment per HighResolutionModule (RSGNET_HIP_TRAIN_SEGMENTS=module, default; every:N cuts every N launches)
+        mode = os.environ.get("RSGNET_HIP_TRAIN_WGRAD_STREAM", "2")
+        self.wgrad_stream_on = mode == "1"
+        self.wgrad_split = mode == "2"
         self._wgrad_stream: Optional[torch.cuda.Stream] = None
         self.flops_fwd = 0
         W, H = model.cfg.MODEL.IMAGE_SIZE
@@ -609,8 +617,25 @@ class TrainPlan:
         # are told which parameters are still pending.
         def top(nm):
             return nm.split(".")[0]
+
+        def module_of(nm):                       # "stage4.2.fuse.1.0" -> "stage4.2"; everything else by its top-level name
+            parts = nm.split(".")
+            return ".".join(parts[:2]) if parts[0].startswith("stage") and len(parts) > 1 else parts[0]
         cuts = []
+        seg_mode = os.environ.get("RSGNET_HIP_TRAIN_SEGMENTS", "module") if self.wgrad_split else "stage"
+        by_module = seg_mode == "module"
+        every = int(seg_mode.split(":")[1]) if seg_mode.startswith("every:") else 0
         for k in range(1, len(self.bwd)):
+            if every:
+                if k % every == 0:
+                    cuts.append(k)
+                continue
+            if by_module:
+                # with the weight gradients of a segment running beside the NEXT segment's chain (wgrad_split), finer segments
+                # overlap more of them: one per HighResolutionModule, layer1, the stem
+                if module_of(self.bwd[k - 1][0]) != module_of(self.bwd[k][0]):
+                    cuts.append(k)
+                continue
             a, b = top(self.bwd[k - 1][0]), top(self.bwd[k][0])
             if a != b and a in ("stage4", "stage3") and b not in ("stage4", "stage3"):
                 cuts.append(k)
@@ -694,10 +719,17 @@ class TrainPlan:
             rec[1](s)
         torch._foreach_add_(self._nbt, 1)            # num_batches_tracked of every BatchNorm, one launch
 
-    def _run_backward(self, seg: Optional[int] = None):
+    def _run_backward(self, seg: Optional[int] = None, which: Optional[str] = None):
+        """which: None = every launch of the segment; "main" / "wgrad" = all but / only the weight-gradient launches
+        (wgrad_mode 2: two graphs per segment, the second replayed on the side stream behind the first)."""
         main = torch.cuda.current_stream(self.device)
         s = main.cuda_stream
         lo, hi = (0, len(self.bwd)) if seg is None else self._bwd_segments[seg]
+        if which is not None:
+            for rec in self.bwd[lo:hi]:
+                if isinstance(rec[1], _WgradLaunch) == (which == "wgrad"):
+                    rec[1](s)
+            return
         if not self.wgrad_stream_on:
             for rec in self.bwd[lo:hi]:
                 rec[1](s)
@@ -755,9 +787,14 @@ class TrainPlan:
             stats = [(m.running_mean.clone(), m.running_var.clone()) for m in self._bns]
             with torch.cuda.graph(gf):
                 self._run_forward()
+            gw = [torch.cuda.CUDAGraph() for _ in self._bwd_segments] if self.wgrad_split else None
             for k, g in enumerate(gb):
                 with torch.cuda.graph(g):
-                    self._run_backward(k)
+                    self._run_backward(k, "main" if self.wgrad_split else None)
+                if gw is not None:
+                    with torch.cuda.graph(gw[k]):
+                        self._run_backward(k, "wgrad")
+            self._wgrad_graphs = gw
             # capture does not execute, but be explicit that nothing observable moved
             for t, c in zip(self._nbt, nbt):
                 t.copy_(c)
@@ -796,14 +833,35 @@ class TrainPlan:
         else:
             self.dfeat16.copy_(dheat.permute(0, 2, 3, 1))          # fp32 NCHW -> bf16 NHWC (layout and type in one copy)
         hooks = getattr(self.model, "grad_ready_hooks", ())
-        for k in range(len(self._bwd_segments)):
-            if self._graphs is not None:
-                self._graphs[1][k].replay()
-            else:
-                self._run_backward(k)
-            if k + 1 < len(self._bwd_segments):
-                for cb in hooks:                 # e.g. DataParallelStep: all-reduce the finished tail under the rest
-                    cb(self._pending_after[k])
+        if self.wgrad_split:
+            main = torch.cuda.current_stream(self.device)
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream(self.device)
+            side = self._wgrad_stream
+            for k in range(len(self._bwd_segments)):
+                if self._graphs is not None:
+                    self._graphs[1][k].replay()
+                else:
+                    self._run_backward(k, "main")
+                side.wait_stream(main)               # the segment's gradient maps are final where the main stream stands now
+                with torch.cuda.stream(side):
+                    if self._graphs is not None:
+                        self._wgrad_graphs[k].replay()
+                    else:
+                        self._run_backward(k, "wgrad")
+                    if k + 1 < len(self._bwd_segments):
+                        for cb in hooks:             # the segment's parameter gradients are final on the SIDE stream
+                            cb(self._pending_after[k])
+            main.wait_stream(side)                   # the optimizer, and the next forward's writes to the activations
+        else:
+            for k in range(len(self._bwd_segments)):
+                if self._graphs is not None:
+                    self._graphs[1][k].replay()
+                else:
+                    self._run_backward(k)
+                if k + 1 < len(self._bwd_segments):
+                    for cb in hooks:                 # e.g. DataParallelStep: all-reduce the finished tail under the rest
+                        cb(self._pending_after[k])
         if self._graphs is None:
             self._warm += 1
         self._publish_grads()

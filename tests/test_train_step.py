@@ -282,7 +282,7 @@ def test_training_step_composition_is_independent_of_the_launch_structure(monkey
     base = _one_step_grads(monkeypatch, {})
     plain = _one_step_grads(monkeypatch, {"RSGNET_HIP_TRAIN_LANES": "0", "RSGNET_HIP_TRAIN_FUSE_LANES": "0",
                                           "RSGNET_HIP_TRAIN_FOLD_ADD": "0", "RSGNET_HIP_TRAIN_WGRAD_PIPE": "0",
-                                          "RSGNET_HIP_TRAIN_GRAPH": "0"})
+                                          "RSGNET_HIP_TRAIN_GRAPH": "0", "RSGNET_HIP_TRAIN_WGRAD_STREAM": "0"})
     assert torch.equal(base[0], plain[0])                 # the forward has no such freedom at all
     worst = []
     for n, g in base[1].items():
@@ -294,11 +294,12 @@ def test_training_step_composition_is_independent_of_the_launch_structure(monkey
     print("composition: largest relative L2 differences", worst[:5])
     assert worst[0][0] < FOLD_BAR, worst[:8]
     # each switch alone against the default, same bar: a failure names the switch
-    for k in ("RSGNET_HIP_TRAIN_LANES", "RSGNET_HIP_TRAIN_FOLD_ADD", "RSGNET_HIP_TRAIN_WGRAD_PIPE", "RSGNET_HIP_TRAIN_WGRAD_STREAM"):
-        one = _one_step_grads(monkeypatch, {k: "1" if k == "RSGNET_HIP_TRAIN_WGRAD_STREAM" else "0"})     # (that one is opt-in)
+    for k, v in (("RSGNET_HIP_TRAIN_LANES", "0"), ("RSGNET_HIP_TRAIN_FOLD_ADD", "0"), ("RSGNET_HIP_TRAIN_WGRAD_PIPE", "0"),
+                 ("RSGNET_HIP_TRAIN_WGRAD_STREAM", "0"), ("RSGNET_HIP_TRAIN_WGRAD_STREAM", "1")):     # (default: 2)
+        one = _one_step_grads(monkeypatch, {k: v})
         bad = [(float((one[1][n].double() - g.double()).norm()) / max(float(g.double().norm()), 1e-30), n) for n, g in base[1].items()]
         bad.sort(reverse=True)
-        print(k, "flipped:", bad[:2])
+        print(k, "=", v, ":", bad[:2])
         assert bad[0][0] < FOLD_BAR, (k, bad[:6])
         if k in ("RSGNET_HIP_TRAIN_WGRAD_PIPE", "RSGNET_HIP_TRAIN_WGRAD_STREAM"):
             # only WHERE the partial tiles are summed / WHEN a weight gradient runs (beside the data-gradient chain, on a
