@@ -415,7 +415,7 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="issue consecutive batches on this many alternating HIP streams (each has its own plan: arena + graph), "
                          "so that two batches in flight overlap on the GPU (same-visit: 1.54 -> 1.36 ms per batch of 64); the line "
-                         "carries the one-stream figure too (`single_stream`).  1 with --pipeline / --from-host (shared staging)")
+                         "carries the one-stream figure too (`single_stream`).  1 with --flip-test / --pipeline (forward_flip_test overlaps its own two forwards) and --from-host")
     ap.add_argument("--settle-seconds", type=float, default=2.0,
                     help="inference: at most this long, untimed steps of the same workload in front of the warm-up until "
                          "the step time stops improving (settle_clocks; 0: time the cold region, as rounds 1-2 did)")
@@ -486,8 +486,9 @@ def main():
 
     x_host = x.cpu().pin_memory() if a.from_host else None
 
-    if a.pipeline or a.from_host:
-        a.streams = 1
+    if a.pipeline or a.from_host or a.flip_test:
+        a.streams = 1           # (flip test: forward_flip_test itself runs its two forwards of batch B beside each other;
+                                #  two such calls in flight on top measured slower, 3.52 -> 3.91 ms)
     side = [torch.cuda.Stream(dev) for _ in range(a.streams)] if a.streams > 1 else None
     issued = [0]
 
@@ -531,7 +532,11 @@ def main():
         step()                                    # builds / binds it
         side = keep_side
         torch.cuda.synchronize()
-    plan = model.plan_for(torch.cat((x, x)) if a.flip_test else x)
+    if a.flip_test:             # the flip test runs two forwards of batch B beside each other (rsgnet_amd/flip.py): the pass
+        with torch.no_grad():   # below times the launch list of ONE of them, on the default stream's plan
+            model(x)
+        torch.cuda.synchronize()
+    plan = model.plan_for(x)
     plan.check_handoff()        # the in-launch hand-off's error word, read back (raises if any poll gave up)
     # per-launch timing pass (outside the timed region, rank 0): the launch list runs IN ORDER, eagerly, with a HIP
     # event pair around every launch on the launch stream, several passes; each launch therefore meets the caches
@@ -584,7 +589,8 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": model.compute_dtype, "data": "synthetic",
             "config": {"workload": a.workload, "per_gpu_batch": batch, "global_batch": batch * world,
-                       "image": f"{wh[1]}x{wh[0]}", "parallelism": f"dp{world} (independent shards)" + (f", {a.streams} batches in flight per GPU (alternating streams)" if side is not None else ""),
+                       "image": f"{wh[1]}x{wh[0]}", "parallelism": f"dp{world} (independent shards)" + (f", {a.streams} batches in flight per GPU (alternating streams)" if side is not None else "")
+                       + (", the flip test's two forwards of batch B overlap on two streams" if a.flip_test else ""),
                        "weights": "synthetic name-keyed rule + calibrated BN stats", "graph": plan.graph_mode,
                        "launches_per_step": len(plan.ops), "streams": a.streams,
                        # the figures of the same {warm-up, steps} region timed cold, as rounds 1-2 timed `value`, and the
