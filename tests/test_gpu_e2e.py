@@ -303,12 +303,15 @@ def test_flip_merge_kernel_is_exact(shift):
 
 
 def test_flip_test_forward_hrnet():
-    """One 2B forward + fused merge == the reference's two forwards + host flip_back (function.py:125-146)."""
+    """Two overlapping forwards (or one of batch 2B: same bits) + fused merge == the reference's two forwards + host
+    flip_back (function.py:125-146)."""
     from rsgnet_amd.flip import forward_flip_test
     cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
     model = model.cuda()
     with torch.no_grad():
-        got = forward_flip_test(model, x.cuda(), COCO_FLIP_PAIRS).cpu()
+        got_dev = forward_flip_test(model, x.cuda(), COCO_FLIP_PAIRS)
+        assert torch.equal(got_dev, forward_flip_test(model, x.cuda(), COCO_FLIP_PAIRS, overlap=False))
+        got = got_dev.cpu()
     want = po.flip_test_merge(po.hrnet_forward(sd, cfg, x), po.hrnet_forward(sd, cfg, x.flip(3)), COCO_FLIP_PAIRS)
     e = _stats("flip-test heatmaps", got, want.numpy())
     assert e < REL_TOL * float(want.std())
