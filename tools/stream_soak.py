@@ -32,4 +32,10 @@ with torch.no_grad():
                 if not torch.equal(a, b):
                     bad[nm] = bad.get(nm, 0) + 1
         done += 24
-print(f"{tag} batch {xs[0].shape[0]}: {done} overlapped forwards, outputs that differ from the one-stream result: {bad or 'none'}")
+import ctypes
+from rsgnet_amd import hip
+n_to = ctypes.c_uint32(0)
+hip.check(hip.lib().rsg_chain_handoff_timeouts(ctypes.byref(n_to)))
+uses = any(p._ho_flags for p in model._plans.values())
+print(f"{tag} batch {xs[0].shape[0]}: {done} overlapped forwards, outputs that differ from the one-stream result: {bad or 'none'}; "
+      f"in-launch hand-offs {'in use' if uses else 'not used'}, consumers that gave up waiting: {n_to.value}")
