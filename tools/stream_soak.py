@@ -11,6 +11,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 600
 mult = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 cfg, model, sd, x, gold = load_case(tag)
 model = model.cuda().eval()
+model.compute_dtype = os.environ.get("SOAK_DTYPE", "fp16")
 xb = torch.cat([x] * mult)
 xs = [xb.cuda(), torch.flip(xb, dims=[3]).contiguous().cuda(), (0.5 * xb).cuda()]
 tens = lambda o: [t for t in ((o,) if torch.is_tensor(o) else o) if torch.is_tensor(t)]
@@ -37,5 +38,5 @@ from rsgnet_amd import hip
 n_to = ctypes.c_uint32(0)
 hip.check(hip.lib().rsg_chain_handoff_timeouts(ctypes.byref(n_to)))
 uses = any(p._ho_flags for p in model._plans.values())
-print(f"{tag} batch {xs[0].shape[0]}: {done} overlapped forwards, outputs that differ from the one-stream result: {bad or 'none'}; "
+print(f"{tag} {model.compute_dtype} batch {xs[0].shape[0]}: {done} overlapped forwards, outputs that differ from the one-stream result: {bad or 'none'}; "
       f"in-launch hand-offs {'in use' if uses else 'not used'}, consumers that gave up waiting: {n_to.value}")
