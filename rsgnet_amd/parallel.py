@@ -105,11 +105,17 @@ class DataParallelStep:
 
     def _on_grads_ready(self, pending_params):
         """`pending_params`: the parameters whose gradient is NOT final yet."""
-        hi = 0
-        for p in pending_params:
-            off = self.optimizer.flat_offset_of(p)
-            if off is not None:
-                hi = max(hi, off + p.numel())
+        cache = self.__dict__.setdefault("_ready_hi", {})          # the plan hands over the same list object every step
+        key = (id(pending_params), len(pending_params), id(pending_params[0]) if pending_params else 0,
+               id(pending_params[-1]) if pending_params else 0)
+        hi = cache.get(key)
+        if hi is None:
+            hi = 0
+            for p in pending_params:
+                off = self.optimizer.flat_offset_of(p)
+                if off is not None:
+                    hi = max(hi, off + p.numel())
+            cache[key] = hi
         self.reducer.ready(hi)
 
     def exchange(self):
