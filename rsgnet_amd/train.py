@@ -127,7 +127,8 @@ class TrainPlan:
         #   2  (default) the weight gradients of a backward segment as a GRAPH OF THEIR OWN, replayed on the side stream once
         #      the segment's data-gradient graph has been issued: it runs beside the NEXT segment's chain -- overlap between
         #      graphs, the form that paid for inference.  12.47 ms with the three data-parallel segments, 11.95 ms with one
-        #      segment per HighResolutionModule (RSGNET_HIP_TRAIN_SEGMENTS=module, default; every:N cuts every N launches)
+        #      segment per HighResolutionModule (RSGNET_HIP_TRAIN_SEGMENTS=module), 11.86 ms cutting every 40 launches
+        #      (every:40, default)
         mode = os.environ.get("RSGNET_HIP_TRAIN_WGRAD_STREAM", "2")
         self.wgrad_stream_on = mode == "1"
         self.wgrad_split = mode == "2"
@@ -622,7 +623,7 @@ class TrainPlan:
             parts = nm.split(".")
             return ".".join(parts[:2]) if parts[0].startswith("stage") and len(parts) > 1 else parts[0]
         cuts = []
-        seg_mode = os.environ.get("RSGNET_HIP_TRAIN_SEGMENTS", "module") if self.wgrad_split else "stage"
+        seg_mode = os.environ.get("RSGNET_HIP_TRAIN_SEGMENTS", "every:40") if self.wgrad_split else "stage"
         by_module = seg_mode == "module"
         every = int(seg_mode.split(":")[1]) if seg_mode.startswith("every:") else 0
         for k in range(1, len(self.bwd)):

@@ -484,7 +484,9 @@ def test_flip_test_forward_rsgnet_crowdpose():
     cfg, model, sd, x, gold = load_case(tag)
     model = model.cuda()
     with torch.no_grad():
-        got = forward_flip_test(model, x.cuda(), CROWDPOSE_FLIP_PAIRS).cpu()
+        got_dev = forward_flip_test(model, x.cuda(), CROWDPOSE_FLIP_PAIRS)
+        assert torch.equal(got_dev, forward_flip_test(model, x.cuda(), CROWDPOSE_FLIP_PAIRS, overlap=False))   # two overlapping forwards == one of 2B
+        got = got_dev.cpu()
     a = po.rsgnet_forward(sd, cfg, x, want_scores=False)[1]
     b = po.rsgnet_forward(sd, cfg, x.flip(3), want_scores=False)[1]
     want = po.flip_test_merge(a, b, CROWDPOSE_FLIP_PAIRS)
