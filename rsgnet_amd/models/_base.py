@@ -2,12 +2,27 @@
 from __future__ import annotations
 
 import logging
+import operator
 import os
 
 import torch
 import torch.nn as nn
 
 logger = logging.getLogger(__name__)
+
+# Bumped whenever any module of the process registers a parameter, a buffer or a sub-module (assignments go through
+# register_parameter / register_buffer / add_module): HipPoseModule._param_signature rebuilds its flat tensor list then.
+_REGISTRATIONS = [0]
+_VERSION_OF = operator.attrgetter("_version")
+
+
+def _registered(*_args, **_kwargs):
+    _REGISTRATIONS[0] += 1
+
+
+nn.modules.module.register_module_parameter_registration_hook(_registered)
+nn.modules.module.register_module_buffer_registration_hook(_registered)
+nn.modules.module.register_module_module_registration_hook(_registered)
 
 
 class HipPoseModule(nn.Module):
@@ -41,7 +56,7 @@ class HipPoseModule(nn.Module):
     def invalidate_plan(self) -> None:
         self._plans = {}
         self._train_plans = {}
-        self.__dict__.pop("_sig_modules", None)
+        self.__dict__.pop("_sig_tensors", None)
 
     def _apply(self, fn, *a, **kw):
         self.invalidate_plan()
@@ -78,26 +93,21 @@ class HipPoseModule(nn.Module):
         """Changes whenever a parameter or buffer was written in place (torch bumps `_version` on every in-place op:
         `p.data.copy_`, torch optimizers' updates), was replaced by another tensor object, or FusedAdam stepped (its kernel
         writes through raw pointers and bumps `optim.PARAM_EPOCH` instead): the folded/packed weights of a cached plan are
-        then stale.  Runs in front of EVERY forward, so it walks a cached list of the modules that own tensors and reads
-        their `_parameters` / `_buffers` dicts directly: `self.parameters()` + `self.buffers()` (two generator walks over
-        the ~1 000 modules of the tree) took 1.4 ms of host time per forward - as long as the forward itself takes on the
-        GPU (profiles/r03m_host_time_per_forward.txt).  The module list is rebuilt after `.to()` / `load_state_dict` /
-        `invalidate_plan()`; sub-modules are not added to a built model."""
+        then stale.  Runs in front of EVERY forward, so it is one C-level pass over a cached flat list of the model's
+        tensors (0.05 ms for the 1 754 of HRNet-W32); the list is rebuilt when ANY module of the process registered a
+        parameter, buffer or sub-module since (`_REGISTRATIONS`, torch's global registration hooks: `m.weight =
+        nn.Parameter(...)` goes through them), after `.to()` / `load_state_dict` / `invalidate_plan()`.  History: the first
+        form, `self.parameters()` + `self.buffers()` (two generator walks over the ~1 000 modules of the tree), took 1.4 ms
+        of host time per forward - as long as the forward itself takes on the GPU (profiles/r03m_host_time_per_forward.txt);
+        the second walked the modules' `_parameters` / `_buffers` dicts (0.2 ms)."""
         from .. import optim
-        mods = self.__dict__.get("_sig_modules")
-        if mods is None:
-            mods = self.__dict__["_sig_modules"] = [m for m in self.modules() if m._parameters or m._buffers]
-        sig, ids = optim.PARAM_EPOCH, 0
-        for m in mods:
-            for t in m._parameters.values():
-                if t is not None:
-                    sig += t._version
-                    ids ^= id(t)
-            for t in m._buffers.values():
-                if t is not None:
-                    sig += t._version
-                    ids ^= id(t)
-        return sig, ids
+        ts = self.__dict__.get("_sig_tensors")
+        if ts is None or self.__dict__.get("_sig_epoch") != _REGISTRATIONS[0]:
+            ts = [t for m in self.modules() for d in (m._parameters, m._buffers) for t in d.values() if t is not None]
+            self.__dict__["_sig_tensors"] = ts
+            self.__dict__["_sig_epoch"] = _REGISTRATIONS[0]
+            self.__dict__["_sig_ids"] = hash(tuple(map(id, ts)))
+        return optim.PARAM_EPOCH + sum(map(_VERSION_OF, ts)), self.__dict__["_sig_ids"]
 
     def run_plan(self, x: torch.Tensor):
         """forward's way into the plan: everything (plan build, launches, output allocation) happens with the INPUT's

@@ -92,9 +92,12 @@ def test_param_signature_sees_every_way_the_weights_can_change():
     optim.PARAM_EPOCH -= 1
     assert m._param_signature() == s4
     n_tensors = len(list(m.parameters())) + len(list(m.buffers()))
-    seen = sum(len([t for t in mod._parameters.values() if t is not None]) + len([t for t in mod._buffers.values() if t is not None])
-               for mod in m.__dict__["_sig_modules"])
-    assert seen == n_tensors                   # the cached module list covers every tensor of the model
+    assert len(m.__dict__["_sig_tensors"]) == n_tensors          # the cached flat list covers every tensor of the model
+    m.bn1.register_buffer("extra_stat", torch.zeros(3))           # a tensor that did not exist when the list was built
+    s5 = m._param_signature()
+    assert s5 != s4 and len(m.__dict__["_sig_tensors"]) == n_tensors + 1
+    m.bn1.extra_stat.add_(1.0)
+    assert m._param_signature() != s5
 
 
 def test_library_exports_every_declared_symbol():
