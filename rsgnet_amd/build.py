@@ -51,6 +51,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     extra = {f: vgpr_form for f in ("trp.hip", "chain.hip", "group.hip", "conv_igemm.hip")}
     for f in os.environ.get("RSGNET_HIP_NO_VGPR_FORM", "").split(","):  # experiment switch
         extra.pop(f, None)
+    # trp.hip: no packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The W projection dropped FMA terms beside
+    # another stream's kernels in a form whose v_pk_fma_f32 operands were assembled by v_mov_b32 (DESIGN 9b'; the build
+    # without packed ops never failed); its fp32 per-position kernels are the only ones in the library where the compiler
+    # forms that sequence (static audit of every inference source), and they are latency-bound, not VALU-bound
+    extra["trp.hip"] = extra.get("trp.hip", []) + ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
     # the crop producer reproduces OpenCV's separately rounded double arithmetic: no fused multiply-adds there
     # (-ffp-contract=fast fuses in the backend and ignores `#pragma clang fp contract(off)`)
     extra["crops.hip"] = ["-ffp-contract=off"]
