@@ -177,11 +177,18 @@ int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, cons
                     void* workspace, void* stream);
 size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch);
 /* c = 48 runs on the 16x16x32 MFMA (exactly 48 channels, csrc/chain48.h): ONE BasicBlock per launch (nlayers == 2), no
- * hand-off flags or tail convs, and its layers are packed by rsg_pack_chain48_weights_host (w fp32 [48][48][3][3], BatchNorm
+ * hand-off flags, and its layers are packed by rsg_pack_chain48_weights_host (w fp32 [48][48][3][3], BatchNorm
  * scale / shift or NULL; rsg_chain48_packed_bytes() bytes of weights, 48 floats of bias) instead of
  * rsg_pack_conv_weights_host. */
 size_t rsg_chain48_packed_bytes(void);
 int rsg_pack_chain48_weights_host(const float* w, const float* scale, const float* shift, int32_t dtype, void* wp_out, float* bias_out);
+/* Weight pack of the chains by width.  rsg_chain_pack_kind(c): 16 = the widths of HRNet-W32 (32 / 64 / 128 / 256 channels:
+ * chains on the 16x16x32 MFMA, csrc/chain16.h) take rsg_pack_chain16_weights_host (w fp32 [c][c][3][3], BatchNorm scale / shift
+ * or NULL; 18 c^2 bytes of weights -- the size of the conv pack -- and c floats of bias); 48 = rsg_pack_chain48_weights_host;
+ * 0 = rsg_pack_conv_weights_host.  These chains need no block-input workspace (rsg_basic_chain_workspace_bytes returns 16). */
+int rsg_chain_pack_kind(int32_t c);
+int rsg_pack_chain16_weights_host(const float* w, const float* scale, const float* shift, int32_t c, int32_t dtype,
+                                  void* wp_out, float* bias_out);
 int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch,
                               int32_t* info4);
 /* Up to 6 chains (the branches of one HighResolutionModule, pose_hrnet.py:254-255) in ONE launch; the
@@ -192,19 +199,6 @@ int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_t nlayers, 
  * what it saw.  done_flags: int32[3 * workgroups of the item], zeroed by the caller before the first launch (a
  * launch leaves every word that was seen at zero again) and again whenever rsg_chain_handoff_timeouts reports a
  * poll that gave up. */
-/* A conv of the module's fuse layers (pose_hrnet.py:190-268) that reads a whole-image chain's output: a 1x1 conv
- * (k = 1, stride 1; towards a higher-resolution branch, before its nearest up-sampling) or a 3x3 stride-2 pad-1 conv
- * (k = 3, stride 2; the first step towards a lower-resolution branch), BatchNorm folded by
- * rsg_pack_conv_weights_host, optional ReLU.  The chain's workgroup computes it from its LDS image when the chain
- * ends; out: dense NHWC 16-bit [batch, h/stride, w/stride, cout], cout a multiple of 32.  Results are bit-identical
- * to rsg_conv_igemm on the chain's output. */
-typedef struct rsg_chain_tail {
-    const void* w_packed;
-    const float* bias;
-    void* out;
-    int32_t cout, k, stride, relu;
-} rsg_chain_tail;
-
 typedef struct rsg_chain_item {
     const void* in;
     void* out;
@@ -215,11 +209,9 @@ typedef struct rsg_chain_item {
     void* workspace;               /* rsg_basic_chain_workspace_bytes(c,h,w,nlayers,batch) bytes, own per item */
     void* done_flags;              /* NULL, or 3 x int32 per workgroup (see above) */
     const void* wait_flags;        /* NULL, or the done_flags of an earlier item */
-    int32_t ntails;                /* 0..3 fuse convs computed from the final LDS image (whole-image maps only) */
-    int32_t reserved;
+    int32_t reserved[2];           /* 0 */
     int32_t in_ld, out_ld;         /* pixel stride (elements) of in / out; 0 = dense (= c).  Only c = 48 takes other strides
                                       (HRNet-W48 keeps its 48-channel maps in 64-channel buffers) */
-    rsg_chain_tail tails[3];
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
 /* Sticky error word of the hand-off: the number of polls that gave up since the library was loaded on the current
@@ -270,16 +262,6 @@ int rsg_fuse_classifier(const void* const* same, const int32_t* same_ld, int32_t
 int rsg_fuse_head4(const void* x0, int32_t ld0, const void* const* lows, const int32_t* low_ld, int32_t n_low,
                    const void* const* w_low, const float* const* b_low, const void* w_cls, const float* b_cls,
                    float* out_nchw_f32, int32_t batch, int32_t h, int32_t w, int32_t cout, int32_t dtype, void* stream);
-/* The two highest-resolution outputs of a HighResolutionModule's fuse (pose_hrnet.py:190-268) in one launch:
- *   y0 = ReLU(x0 + up(bn(conv1x1(x_j))), j >= 1),   y1 = ReLU(bn(conv3x3 s2(x0)) + x1 + up(bn(conv1x1(x_j))), j >= 2),
- * row bands of 8 y0 rows with everything between the branch maps and the outputs in LDS.  xs[j]: branch j, [batch, h>>j,
- * w>>j, ld[j]], 32<<j channels, j = 0..n_low (1..3); w_a0/b_a0 [n_low]: convs j -> 0 (cout 32); w_d10/b_d10: the strided
- * conv 0 -> 1 (cout 64); w_a1/b_a1 [n_low-1]: convs j -> 1, j >= 2 (cout 64); packed by rsg_pack_conv_weights_host with the
- * BatchNorm folded.  y0: [batch,h,w,ld_y0], y1: [batch,h/2,w/2,ld_y1].  h, w multiples of 8.  Bit-identical to the grouped
- * conv launches + fuse sums it replaces. */
-int rsg_fuse_band(const void* const* xs, const int32_t* ld, int32_t n_low, const void* const* w_a0, const float* const* b_a0,
-                  const void* w_d10, const float* b_d10, const void* const* w_a1, const float* const* b_a1, void* y0,
-                  int32_t ld_y0, void* y1, int32_t ld_y1, int32_t batch, int32_t h, int32_t w, int32_t dtype, void* stream);
 
 /* One launch for several INDEPENDENT ops of a module's fuse layers (pose_hrnet.py:190-268): up to 12
  * convolutions (descriptors as for rsg_conv_igemm; rsg_conv_groupable tells whether one can join a

@@ -1,19 +1,59 @@
-"""Build librsgnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build librsgnet_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The build is keyed on what it builds: a hash over every csrc/* file, the public header, the flag table below, the
+environment switches that change flags and `hipcc --version` is stored beside the library (`<lib>.buildinfo`, JSON);
+`stale()` compares that hash, `info()` returns it with the per-file extra flags (smoke() and bench.py print it), and
+`audit_packed_fp32()` disassembles the library's code objects and counts the packed fp32 VALU ops per source file
+(tests/test_boundary.py asserts 0 for trp.hip: DESIGN 9b').
+
+    python -m rsgnet_amd.build [--force]
+    RSGNET_HIP_BUILD_NAME=base RSGNET_HIP_EXTRA_CFLAGS="-DRSG_CHAIN16=0" python -m rsgnet_amd.build
+        -> rsgnet_amd/lib/base/librsgnet_hip.so, a variant for same-visit A/B runs (RSGNET_HIP_LIB, tools/gpu_ab_lib.sh)
+"""
 from __future__ import annotations
 
 import concurrent.futures as cf
 import glob
+import hashlib
+import json
 import os
 import re
 import shutil
 import subprocess
 import sys
+from typing import Dict, List, Optional
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "librsgnet_hip.so")
+HEADER = os.path.join(os.path.dirname(PKG), "include", "rsgnet_hip.h")
 ARCH = "gfx950"
+
+BASE_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+# MFMA accumulators in VGPRs (gfx950 has one unified register file): the default AGPR form costs
+# v_accvgpr moves wherever VALU code touches an accumulator (64 per tile in trp.hip's sigmoid loop,
+# 16 per tile in every conv epilogue).  Measured in one visit: TRP loop -18 registers; HRNet step -1.8 %.
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# No packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The TRP's W projection dropped FMA terms beside
+# another stream's kernels in a form whose v_pk_fma_f32 operands were assembled by v_mov_b32 (DESIGN 9b'; the build
+# without packed ops never failed).  Every source with fp32 per-element VALU kernels that can run beside another stream's
+# kernels is built this way (inference: trp; training, whose weight gradients run on a side stream: train, train_tail,
+# elementwise); they are latency- or bandwidth-bound, not VALU-bound.  audit_packed_fp32() checks the code objects.
+_NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+NO_PACKED_FP32 = ("trp.hip", "train.hip", "train_tail.hip", "elementwise.hip")
+EXTRA_FLAGS: Dict[str, List[str]] = {
+    "trp.hip": _VGPR_FORM + _NO_PK_F32,
+    "chain.hip": _VGPR_FORM,
+    "group.hip": _VGPR_FORM,
+    "conv_igemm.hip": _VGPR_FORM,
+    "train.hip": _NO_PK_F32,
+    "train_tail.hip": _NO_PK_F32,
+    "elementwise.hip": _NO_PK_F32,
+    # the crop producer reproduces OpenCV's separately rounded double arithmetic: no fused multiply-adds there
+    # (-ffp-contract=fast fuses in the backend and ignores `#pragma clang fp contract(off)`)
+    "crops.hip": ["-ffp-contract=off"],
+}
 
 
 def _hipcc() -> str:
@@ -23,42 +63,101 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: librsgnet_hip.so cannot be built")
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    srcs = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(os.path.dirname(PKG), "include", "rsgnet_hip.h")]
-    return any(os.path.getmtime(s) > t for s in srcs)
+def lib_path(name: Optional[str] = None) -> str:
+    name = name if name is not None else os.environ.get("RSGNET_HIP_BUILD_NAME", "")
+    return os.path.join(LIBDIR, name, "librsgnet_hip.so") if name else LIB
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every csrc/*.hip for gfx950 and link them into rsgnet_amd/lib/librsgnet_hip.so."""
-    if not force and not stale():
-        return LIB
-    hipcc = _hipcc()
-    os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
-    os.makedirs(objdir, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+def _flag_table() -> Dict[str, List[str]]:
+    """Per-file extra flags after the experiment switches of the environment."""
+    extra = {k: list(v) for k, v in EXTRA_FLAGS.items()}
+    for f in os.environ.get("RSGNET_HIP_NO_VGPR_FORM", "").split(","):  # experiment switch
+        if f in extra:
+            extra[f] = [a for a in extra[f] if a not in _VGPR_FORM]
+    return extra
+
+
+def _common_flags() -> List[str]:
+    flags = list(BASE_FLAGS)
     flags += os.environ.get("RSGNET_HIP_EXTRA_CFLAGS", "").split()       # experiment builds (-D switches)
     if os.environ.get("RSGNET_HIP_DEBUG_BUILD") == "1":     # diagnostic library: timing switches that give WRONG results
         flags.append("-DRSG_DEBUG")
-    # MFMA accumulators in VGPRs (gfx950 has one unified register file): the default AGPR form costs
-    # v_accvgpr moves wherever VALU code touches an accumulator (64 per tile in trp.hip's sigmoid loop,
-    # 16 per tile in every conv epilogue).  Measured in one visit: TRP loop -18 registers; HRNet step -1.8 %.
-    vgpr_form = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-    extra = {f: vgpr_form for f in ("trp.hip", "chain.hip", "group.hip", "conv_igemm.hip")}
-    for f in os.environ.get("RSGNET_HIP_NO_VGPR_FORM", "").split(","):  # experiment switch
-        extra.pop(f, None)
-    # trp.hip: no packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The W projection dropped FMA terms beside
-    # another stream's kernels in a form whose v_pk_fma_f32 operands were assembled by v_mov_b32 (DESIGN 9b'; the build
-    # without packed ops never failed); its fp32 per-position kernels are the only ones in the library where the compiler
-    # forms that sequence (static audit of every inference source), and they are latency-bound, not VALU-bound
-    extra["trp.hip"] = extra.get("trp.hip", []) + ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-    # the crop producer reproduces OpenCV's separately rounded double arithmetic: no fused multiply-adds there
-    # (-ffp-contract=fast fuses in the backend and ignores `#pragma clang fp contract(off)`)
-    extra["crops.hip"] = ["-ffp-contract=off"]
+    return flags
+
+
+_hipcc_version_cache: Optional[str] = None
+
+
+def _hipcc_version() -> str:
+    global _hipcc_version_cache
+    if _hipcc_version_cache is None:
+        try:
+            _hipcc_version_cache = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip()
+        except Exception as e:      # no compiler on this box: a prebuilt library is then judged by its sources alone
+            _hipcc_version_cache = f"unavailable ({type(e).__name__})"
+    return _hipcc_version_cache
+
+
+def source_hash(with_compiler: bool = True) -> str:
+    """sha256 over csrc/*, include/rsgnet_hip.h, the flag table and (optionally) `hipcc --version`."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(CSRC, "*"))) + [HEADER]:
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            with open(path, "rb") as f:
+                h.update(f.read())
+    h.update(json.dumps({"common": _common_flags(), "extra": _flag_table()}, sort_keys=True).encode())
+    if with_compiler:
+        h.update(_hipcc_version().encode())
+    return h.hexdigest()
+
+
+def info(name: Optional[str] = None) -> dict:
+    """The build record of a library: {hash, sources_hash, common_flags, extra_flags, hipcc}; {} when there is none."""
+    p = lib_path(name) + ".buildinfo"
+    if not os.path.exists(p):
+        return {}
+    with open(p) as f:
+        return json.load(f)
+
+
+def describe(name: Optional[str] = None) -> str:
+    """One line for logs: which build of which sources is loaded."""
+    i = info(name)
+    if not i:
+        return f"{lib_path(name)}: no build record"
+    extra = "; ".join(f"{k}: {' '.join(v)}" for k, v in sorted(i.get("extra_flags", {}).items()))
+    return f"librsgnet_hip build {i['hash'][:16]} (sources {i['sources_hash'][:16]}) flags [{' '.join(i.get('common_flags', []))}] per file [{extra}]"
+
+
+def stale(name: Optional[str] = None) -> bool:
+    """True when the library is missing or was built from other sources / flags / compiler than the tree holds now.
+    Without a compiler (a box that only runs the prebuilt library) the sources-and-flags hash alone decides."""
+    lib = lib_path(name)
+    if not os.path.exists(lib):
+        return True
+    i = info(name)
+    if not i:
+        return True
+    try:
+        _hipcc()
+    except RuntimeError:
+        return i.get("sources_hash") != source_hash(with_compiler=False)
+    return i.get("hash") != source_hash()
+
+
+def build(force: bool = False, verbose: bool = False, name: Optional[str] = None) -> str:
+    """Compile every csrc/*.hip for gfx950 and link them into rsgnet_amd/lib[/name]/librsgnet_hip.so."""
+    lib = lib_path(name)
+    if not force and not stale(name):
+        return lib
+    hipcc = _hipcc()
+    libdir = os.path.dirname(lib)
+    objdir = os.path.join(libdir, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    flags = _common_flags()
+    extra = _flag_table()
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
@@ -71,14 +170,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         # kernel spilled a handful of VGPRs gave different bits from run to run (one wave's pixels wrong, a few
         # per cent of the launches; tools/chain_group_stress.py), and went away with the spills.  RSGNET_HIP_ALLOW_SCRATCH=1
         # turns the check into a warning for experiments.
-        name, bad = None, []
+        kname, bad = None, []
         for line in r.stderr.splitlines():
             m = re.search(r"Function Name: (\S+)", line)
             if m:
-                name = m.group(1)
+                kname = m.group(1)
             m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-            if m and int(m.group(1)) and name:
-                bad.append(f"{name}: {m.group(1)} B/lane")
+            if m and int(m.group(1)) and kname:
+                bad.append(f"{kname}: {m.group(1)} B/lane")
         if bad:
             msg = f"{os.path.basename(src)}: kernels using scratch memory: " + "; ".join(bad)
             if os.environ.get("RSGNET_HIP_ALLOW_SCRATCH", "0") == "0":
@@ -92,14 +191,62 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with cf.ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, srcs))
-    tmp = LIB + ".tmp"
+    # build step, not a tool: the sources listed in NO_PACKED_FP32 must hold no packed fp32 VALU op (DESIGN 9b')
+    hits = {k: v for k, v in audit_packed_fp32(objs).items() if k in NO_PACKED_FP32 and v}
+    if hits:
+        raise RuntimeError(f"packed fp32 VALU ops in sources built with -packed-fp32-ops: {hits}")
+    tmp = lib + ".tmp"
     r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", tmp],
                        capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    os.replace(tmp, LIB)
-    return LIB
+    os.replace(tmp, lib)
+    with open(lib + ".buildinfo", "w") as f:
+        json.dump({"hash": source_hash(), "sources_hash": source_hash(with_compiler=False), "common_flags": flags,
+                   "extra_flags": extra, "hipcc": _hipcc_version().splitlines()[0] if _hipcc_version() else ""}, f, indent=1)
+    return lib
+
+
+def _llvm_tool(tool: str) -> Optional[str]:
+    for c in (shutil.which(tool), f"/opt/rocm/lib/llvm/bin/{tool}", f"/opt/rocm/llvm/bin/{tool}"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def audit_packed_fp32(objs: Optional[List[str]] = None, name: Optional[str] = None) -> Dict[str, int]:
+    """{source file: number of v_pk_{fma,mul,add}_f32 in its gfx950 code object}, read from the object files of the last
+    build (rsgnet_amd/lib[/name]/obj/*.o).  Needs clang-offload-bundler, llvm-objcopy and llvm-objdump (ROCm's llvm/bin); returns {} when
+    they, llvm-objcopy or the objects are missing."""
+    if objs is None:
+        objs = sorted(glob.glob(os.path.join(os.path.dirname(lib_path(name)), "obj", "*.o")))
+    bundler, objdump, objcopy = _llvm_tool("clang-offload-bundler"), _llvm_tool("llvm-objdump"), _llvm_tool("llvm-objcopy")
+    if not objs or not bundler or not objdump or not objcopy:
+        return {}
+    out: Dict[str, int] = {}
+    pat = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b")
+    for obj in objs:
+        fat, co = obj + ".fatbin", obj + ".gfx950.co"
+        try:
+            # the host object carries the device code as a clang offload bundle in its .hip_fatbin section
+            r = subprocess.run([objcopy, f"--dump-section=.hip_fatbin={fat}", obj], capture_output=True, text=True)
+            if r.returncode or not os.path.exists(fat):
+                continue            # a host-only source (graph.hip)
+            r = subprocess.run([bundler, "--type=o", f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--input={fat}",
+                                f"--output={co}", "--unbundle"], capture_output=True, text=True)
+            if r.returncode or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            d = subprocess.run([objdump, "-d", f"--mcpu={ARCH}", co], capture_output=True, text=True)
+            if d.returncode == 0:
+                out[os.path.basename(obj)[:-2] + ".hip"] = len(pat.findall(d.stdout))
+        finally:
+            for f in (fat, co):
+                if os.path.exists(f):
+                    os.remove(f)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)
+    print(describe())

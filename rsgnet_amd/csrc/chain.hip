@@ -42,13 +42,13 @@
 // boundaries into a side buffer that nothing else reads (tools/chain_stamps.py prints the shares).  The
 // production build contains none of this.
 #ifdef RSG_CHAIN_STAMPS
-__device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][16 waves][32]
+__device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][16 waves][64]
 #define RSG_STAMP(slot)                                                                              \
     do {                                                                                             \
         if (g_chain_stamps && (threadIdx.x & 63) == 0) {                                             \
             unsigned long long t__;                                                                  \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");              \
-            g_chain_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 32 + (slot)] = t__;       \
+            g_chain_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (slot)] = t__;       \
         }                                                                                            \
     } while (0)
 #else
@@ -61,21 +61,6 @@ __device__ unsigned long long* g_chain_stamps = nullptr;   // [blocks][16 waves]
 // the dispatch order: rsg_basic_chain_group refuses a launch whose waiting workgroups could fill the machine (see
 // there), so a producer always finds a CU; the bound only turns a bug into an error instead of a hung GPU.
 __device__ unsigned g_chain_handoff_timeouts = 0;
-
-// A convolution of the module's fuse layers (pose_hrnet.py:190-268) that reads this chain's OUTPUT: the 1x1 convs
-// towards the higher-resolution branches and the first strided 3x3 conv towards every lower one.  The chain's final
-// image is still in LDS when it ends, so the workgroup computes them right there (BatchNorm folded, optional ReLU,
-// 16-bit NHWC out) instead of a later launch staging the same map again from memory.  Whole-image chains only.
-#define RSG_CHAIN_MAX_TAILS 3
-struct ChainTail {
-    const uint4* wpk;      // packed like every conv (cin = the chain's C)
-    const float* bias;
-    char* out;             // [B, Ho, Wo, cout] 16-bit
-    int cout;              // multiple of 32
-    int k, stride;         // 1x1 stride 1, or 3x3 stride 2 (pad 1)
-    int relu;
-    int Ho, Wo;
-};
 
 struct ChainArgs {
     const char* in;
@@ -97,75 +82,10 @@ struct ChainArgs {
     // Both null for an ordinary chain.
     int* done;
     const int* wait;
-    int ntails;
-    ChainTail tail[RSG_CHAIN_MAX_TAILS];
     int dual;     // 1: two LDS images (ping-pong): a layer reads one and writes the other, the block input stays in LDS
     int ldi, ldo; // pixel stride (elements) of in / out; == C except for the 48-channel maps of HRNet-W48 (kept in 64-channel buffers)
     int debug;    // rsg_tune("chain_debug"): bit 4 = fault injection, producers never signal (the error word's test); -DRSG_DEBUG builds only: bit 2 = no block-input fetch (timing experiment, WRONG results)
 };
-
-// One tail conv over the LDS image `img` (slot layout of chain_body: slot_rows rows of RP bytes per image, pixel
-// stride PS, one zero row/pixel around every image = the conv's zero padding).  Output tiles (32 couts x 32 pixels)
-// are dealt to the waves cout-tile-major (neighbouring waves share the weight fragments in L1); per tile the k-steps
-// run in packed order with the A operand NPF steps and the B operand one step ahead, accumulators start at the bias:
-// the same sums in the same order as conv_igemm.hip, so the results are bit-identical to the separate launch.
-template <class DT, int C, int NWAVES, int NTAPS>
-__device__ __forceinline__ void chain_tail_conv(const ChainTail& t, const char* img, int NI, int b0, int B, int slot_rows, int RP) {
-    constexpr int CINB = (C % 64 == 0) ? 64 : (C % 32 == 0 ? 32 : 16);
-    constexpr int NCH = C / CINB, KPT = CINB / 16, KS = NCH * NTAPS * KPT;
-    constexpr int PS = 2 * C + 16;
-    constexpr int NPF = (KS % 4 == 0) ? 4 : (KS % 2 == 0 ? 2 : 3);
-    static_assert(KS % NPF == 0, "tail prefetch ring");
-    const int lane = threadIdx.x & 63, n = lane & 31, hh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int per_img = t.Ho * t.Wo, npix = NI * per_img;
-    const int ngroups = (npix + 31) >> 5, nct = t.cout >> 5;
-    auto boff = [&](int ks) {
-        const int ch = ks / (NTAPS * KPT), tp = (ks / KPT) % NTAPS, c = ks % KPT;
-        return (NTAPS == 9 ? (tp / 3 - 1) * RP + (tp % 3 - 1) * PS : 0) + ch * CINB * 2 + c * 32;
-    };
-    for (int tile = wave; tile < nct * ngroups; tile += NWAVES) {
-        const int ct = tile / ngroups, g = tile - ct * ngroups;
-        const int q = g * 32 + n;
-        const bool live = q < npix;
-        const int qq = live ? q : 0;
-        const int i = qq / per_img, rem = qq - i * per_img;
-        const int oy = rem / t.Wo, ox = rem - oy * t.Wo;
-        const char* px = img + (i * slot_rows + oy * t.stride + 1) * RP + (ox * t.stride + 1) * PS + hh * 16;
-        const uint4* ap = t.wpk + (size_t)ct * KS * 64 + lane;
-        f32x16 acc;
-        {
-            const float* bp = t.bias + ct * 32 + hh * 16;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 bv = *reinterpret_cast<const float4*>(bp + r4 * 4);
-                acc[r4 * 4 + 0] = bv.x; acc[r4 * 4 + 1] = bv.y; acc[r4 * 4 + 2] = bv.z; acc[r4 * 4 + 3] = bv.w;
-            }
-        }
-        uint4 aq[NPF], bq[2];
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
-        bq[0] = *reinterpret_cast<const uint4*>(px + boff(0));
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
-            if (ks + 1 < KS) bq[(ks + 1) & 1] = *reinterpret_cast<const uint4*>(px + boff(ks + 1));
-            if (ks + NPF < KS) aq[ks % NPF] = ap[(ks + NPF) * 64];
-            acc = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1]), acc);
-        }
-        if (live && b0 + i < B) {
-            char* o = t.out + ((size_t)((b0 + i) * per_img + rem) * t.cout + ct * 32 + hh * 16) * 2;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                f32x8 v;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = acc[k * 8 + e];
-                const typename DT::vec8 pk = t.relu ? DT::relu_pack(v) : __builtin_convertvector(v, typename DT::vec8);
-                *reinterpret_cast<uint4*>(o + k * 16) = __builtin_bit_cast(uint4, pk);
-            }
-        }
-    }
-}
 
 // NHELD: the block input of the first NHELD pixel groups waits in REGISTERS instead of the global workspace (in-place
 // mode only): each lane reads its own pixels of the block input from the LDS image just before it overwrites them with
@@ -210,7 +130,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
     if (g_chain_stamps && (threadIdx.x & 63) == 0) {         // which XCD (clock domain) and CU this workgroup runs on
         unsigned xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hwid));
-        g_chain_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 32 + 31] = ((unsigned long long)xcc << 32) | hwid;
+        g_chain_stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + 63] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
     // ---- zero what staging does not write: the border row above and below every image slot and the border pixel
@@ -407,7 +327,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 #pragma unroll
             for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
         }
-        RSG_STAMP(3 + 3 * l);
+        RSG_STAMP(3 + 4 * l);
         // k-loop, one scheduling region per k-step (the compiler otherwise sinks the prefetches next to
         // their uses): issue the A load NPF steps ahead and the B reads one step ahead, then the MFMAs.
         auto boff = [&](int ks) {
@@ -497,6 +417,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             }
         }
 
+        RSG_STAMP(4 + 4 * l);
         // ---- (+ block input on odd layers) -> 16 bit -> ReLU.  One packed convert and one packed max per two
         // elements (the residual add is a packed fp32 add); a wave-uniform branch for the residual instead of a
         // per-element select.  No in-picture mask: every held row lies inside the picture (clamped window), and an
@@ -529,7 +450,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
                 }
             }
         }
-        RSG_STAMP(4 + 3 * l);
+        RSG_STAMP(5 + 4 * l);
         if (!dual) __syncthreads();                    // in place: every wave has finished reading the image
         int wd = own_delta;
         asm volatile("" : "+v"(wd));                     // keep the 2*NT write addresses out of the loop preheader
@@ -550,7 +471,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             }
         }
         __syncthreads();                                 // the new image is complete
-        RSG_STAMP(5 + 3 * l);
+        RSG_STAMP(6 + 4 * l);
     }
 
     // ---- store the TH output rows of every image slot (sc1: written through, see the hand-off above) ----------
@@ -569,24 +490,41 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
             if (c >= rowc) { c -= rowc; ++r; }
         }
     }
-    // ---- the module's fuse convs that read this chain's output, straight from the LDS image (whole images only)
-    if (p.ntails) {
-        const char* const img = smem + (dual ? (p.nlayers & 1) * lds_bytes : 0);
-        for (int ti = 0; ti < p.ntails; ++ti) {
-            if (p.tail[ti].k == 3) chain_tail_conv<DT, C, WM * WN, 9>(p.tail[ti], img, p.NI, b0, p.B, slot_rows, RP);
-            else chain_tail_conv<DT, C, WM * WN, 1>(p.tail[ti], img, p.NI, b0, p.B, slot_rows, RP);
-        }
-    }
     if (p.done) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores have left the CU
         __syncthreads();
         if (tid < 3 && !(p.debug & 4))     // debug bit 4 (tests): the producer never signals, every consumer poll gives up
             __hip_atomic_store(p.done + block_id * 3 + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    RSG_STAMP(30);
+    RSG_STAMP(62);
 }
 
 #include "chain48.h"
+#include "chain16.h"
+
+// HRNet-W32's widths run chain16_body (16x16x32 MFMA, chain16.h); -DRSG_CHAIN16=0 builds the 32x32x16 bodies for them
+// (same-visit A/B).  rsg_chain_pack_kind tells a caller which weight pack the chains of a width expect.
+#ifndef RSG_CHAIN16
+#define RSG_CHAIN16 1
+#endif
+// 128 channels stay on chain_body: its 16x12 map runs on four waves (one per SIMD), and a single wave cannot keep the 16-cycle
+// MFMA fed (two of them + a B read + its wait fill the issue slots: k-loop 69 % against 88 % with the 32-cycle form)
+#ifndef RSG_CHAIN16_128
+#define RSG_CHAIN16_128 0
+#endif
+static bool chain_is16(int C) { return RSG_CHAIN16 && (C == 32 || C == 64 || (RSG_CHAIN16_128 && C == 128) || C == 256); }
+
+template <class DT, int C, int WM, int WN, int NG, bool DUAL = false, int WC = 0>
+__global__ void __launch_bounds__(C == 128 ? 512 : 64 * WM * WN) chain16_kernel(const ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    chain16_body<DT, C, WM, WN, NG, DUAL, WC>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), smem);
+}
+#ifdef RSG_CHAIN16_PROBE    // register budgets of the bodies the grouped kernel inlines (diagnostic compile only)
+template __global__ void chain16_kernel<F16, 32, 1, 8, 14, false, 48>(const ChainArgs);
+template __global__ void chain16_kernel<F16, 64, 2, 4, 12, false, 24>(const ChainArgs);
+template __global__ void chain16_kernel<F16, 256, 8, 1, 3, true, 6>(const ChainArgs);
+template __global__ void chain16_kernel<F16, 256, 8, 1, 6, false, 6>(const ChainArgs);
+#endif
 
 template <class DT>
 __global__ void __launch_bounds__(768) chain48_kernel(const ChainArgs p) {
@@ -643,6 +581,41 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
 #pragma unroll
     for (int j = 1; j < RSG_CHAIN_GROUP_MAX; ++j) i += (j < g.n && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
     const int bid = rsg_xcd_tile(blockIdx.x - g.first[i], g.first[i + 1] - g.first[i]);   // an item's row bands of one image on one XCD
+#if RSG_CHAIN16
+    // the maps of a 256x192 crop (48 / 24 / 12 / 6 pixels wide) with the row pitch as a compile-time constant (chain16.h, WC)
+    const ChainArgs& a = g.a[i];
+    const int npx = a.NI * a.R * a.W;
+    switch (g.c[i]) {
+        case 32:   // 36-row tiles of 4-layer chains: 108 pixel groups over 8 waves; 32-row tiles: 96
+            if (npx <= 1536) chain16_body<DT, 32, 1, 8, 12>(a, bid, smem, pf);
+            else if (a.W == 48 && a.RP == chain16_row_pitch(32, 48)) chain16_body<DT, 32, 1, 8, 14, false, 48>(a, bid, smem, pf);
+            else chain16_body<DT, 32, 1, 8, 14>(a, bid, smem, pf);
+            break;
+        case 64:
+            if (a.W == 24 && a.RP == chain16_row_pitch(64, 24)) chain16_body<DT, 64, 2, 4, 12, false, 24>(a, bid, smem, pf);
+            else chain16_body<DT, 64, 2, 4, 12>(a, bid, smem, pf);
+            break;
+        case 128:  // 16x12 maps on FOUR waves (one per SIMD, all 12 pixel groups each; waves 4-7 leave at once): half the
+            // weight-fragment loads of eight waves (profiles/r02m_ab_w4_c128.txt)
+            if (threadIdx.x >= 256) return;
+#if RSG_CHAIN16_128
+            if (a.dual) chain16_body<DT, 128, 4, 1, 12, true>(a, bid, smem, pf);
+            else chain16_body<DT, 128, 4, 1, 12>(a, bid, smem, pf);
+#else
+            if (a.dual) chain_body<DT, 128, 4, 1, 6, true>(a, bid, smem, pf);
+            else chain_body<DT, 128, 4, 1, 6>(a, bid, smem, pf);
+#endif
+            break;
+        case 256:   // 8x6 maps: one image = exactly 3 pixel groups; two images per workgroup = 6
+            if (npx <= 48) {
+                if (a.dual && a.W == 6 && a.RP == chain16_row_pitch(256, 6)) chain16_body<DT, 256, 8, 1, 3, true, 6>(a, bid, smem, pf);
+                else if (a.dual) chain16_body<DT, 256, 8, 1, 3, true>(a, bid, smem, pf);
+                else chain16_body<DT, 256, 8, 1, 3>(a, bid, smem, pf);
+            } else if (a.W == 6 && a.RP == chain16_row_pitch(256, 6)) chain16_body<DT, 256, 8, 1, 6, false, 6>(a, bid, smem, pf);
+            else chain16_body<DT, 256, 8, 1, 6>(a, bid, smem, pf);
+            break;
+    }
+#else
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains need 7 pixel groups per wave, 32-row tiles 6
             if (g.a[i].R * g.a[i].W <= 1536) chain_body<DT, 32, 1, 8, 6, false, RSG_CHAIN_HELD32_NT6>(g.a[i], bid, smem, pf);
@@ -666,6 +639,7 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
             } else chain_body<DT, 256, 8, 1, 3>(g.a[i], bid, smem, pf);
             break;
     }
+#endif
 }
 
 // The widths of HRNet-W48 (48 / 96 / 192 / 384 channels: 1.5, 3, 6, 12 output-channel tiles) do not divide eight waves:
@@ -751,6 +725,18 @@ extern "C" int rsg_tune(const char* key, int32_t value) {
 typedef void (*chain_fn)(const ChainArgs);
 template <class DT>
 static chain_fn chain_lookup(int C, int npix, int dual) {
+#if RSG_CHAIN16
+    switch (C) {
+        case 32: return npix <= 1536 ? chain16_kernel<DT, 32, 1, 8, 12> : chain16_kernel<DT, 32, 1, 8, 14>;
+        case 64: return chain16_kernel<DT, 64, 2, 4, 12>;
+#if RSG_CHAIN16_128
+        case 128: return dual ? chain16_kernel<DT, 128, 4, 1, 12, true> : chain16_kernel<DT, 128, 4, 1, 12>;
+#endif
+        case 256:
+            if (npix <= 48) return dual ? chain16_kernel<DT, 256, 8, 1, 3, true> : chain16_kernel<DT, 256, 8, 1, 3>;
+            return chain16_kernel<DT, 256, 8, 1, 6>;
+    }
+#endif
     if (dual) {
         if (C == 256 && npix <= 64) return chain_kernel<DT, 256, 8, 1, 2, true>;
         if (C == 128) return chain_kernel<DT, 128, 4, 1, 6, true>;
@@ -868,6 +854,7 @@ extern "C" int rsg_basic_chain_supported(int32_t c, int32_t h, int32_t w, int32_
 
 // bytes of the block-input workspace of one chain: a 32-byte slot per lane and pixel group, per workgroup
 static size_t chain_ws_bytes(int C, const ChainArgs& a, int batch, int nlayers, int nthr) {
+    if (chain_is16(C)) return 16;       // chain16_body parks nothing in memory (the pointer must still be valid and aligned)
     const int blocks = ceil_div(batch, a.NI) * a.tiles_y;
     return (size_t)blocks * nthr * kChainMaxNT * 32;
 }
@@ -945,20 +932,6 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         a.ws = (uint4*)it.workspace;
         a.done = (int*)it.done_flags;
         a.wait = (const int*)it.wait_flags;
-        if (it.ntails < 0 || it.ntails > RSG_CHAIN_MAX_TAILS) RSG_FAIL("chain_group: item %d: ntails=%d", i, it.ntails);
-        if (it.ntails && a.tiles_y != 1) RSG_FAIL("chain_group: item %d: tail convs need a whole-image chain", i);
-        a.ntails = it.ntails;
-        for (int k = 0; k < it.ntails; ++k) {
-            const rsg_chain_tail& t = it.tails[k];
-            if (!t.w_packed || !t.bias || !t.out || t.cout < 32 || t.cout % 32 ||
-                !((t.k == 1 && t.stride == 1) || (t.k == 3 && t.stride == 2 && it.h % 2 == 0 && it.w % 2 == 0)))
-                RSG_FAIL("chain_group: item %d tail %d: 1x1 stride 1 or 3x3 stride 2 (even map), cout %% 32 == 0", i, k);
-            if (((uintptr_t)t.out | (uintptr_t)t.w_packed | (uintptr_t)t.bias) & 15) RSG_FAIL("chain_group: item %d tail %d: alignment", i, k);
-            ChainTail& d = a.tail[k];
-            d.wpk = (const uint4*)t.w_packed; d.bias = t.bias; d.out = (char*)t.out;
-            d.cout = t.cout; d.k = t.k; d.stride = t.stride; d.relu = t.relu ? 1 : 0;
-            d.Ho = it.h / t.stride; d.Wo = it.w / t.stride;
-        }
         a.debug = g_chain_debug;
         if (it.wait_flags) {
             // the producer comes EARLIER in the grid (in-order dispatch then makes the wait short; correctness does
@@ -978,7 +951,7 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         }
         // prefetch range: the item's layers when the caller packed them back to back (the plan does)
         const size_t layer_bytes = it.c == 48 ? (size_t)RSG_CHAIN48_KS * 3 * 64 * 16 : (size_t)it.c * it.c * 18;
-        if (it.c == 48 && (it.wait_flags || it.done_flags || it.ntails)) RSG_FAIL("chain_group: item %d: the 48-channel chain takes no hand-off flags or tail convs", i);
+        if (it.c == 48 && (it.wait_flags || it.done_flags)) RSG_FAIL("chain_group: item %d: the 48-channel chain takes no hand-off flags", i);
         bool contiguous = g_chain_prefetch != 0;
         for (int l = 1; l < it.nlayers; ++l)
             contiguous = contiguous && (const char*)it.w_packed[l] == (const char*)it.w_packed[0] + l * layer_bytes;
@@ -1038,5 +1011,38 @@ extern "C" int rsg_pack_chain48_weights_host(const float* w, const float* scale,
                     dst[(((size_t)s * 3 + m) * 64 + lane) * 8 + j] = bits;
                 }
     for (int co = 0; co < 48; ++co) bias_out[co] = shift ? shift[co] : 0.f;
+    return 0;
+}
+
+// Which weight pack the chains of width c expect: 16 = rsg_pack_chain16_weights_host, 48 = rsg_pack_chain48_weights_host,
+// 0 = the conv pack (rsg_pack_conv_weights_host).  rsg_pack_chain_weights_host packs one layer in that format.
+extern "C" int rsg_chain_pack_kind(int32_t c) { return chain_is16(c) ? 16 : (c == 48 ? 48 : 0); }
+
+// Weights of one layer of a chain16_body chain (chain16.h): w fp32 [C][C][3][3], BatchNorm folded like
+// rsg_pack_conv_weights_host (scale into the weights, shift into the bias; either may be NULL).
+// wp_out: 18 C^2 bytes = [wave row C/32][k-step (32-channel block, tap)][tile 2][lane 64] x 16 B; bias_out: C floats.
+extern "C" int rsg_pack_chain16_weights_host(const float* w, const float* scale, const float* shift, int32_t c, int32_t dtype,
+                                             void* wp_out, float* bias_out) {
+    if (!w || !wp_out || !bias_out) RSG_FAIL("pack_chain16: null pointer");
+    if (c < 32 || c % 32) RSG_FAIL("pack_chain16: %d channels (multiples of 32)", c);
+    unsigned short* dst = (unsigned short*)wp_out;
+    const int KS = c / 32 * 9;
+    for (int wm = 0; wm < c / 32; ++wm)
+        for (int s = 0; s < KS; ++s)
+            for (int m = 0; m < 2; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 15, q = lane >> 4, sig = ((q & 1) << 1) | (q >> 1);
+                    const int co = 32 * wm + 8 * (i >> 2) + 4 * m + (i & 3);
+                    const int cb = s / 9, tap = s % 9;
+                    for (int e = 0; e < 8; ++e) {
+                        const int ci = 32 * cb + 8 * sig + e;
+                        const float v = w[((size_t)co * c + ci) * 9 + tap] * (scale ? scale[co] : 1.f);
+                        unsigned short bits;
+                        if (dtype == RSG_BF16) { const BF16::elem h = BF16::from_f32(v); memcpy(&bits, &h, 2); }
+                        else { const F16::elem h = F16::from_f32(v); memcpy(&bits, &h, 2); }
+                        dst[((((size_t)wm * KS + s) * 2 + m) * 64 + lane) * 8 + e] = bits;
+                    }
+                }
+    for (int co = 0; co < c; ++co) bias_out[co] = shift ? shift[co] : 0.f;
     return 0;
 }

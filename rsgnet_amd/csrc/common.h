@@ -15,6 +15,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#define RSG_MAX_DEVICES 64       // per-device caches of launch attributes (hipFuncSetAttribute is per device)
+
 extern thread_local char g_rsg_err[512];
 
 #define RSG_FAIL(...)                                        \

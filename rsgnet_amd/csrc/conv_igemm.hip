@@ -185,6 +185,7 @@ int rsg_conv_prepare(const rsg_conv_desc* d, ConvArgs& a, TilePlan& t, dim3& gri
     a.tso = a.tsr = 32;                 // dense NHWC maps (the pair tails may be told otherwise: RSG_LAYOUT_*)
     if (!d || !d->in || !d->w_packed || !d->bias || (!d->out16 && !d->out_nchw_f32))
         RSG_FAIL("conv: null pointer in descriptor");
+    if (d->layout) RSG_FAIL("conv: layout bits 0x%x: channel-tile planes are read / written by rsg_conv_pair* and rsg_conv_dual only", d->layout);
     if (!((d->kh == 3 && d->kw == 3) || (d->kh == 1 && d->kw == 1) || (d->kh == 2 && d->kw == 2)))
         RSG_FAIL("conv: kernel %dx%d not supported (3x3, 1x1, 2x2)", d->kh, d->kw);
     if (d->stride < 1 || d->stride > 2) RSG_FAIL("conv: stride %d", d->stride);
@@ -286,6 +287,7 @@ static int pair_launch(const rsg_conv_desc* inner, const void* head_x, int32_t h
     rsg_conv_desc d = *inner;
     d.out16 = out16;                   // placeholders for the shared validation; the tail's values are set below
     d.out_ld = 64; d.residual = nullptr; d.relu = 1; d.relu_tile_mask = 0; d.out_c_store = 0;
+    d.layout = 0;                      // the plane bits were consumed above (they describe the tail's output / residual)
     // all 64 inner channels of a pixel in one workgroup: 2 x 2 waves, 3 pixel groups each
     int best_h = 0, best_w = 0;
     {

@@ -38,19 +38,13 @@ class FuseItem(C.Structure):
                 ("low_ld", C.c_int32 * 3), ("reserved", C.c_int32)]
 
 
-class ChainTail(C.Structure):
-    """struct rsg_chain_tail (include/rsgnet_hip.h)."""
-    _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("cout", C.c_int32), ("k", C.c_int32),
-                ("stride", C.c_int32), ("relu", C.c_int32)]
-
-
 class ChainItem(C.Structure):
     """struct rsg_chain_item (include/rsgnet_hip.h)."""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
                 ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
                 ("w", C.c_int32), ("c", C.c_int32), ("images_per_workgroup", C.c_int32), ("workspace", C.c_void_p),
-                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("ntails", C.c_int32), ("reserved", C.c_int32),
-                ("in_ld", C.c_int32), ("out_ld", C.c_int32), ("tails", ChainTail * 3)]
+                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("reserved", C.c_int32 * 2),
+                ("in_ld", C.c_int32), ("out_ld", C.c_int32)]
 
 
 class PackItem(C.Structure):
@@ -128,7 +122,6 @@ SYMBOLS = {
     "rsg_hr_fuse_sum": (C.c_int, [C.POINTER(_vp), _i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _vp,
                                   _i, _i, _i, _i, _i, _vp]),
     "rsg_fuse_classifier": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "rsg_fuse_band": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_fuse_head4": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_flip_merge_nchw_f32": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_decode_heatmaps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -164,6 +157,8 @@ SYMBOLS = {
     "rsg_wgrad_set_quad": (None, [_i]),
     "rsg_chain48_packed_bytes": (C.c_size_t, []),
     "rsg_pack_chain48_weights_host": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "rsg_chain_pack_kind": (C.c_int, [_i]),
+    "rsg_pack_chain16_weights_host": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "rsg_wgrad_tune": (None, [_i, _i, _i, _i, _i]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -197,7 +192,8 @@ def lib() -> C.CDLL:
                          ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual"),
                          ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows")):
             if os.environ.get(env):
-                l.rsg_tune(key, int(os.environ[env]))
+                if l.rsg_tune(key, int(os.environ[env])):       # the library validates the value
+                    raise RuntimeError(f"{env}={os.environ[env]}: {l.rsg_last_error().decode(errors='replace')}")
         # the wrong-result timing switches (chain_debug bits 1|2, bottleneck_debug) exist only in a -DRSG_DEBUG build
         # (RSGNET_HIP_DEBUG_BUILD=1 python -m rsgnet_amd.build --force) and are never set from the environment of a
         # production process; tools/ call rsg_tune themselves and fail loudly on a production library
@@ -214,6 +210,33 @@ def lib() -> C.CDLL:
             l.rsg_wgrad_set_quad(int(os.environ["RSGNET_HIP_WGRAD_QUAD"]))
         _lib = l
     return _lib
+
+
+def pack_chain_layer(w, scale, shift, dtype: int):
+    """One 3x3 C->C layer of a BasicBlock chain in the order the chain kernels of its width read
+    (rsg_chain_pack_kind: 16x16x32 pack for HRNet-W32's widths, the 48-channel pack, else the conv pack).
+    w fp32 [C,C,3,3], scale / shift fp32 [C] or None (folded BatchNorm); returns (weights u8, bias f32) as numpy arrays."""
+    import numpy as np
+    l = lib()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    c = w.shape[0]
+    if w.shape != (c, c, 3, 3):
+        raise ValueError(f"pack_chain_layer: weight of shape {w.shape}")
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    sh = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
+    ps, ph = (sc.ctypes.data if sc is not None else None), (sh.ctypes.data if sh is not None else None)
+    kind = l.rsg_chain_pack_kind(c)
+    if kind == 16:
+        wp, bo = np.empty(18 * c * c, dtype=np.uint8), np.empty(c, dtype=np.float32)
+        check(l.rsg_pack_chain16_weights_host(w.ctypes.data, ps, ph, c, dtype, wp.ctypes.data, bo.ctypes.data), "pack_chain16")
+    elif kind == 48:
+        wp, bo = np.empty(l.rsg_chain48_packed_bytes(), dtype=np.uint8), np.empty(48, dtype=np.float32)
+        check(l.rsg_pack_chain48_weights_host(w.ctypes.data, ps, ph, dtype, wp.ctypes.data, bo.ctypes.data), "pack_chain48")
+    else:
+        wp = np.empty(l.rsg_conv_packed_bytes(c, c, 3, 3), dtype=np.uint8)
+        bo = np.empty((c + 31) // 32 * 32, dtype=np.float32)
+        check(l.rsg_pack_conv_weights_host(w.ctypes.data, ps, ph, None, c, c, 3, 3, dtype, wp.ctypes.data, bo.ctypes.data), "pack")
+    return wp, bo
 
 
 def check(rc: int, what: str = "") -> None:

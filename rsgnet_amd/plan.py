@@ -75,6 +75,20 @@ class VT:
         return t[..., self.coff: self.coff + self.C]
 
 
+def _env_int(name: str, default: int, lo: int, hi: int) -> int:
+    """An integer switch of the environment, validated where it is read (a bad value is an error, not a crash later)."""
+    raw = os.environ.get(name)
+    if raw is None or raw == "":
+        return default
+    try:
+        v = int(raw)
+    except ValueError:
+        raise ValueError(f"{name}={raw!r}: not an integer") from None
+    if not lo <= v <= hi:
+        raise ValueError(f"{name}={v}: allowed range {lo}..{hi}")
+    return v
+
+
 class OutSlot:
     """An fp32 output of the plan whose address may change from call to call: the ops that write it run eagerly
     behind the captured graph (`Plan.n_tail`), so a forward can hand out fresh tensors instead of clones of static
@@ -114,14 +128,13 @@ class Plan:
         self.use_graph = self.graph_mode != "0"
         self.use_chain = os.environ.get("RSGNET_HIP_CHAIN", "1") != "0"
         self.use_group = os.environ.get("RSGNET_HIP_GROUP", "1") != "0"
-        self.use_fanout = os.environ.get("RSGNET_HIP_FANOUT", "0") != "0"   # measured +0.7%: merged convs still stage per 32-channel block
         self.conv_log: List[dict] = []
         self.flops = 0
         # lanes = HIP streams the launches are spread over (independent HRNet branches run concurrently);
         # cross-lane ordering comes from events derived from each op's buffer reads/writes
         # a plan built for a side stream expects to share the GPU with another stream's forward: tuned for CU-time, not makespan
         self.throughput = bool(getattr(model, "_plan_for_side_stream", False))
-        self.n_lanes = max(1, min(4, int(os.environ.get("RSGNET_HIP_LANES", "4"))))
+        self.n_lanes = _env_int("RSGNET_HIP_LANES", 4, 1, 4)
         self._lane = 0
         self._streams: List[torch.cuda.Stream] = []
         # in-launch hand-off (chain_group items that wait on an earlier item): off after a failure (models/_base.py)
@@ -135,7 +148,7 @@ class Plan:
         # forwards between two asynchronous reads of the error word: every forward enqueues the 4-byte copy behind its
         # launches and looks at the previous forward's copy first, so at most ONE batch of outputs can leave a plan
         # whose hand-off gave up before HandoffTimeout is raised (advisor, round 2: was 32)
-        self.handoff_poll_every = max(1, int(os.environ.get("RSGNET_HIP_HANDOFF_POLL_EVERY", "1")))
+        self.handoff_poll_every = _env_int("RSGNET_HIP_HANDOFF_POLL_EVERY", 1, 1, 1 << 20)
 
     class _LaneCtx:
         def __init__(self, plan, lane):
@@ -237,18 +250,16 @@ class Plan:
         self._tmp = []
         return self._dev(wp), self._dev(bo), I, O
 
-    def pack_chain48(self, w: torch.Tensor, scale, shift) -> Tuple[torch.Tensor, torch.Tensor]:
-        """One layer of the 48-channel chain (csrc/chain48.h): w fp32 [48,48,3,3] -> (weights, bias) on the device."""
-        w = w.detach().to("cpu", torch.float32).contiguous().numpy()
-        if w.shape != (48, 48, 3, 3):
-            raise ValueError(f"pack_chain48: weight of shape {w.shape}")
-        wp = np.empty(self.lib.rsg_chain48_packed_bytes(), dtype=np.uint8)
-        bo = np.empty(48, dtype=np.float32)
-        sc = None if scale is None else np.ascontiguousarray(scale.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(scale) else scale, dtype=np.float32)
-        sh = None if shift is None else np.ascontiguousarray(shift.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(shift) else shift, dtype=np.float32)
-        hip.check(self.lib.rsg_pack_chain48_weights_host(w.ctypes.data, sc.ctypes.data if sc is not None else None,
-                                                         sh.ctypes.data if sh is not None else None, self.dtype,
-                                                         wp.ctypes.data, bo.ctypes.data), "pack_chain48")
+    def pack_chain(self, conv: nn.Module, scale, shift) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One layer of a BasicBlock chain in the pack the chain kernels of its width read (hip.pack_chain_layer:
+        csrc/chain16.h for HRNet-W32's widths, csrc/chain48.h for 48 channels, else the conv pack) -> (weights, bias) on the device."""
+        if conv.bias is not None:
+            raise ValueError("pack_chain: BasicBlock convs carry no bias (pose_hrnet.py:19-22)")
+
+        def arr(a):
+            return None if a is None else (a.detach().to("cpu", torch.float32).numpy() if torch.is_tensor(a) else a)
+
+        wp, bo = hip.pack_chain_layer(conv.weight.detach().to("cpu", torch.float32).numpy(), arr(scale), arr(shift), self.dtype)
         return self._dev(wp), self._dev(bo)
 
     @staticmethod
@@ -361,35 +372,6 @@ class Plan:
         self.flops += 2 * self.batch * x.H * x.W * (64 * 256 + 64 * 64 * 9 + 256 * 64)
         return out
 
-    def conv_multi(self, x: VT, parts, name="") -> List[VT]:
-        """Several convs that read the SAME input with the same geometry as ONE conv with concatenated output
-        channels (fan-out fusion): parts = [(conv, bn, relu)], every cout a multiple of 32.  Returns one
-        channel view per part."""
-        ws, scs, shs, mask, off = [], [], [], 0, 0
-        for conv, bn, relu in parts:
-            sc, sh = self.bn_fold(bn)
-            O = conv.out_channels
-            if O % 32 or conv.bias is not None:
-                raise ValueError("conv_multi needs bias-free convs with cout % 32 == 0")
-            ws.append(conv.weight.detach().float().cpu())
-            scs.append(sc)
-            shs.append(sh)
-            if relu:
-                for t in range(off // 32, (off + O) // 32):
-                    mask |= 1 << t
-            off += O
-        if off > 1024:
-            raise ValueError("conv_multi: more than 32 output tiles")
-        c0 = parts[0][0]
-        out = self.conv(x, torch.cat(ws, 0), None, None, stride=c0.stride[0], relu=False,
-                        scale_shift=(torch.cat(scs), torch.cat(shs)), relu_mask=mask if mask else 0,
-                        name=name)
-        views, off = [], 0
-        for conv, _bn, _r in parts:
-            views.append(out.view(off, conv.out_channels))
-            off += conv.out_channels
-        return views
-
     def fuse(self, same: Sequence[VT], low: Sequence[Tuple[VT, int]], name="") -> VT:
         ref = same[0]
         out = self.new(ref.H, ref.W, ref.C, name=name)
@@ -403,8 +385,7 @@ class Plan:
         for blk in blocks:
             for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
                 scale, shift = self.bn_fold(bn)
-                wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
-                layers.append((wp, bo))
+                layers.append(self.pack_chain(conv, scale, shift))
         out = self.new(x.H, x.W, x.C, name=name)
         # block-input scratch: a standalone chain owns its buffer (chains of different branches run on different
         # lanes / graph branches, and the scheduler orders ops by the buffers they name: a shared one would be a race)
@@ -418,10 +399,8 @@ class Plan:
         INDEX of an earlier item: that chain then reads the earlier one's output and the two hand over inside the
         launch (done/wait flags, include/rsgnet_hip.h)."""
         subs, outs = [], []
-        self._tail_outs = []                # per item: the VTs its tail convs write (read by the caller)
         for item in items:
             x, blocks = item[0], item[1]
-            tails_in = item[2] if len(item) > 2 else []
             after = None
             if isinstance(x, int):
                 after, x = x, outs[x]
@@ -429,11 +408,7 @@ class Plan:
             for blk in blocks:
                 for conv, bn in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2)):
                     scale, shift = self.bn_fold(bn)
-                    if conv.in_channels == 48:           # the 48-channel chain (16x16x32 MFMA) has a pack of its own
-                        wp, bo = self.pack_chain48(conv.weight, scale, shift)
-                    else:
-                        wp, bo, _i, _o = self.pack_conv(conv.weight, scale, shift, conv.bias)
-                    layers.append((wp, bo))
+                    layers.append(self.pack_chain(conv, scale, shift))
             # the layers of one chain back to back in memory: the grouped launch prefetches them as one range
             allw = torch.cat([w for w, _ in layers])
             self._keep.append(allw)
@@ -444,23 +419,12 @@ class Plan:
             # position k of every grouped launch shares one scratch buffer per size; it is named among the op's
             # writes, so every scheduler (lanes, explicit graph) keeps the sharers in order
             ws = self._chain_workspace(len(subs), x, len(layers), cc)
-            # fuse convs computed from the chain's final LDS image (rsg_chain_tail): (conv, bn, relu) each
-            tails, touts = [], []
-            for conv, bnm, relu in tails_in:
-                sc, sh = self.bn_fold(bnm)
-                wp, bo, _i, O = self.pack_conv(conv.weight, sc, sh, conv.bias)
-                k, st = conv.kernel_size[0], conv.stride[0]
-                tv = self.new(x.H // st, x.W // st, O, name=f"{name}.tail")
-                tails.append(dict(wp=wp, bias=bo, out=tv, cout=O, k=k, stride=st, relu=relu))
-                touts.append(tv)
-                self.flops += 2 * self.batch * tv.H * tv.W * O * x.C * k * k
-            self._tail_outs.append(touts)
-            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, tails=tails, c=cc))
+            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, c=cc))
             outs.append(out)
             self.flops += 2 * self.batch * x.H * x.W * cc * cc * 9 * len(layers)
         self._record(dict(kind="chain_group", subs=subs, name=name),
                      [d["x"] for d in subs if d["after"] is None],
-                     outs + [d["ws"] for d in subs] + [t["out"] for d in subs for t in d["tails"]])
+                     outs + [d["ws"] for d in subs])
         return outs
 
     def chain_mode(self, C_, H, W, nblocks) -> int:
@@ -477,12 +441,12 @@ class Plan:
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nblocks, self.batch, info) and info[0] == H:
             # whole images stay in LDS.  RSGNET_HIP_CHAIN_SLICES=2 cuts the chain in two launches so that
             # both grouped launches of a module hold a slice of EVERY branch (better balanced grids)
-            slices = int(os.environ.get("RSGNET_HIP_CHAIN_SLICES", "2"))
-            return max(1, nblocks // slices) if nblocks % max(slices, 1) == 0 else nblocks
+            slices = _env_int("RSGNET_HIP_CHAIN_SLICES", 2, 1, 8)
+            return max(1, nblocks // slices) if nblocks % slices == 0 else nblocks
         # row tiles: the MFMAs are far from busy on these wide, thin maps, so halo recompute is cheap;
         # RSGNET_HIP_ROWTILE_BLOCKS blocks per launch (default 2: measured best; 4 makes the 2.6x halo
         # recompute and the second wave of workgroups cost more than the saved launch), then 1
-        want = int(os.environ.get("RSGNET_HIP_ROWTILE_BLOCKS", "2"))
+        want = _env_int("RSGNET_HIP_ROWTILE_BLOCKS", 2, 1, 4)
         for nb in (want, 2):
             if 0 < nb <= nblocks and nblocks % nb == 0 and \
                     self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nb, self.batch, info) and info[0] >= 8:
@@ -785,13 +749,6 @@ class Plan:
             it.bias = C.cast(bps, C.POINTER(C.c_void_p))
             it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, cc
             it.workspace = d["ws"].data_ptr() if d["ws"] is not None else None
-            it.ntails = len(d["tails"])
-            for k, t in enumerate(d["tails"]):
-                tv = t["out"]
-                if tv.ld != tv.C or tv.coff:
-                    raise ValueError("tail outputs must be dense tensors")
-                it.tails[k].w_packed, it.tails[k].bias, it.tails[k].out = t["wp"].data_ptr(), t["bias"].data_ptr(), tv.ptr()
-                it.tails[k].cout, it.tails[k].k, it.tails[k].stride, it.tails[k].relu = t["cout"], t["k"], t["stride"], int(t["relu"])
             log.append((cc, x.H, x.W, n))
         for k, d in enumerate(subs):
             if d.get("after") is not None:
@@ -826,9 +783,7 @@ class Plan:
                     total -= blocks[k][0] // 2
         self._keep.append(items)
         fn, nm, n_items, dt = self.lib.rsg_basic_chain_group, r["name"], len(subs), self.dtype
-        tail_flops = float(sum(2 * self.batch * t["out"].H * t["out"].W * t["cout"] * d["x"].C * t["k"] ** 2
-                               for d in subs for t in d["tails"]))
-        self.conv_log.append(dict(name=nm, group=log, tail_flops=tail_flops, tails=sum(len(d["tails"]) for d in subs)))
+        self.conv_log.append(dict(name=nm, group=log))
 
         def launch(stream):
             rc = fn(items, n_items, dt, stream)
@@ -1225,40 +1180,6 @@ class _BackboneMixin:
             return self._unit(y, blk.conv3, blk.bn3, relu=True, residual=res, name=name + ".conv3")
         return self._unit(y, blk.conv2, blk.bn2, relu=True, residual=res, name=name + ".conv2")
 
-    def _fuse_band(self: Plan, xs: List[VT], rows, name: str):
-        """Record rsg_fuse_band for a module: returns the new maps (y0, y1)."""
-        n_low = len(xs) - 1
-        a0 = [self.pack_conv(rows[0][j][0].weight, *self.bn_fold(rows[0][j][1]), None)[:2] for j in range(1, n_low + 1)]
-        d10 = self.pack_conv(rows[1][0][0][0].weight, *self.bn_fold(rows[1][0][0][1]), None)[:2]
-        a1 = [self.pack_conv(rows[1][j][0].weight, *self.bn_fold(rows[1][j][1]), None)[:2] for j in range(2, n_low + 1)]
-        y0 = self.new(xs[0].H, xs[0].W, 32, name=f"{name}.fuse.0")
-        y1 = self.new(xs[1].H, xs[1].W, 64, name=f"{name}.fuse.1")
-        lib, B, dt = self.lib, self.batch, self.dtype
-        h, w = xs[0].H, xs[0].W
-
-        def make():
-            xp = (C.c_void_p * 4)(*[v.ptr() for v in xs])
-            xl = (C.c_int32 * 4)(*[v.ld for v in xs])
-            w0 = (C.c_void_p * 3)(*[wp.data_ptr() for wp, _ in a0])
-            b0 = (C.c_void_p * 3)(*[bo.data_ptr() for _, bo in a0])
-            w1 = (C.c_void_p * 2)(*[wp.data_ptr() for wp, _ in a1])
-            b1 = (C.c_void_p * 2)(*[bo.data_ptr() for _, bo in a1])
-            self._keep += [xp, xl, w0, b0, w1, b1]
-            args = (xp, xl, n_low, w0, b0, d10[0].data_ptr(), d10[1].data_ptr(), w1, b1, y0.ptr(), y0.ld, y1.ptr(), y1.ld, B, h, w, dt)
-
-            def launch(stream):
-                rc = lib.rsg_fuse_band(*args, stream)
-                if rc:
-                    hip.check(rc, f"{name}.fuse.band")
-            return launch
-
-        self.custom(f"{name}.fuse.band", list(xs), [y0, y1], make)
-        fl = 2 * B * (sum((h >> j) * (w >> j) * (32 << j) * 32 for j in range(1, n_low + 1)) + (h // 2) * (w // 2) * 64 * 32 * 9
-                      + sum((h >> j) * (w >> j) * (32 << j) * 64 for j in range(2, n_low + 1)))
-        self.flops += fl
-        self.conv_log.append(dict(name=f"{name}.fuse.band", flops=float(fl)))
-        return y0, y1
-
     def _hr_module(self: Plan, xs: List[VT], mod, name: str, rider=None) -> List[VT]:
         """HighResolutionModule.forward (pose_hrnet.py:250-268).  rider(y_last): records ops that read only the module's
         LAST output; when that output is finished one fuse level before the module's final launch (its sum rides on a conv of
@@ -1298,35 +1219,14 @@ class _BackboneMixin:
                     self.lib.rsg_basic_chain_supported(chan[b], xs[b].H, xs[b].W, 2 * steps[b], self.batch, info)
                     waiters += info[3]
             handoff = waiters <= self.lib.rsg_basic_chain_handoff_max_waiters()
-        pre: Dict[Tuple[int, int], VT] = {}                  # (i, j) -> first conv of fuse path j -> i, done by a chain tail
         if handoff:
             order = sorted(steps, key=lambda b: (not whole(b), -xs[b].C))       # whole-image chains first, widest first
-            # fuse convs that read a whole-image branch ride on that branch's chain (tails of the launch)
-            tails_of: Dict[int, list] = {b: [] for b in order}
-            tail_ij: Dict[int, list] = {b: [] for b in order}
-            # RSGNET_HIP_CHAIN_TAILS=1 (off by default): measured SLOWER in a same-visit A/B (1.780 -> 1.816 ms): the
-            # fuse launches drop from 364 to 278 us but the chain launches grow from 884 to 1000 us -- the small convs
-            # are latency-bound either way, and in the chain kernel (one workgroup per CU) nothing hides that latency,
-            # while the fuse launches run them at 2-3 workgroups per CU (profiles/README.md, r02e)
-            if mod.fuse_layers is not None and os.environ.get("RSGNET_HIP_CHAIN_TAILS", "0") != "0":
-                for i, row in enumerate(mod.fuse_layers):
-                    for j, fl in enumerate(row):
-                        if j == i or j not in steps or not whole(j) or len(tails_of[j]) >= 3:
-                            continue
-                        conv, bnm = (fl[0], fl[1]) if j > i else (fl[0][0], fl[0][1])
-                        relu = False if j > i else len(fl) > 1
-                        ok = conv.out_channels % 32 == 0 and conv.bias is None and conv.in_channels == xs[j].C and \
-                            ((conv.kernel_size == (1, 1) and conv.stride == (1, 1)) or
-                             (conv.kernel_size == (3, 3) and conv.stride == (2, 2) and xs[j].H % 2 == 0 and xs[j].W % 2 == 0))
-                        if ok:
-                            tails_of[j].append((conv, bnm, relu))
-                            tail_ij[j].append((i, j))
             items, where = [], {}
             for b in order:
                 blocks = list(mod.branches[b])
                 if whole(b):
                     where[b] = len(items)
-                    items.append((xs[b], blocks, tails_of[b]))
+                    items.append((xs[b], blocks))
             for b in order:                      # first halves, then second halves: a producer precedes its consumer
                 if not whole(b):
                     where[b] = len(items)
@@ -1336,10 +1236,6 @@ class _BackboneMixin:
                     first, where[b] = where[b], len(items)
                     items.append((first, list(mod.branches[b])[steps[b]:]))
             outs = self.chain_group(items, f"{name}.chains")
-            for b in order:
-                if whole(b):
-                    for ij, tv in zip(tail_ij[b], self._tail_outs[where[b]]):
-                        pre[ij] = tv
             for b in order:
                 xs[b] = outs[where[b]]
             steps = {}
@@ -1388,7 +1284,7 @@ class _BackboneMixin:
         if mod.fuse_layers is None:
             return xs
         # the LAST module of pose_hrnet (one output): its 1x1 convs, the sum and the classifier in one launch (HRNetPlan)
-        if getattr(self, "_defer_sum0", None) == name and os.environ.get("RSGNET_HIP_FUSE_HEAD4", "1") != "0" and not pre \
+        if getattr(self, "_defer_sum0", None) == name and os.environ.get("RSGNET_HIP_FUSE_HEAD4", "1") != "0" \
                 and len(mod.fuse_layers) == 1 and 2 <= len(xs) <= 4 and all(xs[j].C == 32 << j for j in range(len(xs))) \
                 and all(xs[j].coff == 0 for j in range(len(xs))) and xs[0].H % 8 == 0 and xs[0].W % 8 == 0 \
                 and all(mod.fuse_layers[0][j][0].kernel_size == (1, 1) and mod.fuse_layers[0][j][0].bias is None for j in range(1, len(xs))):
@@ -1400,42 +1296,19 @@ class _BackboneMixin:
         rows = mod.fuse_layers
         n_out = len(rows)
         cur = {}                                         # (i, j) -> tensor produced so far on that path
-        depth = {}                                       # (i, j) -> number of convs on that path LEFT for these launches
-        done = {}                                        # (i, j) -> convs of the path a chain tail has already run
+        depth = {}                                       # (i, j) -> number of convs on that path
         for i, row in enumerate(rows):
             for j, fl in enumerate(row):
                 if j != i:
-                    done[(i, j)] = 1 if (i, j) in pre else 0
-                    depth[(i, j)] = (1 if j > i else len(fl)) - done[(i, j)]
-                    cur[(i, j)] = pre.get((i, j), xs[j])
+                    depth[(i, j)] = 1 if j > i else len(fl)
+                    cur[(i, j)] = xs[j]
         outs: List[Optional[VT]] = [None] * n_out
-        # OPT-IN (RSGNET_HIP_FUSE_BAND=1; measured SLOWER, profiles/r03_ab_fuse_band.txt): outputs 0 and 1 in ONE launch of their
-        # own (rsg_fuse_band: row bands through the 1x1 convs j -> 0, the strided conv 0 -> 1, the 1x1 convs j -> 1 and both
-        # sums) -- those paths hold 90 % of the fuse bytes and half of the grouped launches' workgroups but few weights; the
-        # grouped launches below keep the deeper paths.  Bit-identical (tests/test_gpu_kernels.py).
-        band = os.environ.get("RSGNET_HIP_FUSE_BAND", "0") == "1" and self.use_group and not pre and not self.use_fanout \
-            and n_out >= 2 and n_out == len(xs) and 2 <= len(xs) <= 4 and all(xs[j].C == 32 << j and xs[j].coff == 0 for j in range(len(xs))) \
-            and xs[0].H % 8 == 0 and xs[0].W % 8 == 0 and os.environ.get("RSGNET_HIP_FOLD_SUM", "1") != "0" \
-            and all(rows[0][j][0].kernel_size == (1, 1) and rows[0][j][0].bias is None for j in range(1, len(xs))) \
-            and all(rows[1][j][0].kernel_size == (1, 1) and rows[1][j][0].bias is None for j in range(2, len(xs))) \
-            and len(rows[1][0]) == 1 and rows[1][0][0][0].kernel_size == (3, 3) and rows[1][0][0][0].stride == (2, 2) \
-            and rows[1][0][0][0].bias is None
-        if band:
-            outs[0], outs[1] = self._fuse_band(xs, rows, name)
-            for key in [k for k in depth if k[0] in (0, 1)]:
-                del depth[key]
-            if not depth:                                 # a module with two branches: everything is done
-                if rider is not None:
-                    self._rider_out = rider(outs[n_out - 1]) if os.environ.get("RSGNET_HIP_TRANS_RIDE", "1") != "0" else None
-                return outs
         max_depth = max(depth.values()) if depth else 0
         ready = {i: max([d for (ii, _), d in depth.items() if ii == i], default=0) for i in range(n_out)}
-        if band:
-            ready[0] = ready[1] = -1                      # no sums left for them
         # output n_out-1 has no up-sampled addends and at most three others besides its longest chain: fold its sum
         fold_into = None
         last = n_out - 1
-        if os.environ.get("RSGNET_HIP_FOLD_SUM", "1") != "0" and not self.use_fanout and last >= 1 and last == len(xs) - 1 \
+        if os.environ.get("RSGNET_HIP_FOLD_SUM", "1") != "0" and last >= 1 and last == len(xs) - 1 \
                 and last <= 3 and depth.get((last, 0), 0) == last and depth[(last, 0)] == max_depth:
             fold_into = (last, 0)
             ready[last] = -1                              # no separate sum for it
@@ -1443,40 +1316,30 @@ class _BackboneMixin:
             if fold_into is not None and level == max_depth and not any(r == level for r in ready.values()):
                 break                                     # nothing left for a last, sum-only level
             self.begin_group()
-            # convs of this level, bucketed by (input tensor, geometry): same-bucket convs share one launch
-            # item with concatenated output channels (fan-out fusion: the input tile is staged once)
+            # convs of this level (the level-th conv of every path that is that long), those that read the same tensor next
+            # to each other in the launch (their workgroups share the staged lines in L2)
             buckets: Dict[tuple, list] = {}
             for (i, j), dep in depth.items():
                 if level < dep:
                     fl = rows[i][j]
-                    step = level + done[(i, j)]          # index of the conv on its path
-                    conv, bnm = (fl[0], fl[1]) if j > i else (fl[step][0], fl[step][1])
+                    conv, bnm = (fl[0], fl[1]) if j > i else (fl[level][0], fl[level][1])
                     relu = False if j > i else (level != dep - 1)
                     xin = cur[(i, j)]
                     key = (id(xin.base), xin.coff, xin.C, conv.kernel_size, conv.stride)
                     buckets.setdefault(key, []).append(((i, j), xin, conv, bnm, relu))
             for items in buckets.values():
-                mergeable = self.use_fanout and len(items) > 1 and \
-                    all(c.out_channels % 32 == 0 and c.bias is None for _, _, c, _, _ in items)
-                if mergeable:
-                    xin = items[0][1]
-                    views = self.conv_multi(xin, [(c, b, r) for _, _, c, b, r in items],
-                                            name=f"{name}.fuse.L{level}.from{items[0][0][1]}x{len(items)}")
-                    for (ij, _x, _c, _b, _r), v in zip(items, views):
-                        cur[ij] = v
-                else:
-                    for ij, xin, conv, bnm, relu in items:
-                        nm = f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level + done[ij]}")
-                        if ij == fold_into and level == depth[ij] - 1:
-                            # the sum of the lowest-resolution output rides on the last conv that feeds it: every other
-                            # addend (the identity and the shorter strided chains) was finished at an earlier level
-                            i = ij[0]
-                            others = [xs[i]] + [cur[(i, j)] for j in range(1, i)]
-                            outs[i] = self._unit(xin, conv, bnm, relu=True, residual=others[0], more_residuals=others[1:],
-                                                 name=nm + "+sum")
-                            cur[ij] = outs[i]
-                            continue
-                        cur[ij] = self._unit(xin, conv, bnm, relu=relu, name=nm)
+                for ij, xin, conv, bnm, relu in items:
+                    nm = f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level}")
+                    if ij == fold_into and level == depth[ij] - 1:
+                        # the sum of the lowest-resolution output rides on the last conv that feeds it: every other
+                        # addend (the identity and the shorter strided chains) was finished at an earlier level
+                        i = ij[0]
+                        others = [xs[i]] + [cur[(i, j)] for j in range(1, i)]
+                        outs[i] = self._unit(xin, conv, bnm, relu=True, residual=others[0], more_residuals=others[1:],
+                                             name=nm + "+sum")
+                        cur[ij] = outs[i]
+                        continue
+                    cur[ij] = self._unit(xin, conv, bnm, relu=relu, name=nm)
             for i in range(n_out):
                 if ready[i] == level:                    # every addend was finished by the previous level
                     same = [cur[(i, j)] for j in range(i)] + [xs[i]]

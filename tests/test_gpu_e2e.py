@@ -452,28 +452,6 @@ def test_handoff_timeout_reaches_the_caller_and_the_model_recovers():
         assert torch.equal(again, good)
 
 
-def test_chain_tails_change_no_bits(monkeypatch):
-    """The fuse convs that read a whole-image branch run as tails of that branch's chain (from its LDS image) instead
-    of in the fuse launches: same sums in the same order, so the heat maps are bit-identical, with fewer, lighter
-    fuse launches."""
-    cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
-    model = model.cuda()
-    xx = torch.cat([x, x.flip(3), x.flip(2)], 0).cuda()        # 6 crops: not a multiple of anything convenient
-    monkeypatch.setenv("RSGNET_HIP_CHAIN_TAILS", "1")          # opt-in (measured slower than the fuse launches: plan.py)
-    with torch.no_grad():
-        y1 = model(xx).clone()
-        plan1 = next(iter(model._plans.values()))
-        ntails = sum(e.get("tails", 0) for e in plan1.conv_log)
-        n1 = len(plan1.ops)
-        monkeypatch.setenv("RSGNET_HIP_CHAIN_TAILS", "0")
-        model.invalidate_plan()
-        y0 = model(xx)
-        plan0 = next(iter(model._plans.values()))
-    assert ntails >= 8 * 3 and sum(e.get("tails", 0) for e in plan0.conv_log) == 0
-    assert torch.equal(y1, y0)
-    assert n1 <= len(plan0.ops)
-
-
 def test_flip_test_forward_rsgnet_crowdpose():
     """BASELINE configs[4]: the CrowdPose RSGNet (14 joints, cp_kpt_word_embs) under the flip test -- one 2B forward and
     the fused merge (rsgnet_amd/flip.py) against the reference's procedure restated on the oracle: two forwards, host

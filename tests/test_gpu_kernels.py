@@ -296,17 +296,8 @@ def test_trp_attention_project_tail_scores_mse():
 
 
 def _pack_chain_layer(lib, w, scale, shift, Cc):
-    """One 3x3 Cc->Cc layer in the order its chain kernel reads (the 48-channel chain has a pack of its own)."""
-    if Cc == 48:
-        wp = np.zeros(lib.rsg_chain48_packed_bytes(), np.uint8)
-        bo = np.zeros(48, np.float32)
-        hip.check(lib.rsg_pack_chain48_weights_host(w.ctypes.data, scale.ctypes.data, shift.ctypes.data, 0, wp.ctypes.data, bo.ctypes.data))
-        return wp, bo
-    wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
-    bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
-    hip.check(lib.rsg_pack_conv_weights_host(w.ctypes.data, scale.ctypes.data, shift.ctypes.data, None, Cc, Cc, 3, 3, 0,
-                                             wp.ctypes.data, bo.ctypes.data))
-    return wp, bo
+    """One 3x3 Cc->Cc layer in the order its chain kernel reads (rsg_chain_pack_kind: three packs by width)."""
+    return hip.pack_chain_layer(w, scale, shift, 0)
 
 
 @pytest.mark.parametrize("Cc,H,W,L", [(128, 16, 12, 8), (256, 8, 6, 8), (64, 32, 24, 8), (32, 64, 48, 2),
@@ -1126,31 +1117,3 @@ def test_fuse_classifier_and_head4_equal_the_separate_launches():
     assert torch.isfinite(outs["separate"]).all()
     assert torch.equal(outs["separate"], outs["sum+classifier"]) and torch.equal(outs["separate"], outs["module+classifier"])
     assert nops["sum+classifier"] == nops["separate"] - 1 and nops["module+classifier"] == nops["separate"] - 2
-
-
-def test_fuse_band_equals_the_grouped_launches():
-    """rsg_fuse_band (outputs 0 and 1 of every HighResolutionModule's fuse in one launch of row bands: the 1x1 convs j -> 0,
-    the strided conv 0 -> 1, the 1x1 convs j -> 1, both sums) against the grouped conv launches and fuse sums it replaces,
-    bit for bit, through the model plans of HRNet-W32 (2-, 3- and 4-branch modules, the folded sum of stage 2) and
-    RSGNet-W32: RSGNET_HIP_FUSE_BAND=0/1 on the same weights and input."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.dirname(__file__))
-    from util import load_case
-    for tag in ("hrnet_w32_256x192", "rsgnet_w32_256x192_coco"):
-        outs, names = {}, {}
-        for flag in ("0", "1"):
-            os.environ["RSGNET_HIP_FUSE_BAND"] = flag
-            try:
-                cfg, model, sd, x, gold = load_case(tag)
-                model = model.cuda()
-                x3 = torch.cat((x, x[:1] * 0.5)).cuda()
-                with torch.no_grad():
-                    o = model(x3)
-                outs[flag] = [t.cpu() for t in (o if isinstance(o, tuple) else (o,)) if torch.is_tensor(t)]
-                names[flag] = [n for n, _ in list(model._plans.values())[0].ops]
-            finally:
-                os.environ.pop("RSGNET_HIP_FUSE_BAND", None)
-        assert sum(n.endswith(".fuse.band") for n in names["1"]) == 7 and not any(n.endswith(".fuse.band") for n in names["0"])
-        for a, b in zip(outs["0"], outs["1"]):
-            assert torch.isfinite(a).all() and torch.equal(a, b), tag

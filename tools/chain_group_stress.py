@@ -27,9 +27,7 @@ def make(Cc, H, W, L):
     wps, bps = [], []
     for l in range(L):
         w = (np.random.RandomState(l).randn(Cc, Cc, 3, 3) * (2.0 / (Cc * 9)) ** 0.5).astype(np.float32)
-        wp = np.zeros(lib.rsg_conv_packed_bytes(Cc, Cc, 3, 3), np.uint8)
-        bo = np.zeros(Cc, np.float32)
-        lib.rsg_pack_conv_weights_host(w.ctypes.data, None, None, None, Cc, Cc, 3, 3, 0, wp.ctypes.data, bo.ctypes.data)
+        wp, bo = hip.pack_chain_layer(w, None, None, 0)      # the pack the chain kernels of this width read
         wd, bd = torch.from_numpy(wp).cuda(), torch.from_numpy(bo).cuda()
         keep.extend([wd, bd])
         wps.append(wd.data_ptr())

@@ -41,10 +41,7 @@ for k, (Cc, H, W, L, after) in enumerate(branches):
     wps, bps = [], []
     for l in range(L):
         w = (np.random.randn(Cc, Cc, 3, 3) * (2.0 / (Cc * 9)) ** 0.5).astype(np.float32)
-        wp = np.zeros(Cc * Cc * 9 * 2, np.uint8)
-        bo = np.zeros(Cc, np.float32)
-        lib.rsg_pack_conv_weights_host(C.c_void_p(w.ctypes.data), None, None, None, Cc, Cc, 3, 3, 0,
-                                       C.c_void_p(wp.ctypes.data), C.c_void_p(bo.ctypes.data))
+        wp, bo = hip.pack_chain_layer(w, None, None, 0)      # the pack the chain kernels of this width read
         wd, bd = torch.from_numpy(wp).cuda(), torch.from_numpy(bo).cuda()
         keep += [wd, bd]
         wps.append(wd.data_ptr())
@@ -67,7 +64,7 @@ for k, (Cc, H, W, L, after) in enumerate(branches):
         items[after].done_flags = fl.data_ptr()
         it.wait_flags = fl.data_ptr()
 total = sum(nblk)
-stamps = torch.zeros(total * 16 * 32, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(total * 16 * 64, dtype=torch.int64, device="cuda")
 lib.rsg_chain_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
 for _ in range(3):
     assert lib.rsg_basic_chain_group(items, len(branches), 0, None) == 0, lib.rsg_last_error()
@@ -77,21 +74,21 @@ e0.record()
 lib.rsg_basic_chain_group(items, len(branches), 0, None)
 e1.record()
 torch.cuda.synchronize()
-raw = stamps.cpu().numpy().reshape(total, 16, 32)
+raw = stamps.cpu().numpy().reshape(total, 16, 64)
 sw = raw.astype(np.float64)
 # every XCD has a clock of its own: times are taken from the first start seen on the workgroup's XCD
-xcc = (raw[:, 0, 31] >> 32) & 0xf
-hwid = raw[:, 0, 31] & 0xffffffff
+xcc = (raw[:, 0, 63] >> 32) & 0xf
+hwid = raw[:, 0, 63] & 0xffffffff
 cu = ((hwid >> 8) & 0xf) | (((hwid >> 13) & 0x7) << 4) | (xcc << 8)      # cu_id, se_id (gfx9 HW_ID), XCD
 for x in np.unique(xcc):
     m = xcc == x
-    sw[m, :, :31] -= sw[m, 0, 0].min()
+    sw[m, :, :63] -= sw[m, 0, 0].min()
 print(f"XCDs seen: {sorted(int(v) for v in np.unique(xcc))}, distinct CUs: {len(np.unique(cu))}")
 print(f"grouped launch: {total} workgroups, {e0.elapsed_time(e1) * 1e3:.1f} us by events; "
-      f"last end at {sw[:, 0, 30].max():.0f} cycles")
+      f"last end at {sw[:, 0, 62].max():.0f} cycles")
 first = 0
 for (Cc, H, W, L, after), n in zip(branches, nblk):
-    st, en = sw[first:first + n, 0, 0], sw[first:first + n, 0, 30]
+    st, en = sw[first:first + n, 0, 0], sw[first:first + n, 0, 62]
     d = en - st
     late = int((st > 20000).sum())
     print(f"  C={Cc:3d} {H}x{W} L={L}: {n:3d} workgroups, start {st.min():.0f}..{st.max():.0f}, duration median {np.median(d):.0f} "
@@ -107,7 +104,7 @@ for c in np.unique(cu):
     m = np.where(cu == c)[0]
     m = m[np.argsort(raw[m, 0, 0])]
     s0 = raw[m, 0, 0].astype(np.float64)
-    e0_ = raw[m, 0, 30].astype(np.float64)
+    e0_ = raw[m, 0, 62].astype(np.float64)
     pat[",".join(str(item_of[i]) for i in m)] += 1
     spans.append(e0_.max() - s0.min())
     idle.append(float(sum(max(0.0, s0[j + 1] - e0_[j]) for j in range(len(m) - 1))))

@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, ".")
 from rsgnet_amd import build as B  # noqa: E402
+from rsgnet_amd import hip  # noqa: E402
 
 so = "/tmp/librsg_stamps.so"
 srcs = [os.path.join(B.CSRC, f) for f in ("chain.hip", "graph.hip", "conv_igemm.hip")]
@@ -29,11 +30,7 @@ for Cc, H, W, L in SHAPES:
     keep, wps, bps = [], [], []
     for l in range(L):
         w = (np.random.randn(Cc, Cc, 3, 3) * (2.0 / (Cc * 9)) ** 0.5).astype(np.float32)
-        n = (Cc + 31) // 32 * 32 * Cc * 9 * 2
-        wp = np.zeros(n, np.uint8)
-        bo = np.zeros((Cc + 31) // 32 * 32, np.float32)
-        lib.rsg_pack_conv_weights_host(C.c_void_p(w.ctypes.data), None, None, None, Cc, Cc, 3, 3, 0,
-                                       C.c_void_p(wp.ctypes.data), C.c_void_p(bo.ctypes.data))
+        wp, bo = hip.pack_chain_layer(w, None, None, 0)      # the pack the chain kernels of this width read
         wd, bd = torch.from_numpy(wp).cuda(), torch.from_numpy(bo).cuda()
         keep += [wd, bd]
         wps.append(wd.data_ptr())
@@ -41,7 +38,7 @@ for Cc, H, W, L in SHAPES:
     info = (C.c_int32 * 4)()
     lib.rsg_basic_chain_supported(Cc, H, W, L, Bn, info)
     nblk = info[3]
-    stamps = torch.zeros(nblk * 16 * 32, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(nblk * 16 * 64, dtype=torch.int64, device="cuda")
     lib.rsg_chain_set_stamp_buffer(C.c_void_p(stamps.data_ptr()))
     lib.rsg_basic_chain_workspace_bytes.restype = C.c_size_t
     wsp = torch.empty(max(lib.rsg_basic_chain_workspace_bytes(Cc, H, W, L, Bn), 16), dtype=torch.uint8, device="cuda")
@@ -56,22 +53,22 @@ for Cc, H, W, L in SHAPES:
     lib.rsg_basic_chain(*args)
     e1.record()
     torch.cuda.synchronize()
-    sw = stamps.cpu().numpy().reshape(nblk, 16, 32).astype(np.float64)
+    sw = stamps.cpu().numpy().reshape(nblk, 16, 64).astype(np.float64)
     nw = int(np.count_nonzero(sw[nblk // 2, :, 0]))
     blk = nblk // 2
     t0 = sw[blk, 0, 0]
-    print('   k-loop cycles per layer, wave 0 / last wave: ' + '  '.join(f'{sw[blk, 0, 4 + 3 * l] - sw[blk, 0, 3 + 3 * l]:.0f}/{sw[blk, nw - 1, 4 + 3 * l] - sw[blk, nw - 1, 3 + 3 * l]:.0f}' for l in range(L)))
+    print('   k-loop cycles per layer, wave 0 / last wave: ' + '  '.join(f'{sw[blk, 0, 5 + 4 * l] - sw[blk, 0, 3 + 4 * l]:.0f}/{sw[blk, nw - 1, 5 + 4 * l] - sw[blk, nw - 1, 3 + 4 * l]:.0f}' for l in range(L)))
     for l in range(min(L, 2)):
-        print(f"   layer {l}: per-wave [k-loop start, k-loop end, after barriers] rel. to WG start: " + "  ".join(f"w{w}:{sw[blk, w, 3 + 3 * l] - t0:.0f}/{sw[blk, w, 4 + 3 * l] - t0:.0f}/{sw[blk, w, 5 + 3 * l] - t0:.0f}" for w in range(nw)))
+        print(f"   layer {l}: per-wave [k-loop start, k-loop end, after barriers] rel. to WG start: " + "  ".join(f"w{w}:{sw[blk, w, 3 + 4 * l] - t0:.0f}/{sw[blk, w, 5 + 4 * l] - t0:.0f}/{sw[blk, w, 6 + 4 * l] - t0:.0f}" for w in range(nw)))
     st = sw[:, 0, :]
     d = lambda a, b: np.median(st[:, b] - st[:, a])
-    tot = d(0, 30)
+    tot = d(0, 62)
     parts = [("zero-fill", d(0, 1)), ("stage input", d(1, 2))]
-    kl = np.median(sum(st[:, 4 + 3 * l] - st[:, 3 + 3 * l] for l in range(L)))
-    pro = np.median(sum(st[:, 3 + 3 * l] - (st[:, 2] if l == 0 else st[:, 5 + 3 * (l - 1)]) for l in range(L)))
-    epi = np.median(sum(st[:, 5 + 3 * l] - st[:, 4 + 3 * l] for l in range(L)))
+    kl = np.median(sum(st[:, 5 + 4 * l] - st[:, 3 + 4 * l] for l in range(L)))
+    pro = np.median(sum(st[:, 3 + 4 * l] - (st[:, 2] if l == 0 else st[:, 6 + 4 * (l - 1)]) for l in range(L)))
+    epi = np.median(sum(st[:, 6 + 4 * l] - st[:, 5 + 4 * l] for l in range(L)))
     parts += [("layer prologue (bias/res/B preload)", pro), ("k-loops", kl), ("epilogue+barriers+write", epi),
-              ("final store", d(5 + 3 * (L - 1), 30))]
+              ("final store", d(6 + 4 * (L - 1), 62))]
     print(f"C={Cc} {H}x{W} L={L} blocks={nblk} waves={nw} tile_rows={info[0]} kernel {e0.elapsed_time(e1) * 1e3:.1f} us; "
           f"median WG {tot:.0f} shader clk: " +
           ", ".join(f"{n} {v / tot * 100:.0f}%" for n, v in parts), flush=True)
