@@ -520,7 +520,6 @@ __global__ void __launch_bounds__(C == 128 ? 512 : 64 * WM * WN) chain16_kernel(
     chain16_body<DT, C, WM, WN, NG, DUAL, WC>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), smem);
 }
 #ifdef RSG_CHAIN16_PROBE    // register budgets of the bodies the grouped kernel inlines (diagnostic compile only)
-template __global__ void chain16_kernel<F16, 32, 1, 8, 14, false, 48>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 64, 2, 4, 12, false, 24>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 256, 8, 1, 3, true, 6>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 256, 8, 1, 6, false, 6>(const ChainArgs);
@@ -587,9 +586,9 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
     const int npx = a.NI * a.R * a.W;
     switch (g.c[i]) {
         case 32:   // 36-row tiles of 4-layer chains: 108 pixel groups over 8 waves; 32-row tiles: 96
+            // (14 groups per wave fit the registers only with the pitch as a constant: chain_geometry keeps other maps' tiles <= 1536 pixels)
             if (npx <= 1536) chain16_body<DT, 32, 1, 8, 12>(a, bid, smem, pf);
-            else if (a.W == 48 && a.RP == chain16_row_pitch(32, 48)) chain16_body<DT, 32, 1, 8, 14, false, 48>(a, bid, smem, pf);
-            else chain16_body<DT, 32, 1, 8, 14>(a, bid, smem, pf);
+            else chain16_body<DT, 32, 1, 8, 14, false, 48>(a, bid, smem, pf);
             break;
         case 64:
             if (a.W == 24 && a.RP == chain16_row_pitch(64, 24)) chain16_body<DT, 64, 2, 4, 12, false, 24>(a, bid, smem, pf);
@@ -727,7 +726,7 @@ template <class DT>
 static chain_fn chain_lookup(int C, int npix, int dual) {
 #if RSG_CHAIN16
     switch (C) {
-        case 32: return npix <= 1536 ? chain16_kernel<DT, 32, 1, 8, 12> : chain16_kernel<DT, 32, 1, 8, 14>;
+        case 32: return npix <= 1536 ? chain16_kernel<DT, 32, 1, 8, 12> : chain16_kernel<DT, 32, 1, 8, 14, false, 48>;
         case 64: return chain16_kernel<DT, 64, 2, 4, 12>;
 #if RSG_CHAIN16_128
         case 128: return dual ? chain16_kernel<DT, 128, 4, 1, 12, true> : chain16_kernel<DT, 128, 4, 1, 12>;
@@ -766,10 +765,12 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     if (ni_want < 1) ni_want = g_chain_max_ni;
     if (!cfg) return 1;
     if (C == 48 && nlayers != 2) return 1;               // chain48_body: one BasicBlock, the residual is the launch's own input
-    const int cap = 32 * cfg->NT * cfg->WN;              // pixels a workgroup can own
+    int cap = 32 * cfg->NT * cfg->WN;                    // pixels a workgroup can own
     const int PS = 2 * C + 16;
     nthr = 64 * cfg->WM * cfg->WN;
     const int RP = chain_row_pitch(C, W);
+    // chain16_body<32>: 14 pixel groups per wave (1792 pixels) exist only for the 48-pixel-wide map with its pitch as a constant
+    if (chain_is16(C) && C == 32 && !(W == 48 && RP == chain16_row_pitch(32, 48))) cap = 1536;
     a.RP = RP;
     auto bytes = [&](int ni, int R) { return ni * (R + 2) * RP + RSG_CHAIN_MAX_LAYERS * C * 4; };   // image + biases
     // 384 channels, one BasicBlock, a small batch: whole images would occupy `batch` compute units for the longest

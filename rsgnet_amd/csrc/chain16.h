@@ -265,6 +265,8 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
         }
         block(NCB - 1, std::false_type{});
         RSG_STAMP(4 + 4 * l);
+        int wd = own;
+        if (!WC) asm volatile("" : "+v"(wd));            // keep the NG write addresses out of the loop preheader
         // ---- ReLU -> 16 bit: one packed convert and one packed max per two elements -----------------------------------------
         uint4 o[NG];
 #pragma unroll
@@ -274,14 +276,41 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
             for (int r = 0; r < 4; ++r) { v[r] = acc[g][0][r]; v[4 + r] = acc[g][1][r]; }
             o[g] = __builtin_bit_cast(uint4, DT::relu_pack(v));
         }
-        RSG_STAMP(5 + 4 * l);
-        if (!DUAL) chain16_barrier();                    // in place: every wave has finished reading the image
-        int wd = own;
-        if (!WC) asm volatile("" : "+v"(wd));            // keep the NG write addresses out of the loop preheader
-        if constexpr (!DUAL && !ODD) {                   // first conv of a block: pick up the block input before it is overwritten
+        if constexpr (!DUAL && !ODD) {
+            // first conv of a block, in place: pick up the block input (this lane's chunk of its own pixels) before the
+            // write-back overwrites it.  Nobody writes the image before the barrier below, so the reads go out in front of
+            // it (behind the conversions: both sets of values and the accumulators do not fit the registers together).
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < NG; ++g) xr[g] = *reinterpret_cast<const uint4*>(wr + pix[g] + wd);
         }
+        RSG_STAMP(5 + 4 * l);
+        if (ODD && l + 1 == p.nlayers) {
+            // the chain's last layer goes straight from the accumulators to memory (the TH output rows of the tile; sc1:
+            // written through, see the hand-off): no write-back into the image, no barrier, no second pass over LDS.  A
+            // lane's 16 bytes are a chunk of its pixel; a wave's store covers 16 pixels x 64 B.
+            const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * W * C * 2, 0x00020000);
+            const int r_lo = tile * p.TH - y_first, r_hi = r_lo + min(p.TH, p.H - tile * p.TH);
+            // (opaque: as loop invariants hipcc computes the 14 addresses and their predicates in front of the layer loop and
+            // spills them across it)
+            int q0 = wn * NG * 16 + pi, gl = glim, RWq = R * W, Wq = W;
+            asm volatile("" : "+v"(q0), "+v"(gl), "+s"(RWq), "+s"(Wq));       // (and the division constants)
+            int i = q0 / RWq, rem = q0 - i * RWq;
+            int r = rem / Wq, x = rem - r * Wq;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g < gl && b0 + i < p.B && r >= r_lo && r < r_hi)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[g]), out_rsrc,
+                                                           (((b0 + i) * p.H + y_first + r) * W + x) * (C * 2) + cb8 * 2, 0, 16);
+                x += 16;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)               // a 16-pixel step crosses at most three rows of the narrowest map (6 pixels)
+                    if (x >= W) { x -= W; if (++r == R) { r = 0; ++i; } }
+            }
+            RSG_STAMP(6 + 4 * l);
+            return;
+        }
+        if (!DUAL) chain16_barrier();                    // in place: every wave has finished reading the image
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             if (g < glim) *reinterpret_cast<uint4*>(wr + pix[g] + wd) = o[g];
@@ -294,31 +323,12 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
         layer(l, std::false_type{}, xr);
         layer(l + 1, std::true_type{}, xr);
     }
-
-    // ---- store the TH output rows of every image slot (sc1: written through, see the hand-off) ---------------------------
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.B * p.H * W * C * 2, 0x00020000);
-    const int out_rows = min(p.TH, p.H - tile * p.TH);
-    const char* const img = smem;      // an even number of layers: the last one wrote image 0
-    int ts = threadIdx.x, Ws = W;
-    asm volatile("" : "+v"(ts), "+s"(Ws));                  // the store loop's constants are built here, not in front of the k-loops
-    const int rowcs = Ws * CPP, sq = NTHR / rowcs, sr = NTHR - sq * rowcs;
-    for (int i = 0; i < p.NI; ++i) {
-        if (b0 + i >= p.B) break;
-        const int gbase = ((b0 + i) * p.H + tile * p.TH) * Ws * C * 2;
-        const char* const slot = img + (i * slot_rows + tile * p.TH - y_first + 1) * RP + PS;
-        int r = ts / rowcs, c = ts - r * rowcs;
-        for (int k = ts; k < out_rows * rowcs; k += NTHR) {
-            const uint4 v = *reinterpret_cast<const uint4*>(slot + r * RP + (c / CPP) * PS + (c % CPP) * 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, gbase + k * 16, 0, 16);
-            r += sq; c += sr;
-            if (c >= rowcs) { c -= rowcs; ++r; }
-        }
-    }
     if (p.done) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores have left the CU
         __syncthreads();
-        if (tid < 3 && !(p.debug & 4))     // debug bit 4 (tests): the producer never signals, every consumer poll gives up
-            __hip_atomic_store(p.done + block_id * 3 + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t3 = threadIdx.x;
+        if (t3 < 3 && !(p.debug & 4))      // debug bit 4 (tests): the producer never signals, every consumer poll gives up
+            __hip_atomic_store(p.done + block_id * 3 + t3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     RSG_STAMP(62);
 }
