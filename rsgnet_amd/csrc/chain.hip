@@ -507,10 +507,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& p, const int block_i
 #ifndef RSG_CHAIN16
 #define RSG_CHAIN16 1
 #endif
-// 128 channels stay on chain_body: its 16x12 map runs on four waves (one per SIMD), and a single wave cannot keep the 16-cycle
-// MFMA fed (two of them + a B read + its wait fill the issue slots: k-loop 69 % against 88 % with the 32-cycle form)
+// -DRSG_CHAIN16_128=0 keeps the 128-channel chains on chain_body (same-visit A/B): with TWO output-channel tiles per wave its
+// four waves (one per SIMD) could not keep the 16-cycle MFMA fed (k-loop 69 % against 88 % with the 32-cycle form); with four
+// tiles per wave (chain16_mt) a B fragment feeds four MFMAs
 #ifndef RSG_CHAIN16_128
-#define RSG_CHAIN16_128 0
+#define RSG_CHAIN16_128 1
 #endif
 static bool chain_is16(int C) { return RSG_CHAIN16 && (C == 32 || C == 64 || (RSG_CHAIN16_128 && C == 128) || C == 256); }
 
@@ -520,7 +521,8 @@ __global__ void __launch_bounds__(C == 128 ? 512 : 64 * WM * WN) chain16_kernel(
     chain16_body<DT, C, WM, WN, NG, DUAL, WC>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), smem);
 }
 #ifdef RSG_CHAIN16_PROBE    // register budgets of the bodies the grouped kernel inlines (diagnostic compile only)
-template __global__ void chain16_kernel<F16, 64, 2, 4, 12, false, 24>(const ChainArgs);
+template __global__ void chain16_kernel<F16, 64, 1, 8, 6, false, 24>(const ChainArgs);
+template __global__ void chain16_kernel<F16, 128, 2, 2, 6, false, 12>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 256, 8, 1, 3, true, 6>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 256, 8, 1, 6, false, 6>(const ChainArgs);
 #endif
@@ -591,15 +593,15 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
             else chain16_body<DT, 32, 1, 8, 14, false, 48>(a, bid, smem, pf);
             break;
         case 64:
-            if (a.W == 24 && a.RP == chain16_row_pitch(64, 24)) chain16_body<DT, 64, 2, 4, 12, false, 24>(a, bid, smem, pf);
-            else chain16_body<DT, 64, 2, 4, 12>(a, bid, smem, pf);
+            if (a.W == 24 && a.RP == chain16_row_pitch(64, 24)) chain16_body<DT, 64, 1, 8, 6, false, 24>(a, bid, smem, pf);
+            else chain16_body<DT, 64, 1, 8, 6>(a, bid, smem, pf);
             break;
-        case 128:  // 16x12 maps on FOUR waves (one per SIMD, all 12 pixel groups each; waves 4-7 leave at once): half the
-            // weight-fragment loads of eight waves (profiles/r02m_ab_w4_c128.txt)
+        case 128:  // 16x12 maps on FOUR waves (one per SIMD; waves 4-7 leave at once): half the weight-fragment loads of eight
+            // waves (profiles/r02m_ab_w4_c128.txt); 2 x 2 waves of 64 output channels x 6 pixel groups
             if (threadIdx.x >= 256) return;
 #if RSG_CHAIN16_128
-            if (a.dual) chain16_body<DT, 128, 4, 1, 12, true>(a, bid, smem, pf);
-            else chain16_body<DT, 128, 4, 1, 12>(a, bid, smem, pf);
+            if (a.W == 12 && a.RP == chain16_row_pitch(128, 12)) chain16_body<DT, 128, 2, 2, 6, false, 12>(a, bid, smem, pf);
+            else chain16_body<DT, 128, 2, 2, 6>(a, bid, smem, pf);
 #else
             if (a.dual) chain_body<DT, 128, 4, 1, 6, true>(a, bid, smem, pf);
             else chain_body<DT, 128, 4, 1, 6>(a, bid, smem, pf);
@@ -727,9 +729,9 @@ static chain_fn chain_lookup(int C, int npix, int dual) {
 #if RSG_CHAIN16
     switch (C) {
         case 32: return npix <= 1536 ? chain16_kernel<DT, 32, 1, 8, 12> : chain16_kernel<DT, 32, 1, 8, 14, false, 48>;
-        case 64: return chain16_kernel<DT, 64, 2, 4, 12>;
+        case 64: return chain16_kernel<DT, 64, 1, 8, 6>;
 #if RSG_CHAIN16_128
-        case 128: return dual ? chain16_kernel<DT, 128, 4, 1, 12, true> : chain16_kernel<DT, 128, 4, 1, 12>;
+        case 128: return chain16_kernel<DT, 128, 2, 2, 6>;
 #endif
         case 256:
             if (npix <= 48) return dual ? chain16_kernel<DT, 256, 8, 1, 3, true> : chain16_kernel<DT, 256, 8, 1, 3>;
@@ -788,7 +790,9 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
         lds = bytes(ni, H);
         // two images (ping-pong) where they fit: 16x12x128 and 8x6x256 (73 / 45 KB each)
         const int image = ni * (H + 2) * RP;
-        a.dual = g_chain_dual && (C == 128 || (C == 256 && ni * H * W <= 64)) && lds + image <= CHAIN_LDS_LIMIT ? 1 : 0;
+        // (chain16_body<128> runs in place: its ping-pong form does not fit 256 registers with four output-channel tiles per
+        // wave, and one more barrier per layer among four waves is cheap)
+        a.dual = g_chain_dual && ((C == 128 && !chain_is16(C)) || (C == 256 && ni * H * W <= 64)) && lds + image <= CHAIN_LDS_LIMIT ? 1 : 0;
         if (a.dual) lds += image;
         return 0;
     }
@@ -1021,19 +1025,20 @@ extern "C" int rsg_chain_pack_kind(int32_t c) { return chain_is16(c) ? 16 : (c =
 
 // Weights of one layer of a chain16_body chain (chain16.h): w fp32 [C][C][3][3], BatchNorm folded like
 // rsg_pack_conv_weights_host (scale into the weights, shift into the bias; either may be NULL).
-// wp_out: 18 C^2 bytes = [wave row C/32][k-step (32-channel block, tap)][tile 2][lane 64] x 16 B; bias_out: C floats.
+// wp_out: 18 C^2 bytes = [wave row C / (16 MT)][k-step (32-channel block, tap)][tile MT][lane 64] x 16 B, MT = chain16_mt(C);
+// bias_out: C floats.
 extern "C" int rsg_pack_chain16_weights_host(const float* w, const float* scale, const float* shift, int32_t c, int32_t dtype,
                                              void* wp_out, float* bias_out) {
     if (!w || !wp_out || !bias_out) RSG_FAIL("pack_chain16: null pointer");
     if (c < 32 || c % 32) RSG_FAIL("pack_chain16: %d channels (multiples of 32)", c);
     unsigned short* dst = (unsigned short*)wp_out;
-    const int KS = c / 32 * 9;
-    for (int wm = 0; wm < c / 32; ++wm)
+    const int KS = c / 32 * 9, MT = chain16_mt(c), CW = 16 * MT;
+    for (int wm = 0; wm < c / CW; ++wm)
         for (int s = 0; s < KS; ++s)
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
                 for (int lane = 0; lane < 64; ++lane) {
                     const int i = lane & 15, q = lane >> 4, sig = ((q & 1) << 1) | (q >> 1);
-                    const int co = 32 * wm + 8 * (i >> 2) + 4 * m + (i & 3);
+                    const int co = CW * wm + 4 * MT * (i >> 2) + 4 * m + (i & 3);
                     const int cb = s / 9, tap = s % 9;
                     for (int e = 0; e < 8; ++e) {
                         const int ci = 32 * cb + 8 * sig + e;
@@ -1041,7 +1046,7 @@ extern "C" int rsg_pack_chain16_weights_host(const float* w, const float* scale,
                         unsigned short bits;
                         if (dtype == RSG_BF16) { const BF16::elem h = BF16::from_f32(v); memcpy(&bits, &h, 2); }
                         else { const F16::elem h = F16::from_f32(v); memcpy(&bits, &h, 2); }
-                        dst[((((size_t)wm * KS + s) * 2 + m) * 64 + lane) * 8 + e] = bits;
+                        dst[((((size_t)wm * KS + s) * MT + m) * 64 + lane) * 8 + e] = bits;
                     }
                 }
     for (int co = 0; co < c; ++co) bias_out[co] = shift ? shift[co] : 0.f;

@@ -16,14 +16,14 @@
 //     registers across a k-loop, no global workspace (chain_body parked 3 of 7 pixel groups of the C = 32 chain there:
 //     155 MB moved per grouped launch for 76 MB of activations), and the odd layers' epilogue is the even layers'.
 //
-// Mapping.  A wave owns 32 output channels (wave row wm: two 16-channel tiles) of NG groups of 16 pixels (wave column wn).
-// One k-step = one tap of one 32-channel block of the input: two A fragments (weights, from L2 in packed order through a
-// register ring that keeps running across layers), one ds_read_b128 per pixel group (B), two MFMAs per pixel group.
-//   A lane (i = lane & 15, q = lane >> 4): output channel 32 wm + 8 (i >> 2) + 4 m + (i & 3) of tile m,
+// Mapping.  A wave owns 16 MT output channels (wave row wm: MT = 2 or 4 tiles of 16, chain16_mt) of NG groups of 16 pixels
+// (wave column wn).  One k-step = one tap of one 32-channel block of the input: MT A fragments (weights, from L2 in packed
+// order through a register ring that keeps running across layers), one ds_read_b128 per pixel group (B), MT MFMAs per group.
+//   A lane (i = lane & 15, q = lane >> 4): output channel 16 MT wm + 4 MT (i >> 2) + 4 m + (i & 3) of tile m,
 //                                         input channels 32 cb + 8 sigma(q) .. + 7           (rsg_pack_chain16_weights_host)
 //   B lane (col, q): pixel pi(col) of the group, the same 8 input channels = 16 bytes at chunk sigma(q) of the block
-//   D lane (col, q): rows 4q .. 4q + 3 of tile m  ->  channels 32 wm + 8 q + 4 m + r: the lane's 8 accumulators of a
-//                    pixel group are channels [32 wm + 8 q, + 8) of pixel pi(col)
+//   D lane (col, q): rows 4q .. 4q + 3 of tile m  ->  channels 16 MT wm + 4 MT q + 4 m + r: the lane's 4 MT accumulators of
+//                    a pixel group are channels [16 MT wm + 4 MT q, + 4 MT) of pixel pi(col): MT / 2 chunks of 16 bytes
 // sigma = [0, 2, 1, 3] and pi (columns {0-3, 12-15} take the group's even pixels, {4-11} the odd ones) make every
 // 16-lane phase of a ds_read_b128 ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) cover all 64 banks once with the
 // image's odd pixel stride of (2 C + 16) / 16 chunks; the 8-lane phases of the ds_write_b128 of the epilogue cover the 32
@@ -44,10 +44,17 @@ __device__ __forceinline__ void chain16_barrier() { asm volatile("s_waitcnt lgkm
 // a vector add, and a 16-cycle MFMA leaves half of its issue slots to everything else.
 constexpr int chain16_row_pitch(int C, int W) { return (W + 2) * (2 * C + 16) + (256 - (2 * (2 * C + 16)) % 256) % 256; }
 
+// Output-channel tiles (of 16) per wave, by width -- shared by the kernels and rsg_pack_chain16_weights_host.  Four where the
+// width allows: a B fragment then feeds four MFMAs (one LDS read + its wait per 64 matrix-pipe cycles instead of per 32; a
+// 16-cycle MFMA holds the issue port for 8), and the 128-channel map's four waves stay fed with one wave per SIMD.
+constexpr int chain16_mt(int C) { return (C == 64 || C == 128) ? 4 : 2; }
+
 template <class DT, int C, int WM, int WN, int NG, bool DUAL = false, int WC = 0>
 __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block_id, char* smem, const unsigned pf = 0) {
     constexpr int NTHR = 64 * WM * WN;
-    static_assert(C % 32 == 0 && WM * 32 == C, "one wave row per 32 output channels");
+    constexpr int MT = chain16_mt(C);                    // 16-channel output tiles per wave
+    constexpr int CW = 16 * MT, NX = MT / 2;             // output channels per wave; 16-byte chunks of a pixel per lane
+    static_assert(C % 32 == 0 && WM * CW == C, "one wave row per 16 MT output channels");
     constexpr int NCB = C / 32, KS = NCB * 9;           // k-steps per layer: (32-channel block, tap)
     constexpr int PS = 2 * C + 16;                       // LDS bytes per pixel
     constexpr int CPP = C / 8;                           // 16-byte chunks per pixel
@@ -159,8 +166,8 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
     }
     // groups [0, glim) of this lane are pixels of the tile (the others multiply pixel 0 and write nothing)
     const int glim = (npix - pi + 15) / 16 - wn * NG;
-    const int own = RP + PS + (32 * wm + 8 * q) * 2 - sig * 16;   // pix[g] -> this lane's 8 output channels of the pixel
-    const int cb8 = 32 * wm + 8 * q;
+    const int cb8 = CW * wm + 4 * MT * q;                // this lane's 4 MT consecutive output channels
+    const int own = RP + PS + cb8 * 2 - sig * 16;        // pix[g] -> those channels of the pixel
     __syncthreads();
     asm volatile("" ::"v"(pf));                           // the grouped launch's weight prefetch loads end here
     RSG_STAMP(2);
@@ -168,18 +175,20 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
     // A ring: NPF k-steps ahead (a step is NG x 32 matrix-pipe cycles per wave); B ring: NB fragments in flight.  Both
     // wrap at the end of a 32-channel block (9 taps x NG groups), so the body of one block can be a loop iteration.
     constexpr int NPF = (C == 256 && NG <= 3) ? 9 : 3;
-    constexpr int NB = NG % 7 == 0 ? 7 : (NG % 6 == 0 && NG > 6 ? 6 : 9);
+    constexpr int NB = NG % 7 == 0 ? 7 : (NG % 6 == 0 && (NG > 6 || MT == 4) ? 6 : 9);
     constexpr int NJ = 9 * NG;                           // (tap, pixel group) pairs of a channel block, in issue order
     static_assert(9 % NPF == 0 && NJ % NB == 0, "the fragment rings wrap at the end of a channel block");
-    uint4 aq[NPF][2];
+    uint4 aq[NPF][MT];
     {
-        const uint4* ap = p.wpk[0] + (size_t)wm * KS * 2 * 64 + lane;
+        const uint4* ap = p.wpk[0] + (size_t)wm * KS * MT * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < NPF; ++k) { aq[k][0] = ap[(2 * k) * 64]; aq[k][1] = ap[(2 * k + 1) * 64]; }
+        for (int k = 0; k < NPF; ++k)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) aq[k][m] = ap[(MT * k + m) * 64];
     }
     // One layer; ODD = second conv of a BasicBlock.  xr: this lane's chunk of its pixels of the block input -- picked up by
     // the first conv's write-back just before it overwrites it (in place) and start value of the second conv's accumulators.
-    auto layer = [&](const int l, auto odd_tag, uint4 (&xr)[NG]) {
+    auto layer = [&](const int l, auto odd_tag, uint4 (&xr)[NG][NX]) {
         constexpr bool ODD = decltype(odd_tag)::value;
         const char* const rd = smem + (DUAL ? (ODD ? lds_bytes : 0) : 0);
         char* const wr = smem + (DUAL ? (ODD ? 0 : lds_bytes) : 0);
@@ -189,31 +198,50 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
         if (!WC) asm volatile("" : "+s"(rpl));
         auto toff = [&](int t) { return (t / 3) * rpl + (t % 3) * PS; };
         // ---- accumulators start at the folded-BN bias; second conv of a block: + the block input -------------------------
-        f32x4 acc[NG][2];
+        f32x4 acc[NG][MT];
         {
-            const float4 blo = *reinterpret_cast<const float4*>(sbias + l * C + cb8);
-            const float4 bhi = *reinterpret_cast<const float4*>(sbias + l * C + cb8 + 4);
-            const float b8[8] = {blo.x, blo.y, blo.z, blo.w, bhi.x, bhi.y, bhi.z, bhi.w};
+            float bv[4 * MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float4 b4 = *reinterpret_cast<const float4*>(sbias + l * C + cb8 + 4 * m);
+                bv[4 * m] = b4.x; bv[4 * m + 1] = b4.y; bv[4 * m + 2] = b4.z; bv[4 * m + 3] = b4.w;
+            }
             if constexpr (ODD) {
-                if constexpr (DUAL) {
+                // ping-pong mode: the block input is still in the image this layer overwrites at its end; in batches of GB
+                // pixel groups (all reads first would hold NG x NX x 4 registers beside the accumulators)
+                constexpr int GB = DUAL ? 3 : NG;
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) xr[g] = *reinterpret_cast<const uint4*>(wr + pix[g] + own);
-                }
+                for (int g0 = 0; g0 < NG; g0 += GB) {
+                    if constexpr (DUAL) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, xr[g]), f32x8);
+                        for (int g = g0; g < g0 + GB && g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { acc[g][0][r] = b8[r] + xf[r]; acc[g][1][r] = b8[4 + r] + xf[4 + r]; }
+                            for (int c = 0; c < NX; ++c) xr[g][c] = *reinterpret_cast<const uint4*>(wr + pix[g] + own + 16 * c);
+                    }
+#pragma unroll
+                    for (int g = g0; g < g0 + GB && g < NG; ++g)
+#pragma unroll
+                        for (int c = 0; c < NX; ++c) {
+                            const f32x8 xf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, xr[g][c]), f32x8);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                acc[g][2 * c][r] = bv[8 * c + r] + xf[r];
+                                acc[g][2 * c + 1][r] = bv[8 * c + 4 + r] + xf[4 + r];
+                            }
+                        }
+                    if constexpr (DUAL) __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { acc[g][0][r] = b8[r]; acc[g][1][r] = b8[4 + r]; }
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[g][m][r] = bv[4 * m + r];
             }
         }
-        const uint4* const ap = p.wpk[l] + (size_t)wm * KS * 2 * 64 + lane;
-        const uint4* const apn = p.wpk[l + 1 < p.nlayers ? l + 1 : l] + (size_t)wm * KS * 2 * 64 + lane;
+        const uint4* const ap = p.wpk[l] + (size_t)wm * KS * MT * 64 + lane;
+        const uint4* const apn = p.wpk[l + 1 < p.nlayers ? l + 1 : l] + (size_t)wm * KS * MT * 64 + lane;
         RSG_STAMP(3 + 4 * l);
         // ---- k-loop.  Issue order pinned per k-step (left alone, hipcc sinks the loads next to their uses): the two A
         // loads of step s + NPF, then per pixel group its two MFMAs and the B read that refills the ring slot they freed
@@ -224,8 +252,8 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
         auto block = [&](const int cb, auto more_tag) {
             constexpr bool MORE = decltype(more_tag)::value;    // another channel block of this layer follows
             const char* const rdk = rd + cb * 64;
-            const uint4* const apk = ap + cb * (9 * 2 * 64);
-            const uint4* const nxt = MORE ? apk + 9 * 2 * 64 : apn;
+            const uint4* const apk = ap + cb * (9 * MT * 64);
+            const uint4* const nxt = MORE ? apk + 9 * MT * 64 : apn;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 // the row offset of the fragments issued in this step stays a scalar operand of one add per read: as
@@ -233,26 +261,28 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
                 int ro[3] = {0, rpl, 2 * rpl};
                 if (!WC) asm volatile("" : "+s"(ro[1]), "+s"(ro[2]));
                 auto roff = [&](int tt) { return ro[tt / 3] + (tt % 3) * PS; };
-                const typename DT::vec8 a0 = __builtin_bit_cast(typename DT::vec8, aq[t % NPF][0]);
-                const typename DT::vec8 a1 = __builtin_bit_cast(typename DT::vec8, aq[t % NPF][1]);
+                typename DT::vec8 a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = __builtin_bit_cast(typename DT::vec8, aq[t % NPF][m]);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int j = t * NG + g;
                     const typename DT::vec8 b = __builtin_bit_cast(typename DT::vec8, bq[j % NB]);
-                    acc[g][0] = Mfma16<DT>::run(a0, b, acc[g][0]);
-                    acc[g][1] = Mfma16<DT>::run(a1, b, acc[g][1]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) acc[g][m] = Mfma16<DT>::run(a[m], b, acc[g][m]);
                     if (j + NB < NJ) bq[j % NB] = *reinterpret_cast<const uint4*>(rdk + pix[(j + NB) % NG] + roff((j + NB) / NG));
                     else if (MORE) bq[j % NB] = *reinterpret_cast<const uint4*>(rdk + 64 + pix[(j + NB - NJ) % NG] + roff((j + NB - NJ) / NG));
                 }
                 // the A fragments of step t + NPF go into the slot this step's MFMAs have just read (issued behind them: no copy)
-                if (t + NPF < 9) { aq[t % NPF][0] = apk[(2 * (t + NPF)) * 64]; aq[t % NPF][1] = apk[(2 * (t + NPF) + 1) * 64]; }
-                else { aq[t % NPF][0] = nxt[(2 * (t + NPF - 9)) * 64]; aq[t % NPF][1] = nxt[(2 * (t + NPF - 9) + 1) * 64]; }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    aq[t % NPF][m] = (t + NPF < 9) ? apk[(MT * (t + NPF) + m) * 64] : nxt[(MT * (t + NPF - 9) + m) * 64];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // 2 MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);         // MT MFMAs
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 DS read
                 }
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);              // the A prefetches (VMEM reads)
+                __builtin_amdgcn_sched_group_barrier(0x020, MT, 0);             // the A prefetches (VMEM reads)
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -268,21 +298,28 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
         int wd = own;
         if (!WC) asm volatile("" : "+v"(wd));            // keep the NG write addresses out of the loop preheader
         // ---- ReLU -> 16 bit: one packed convert and one packed max per two elements -----------------------------------------
-        uint4 o[NG];
+        uint4 o[NG][NX];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            f32x8 v;
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = acc[g][0][r]; v[4 + r] = acc[g][1][r]; }
-            o[g] = __builtin_bit_cast(uint4, DT::relu_pack(v));
-        }
+            for (int c = 0; c < NX; ++c) {
+                f32x8 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[g][2 * c][r]; v[4 + r] = acc[g][2 * c + 1][r]; }
+                o[g][c] = __builtin_bit_cast(uint4, DT::relu_pack(v));
+                // pinned in front of the barrier: left alone, hipcc sinks the conversions into the predicated stores BEHIND it,
+                // where every wave then converts while the image waits (they belong under the wait for the slowest wave)
+                asm volatile("" ::"v"(o[g][c].x), "v"(o[g][c].y), "v"(o[g][c].z), "v"(o[g][c].w));
+            }
         if constexpr (!DUAL && !ODD) {
             // first conv of a block, in place: pick up the block input (this lane's chunk of its own pixels) before the
             // write-back overwrites it.  Nobody writes the image before the barrier below, so the reads go out in front of
             // it (behind the conversions: both sets of values and the accumulators do not fit the registers together).
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) xr[g] = *reinterpret_cast<const uint4*>(wr + pix[g] + wd);
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int c = 0; c < NX; ++c) xr[g][c] = *reinterpret_cast<const uint4*>(wr + pix[g] + wd + 16 * c);
         }
         RSG_STAMP(5 + 4 * l);
         if (ODD && l + 1 == p.nlayers) {
@@ -293,15 +330,20 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
             const int r_lo = tile * p.TH - y_first, r_hi = r_lo + min(p.TH, p.H - tile * p.TH);
             // (opaque: as loop invariants hipcc computes the 14 addresses and their predicates in front of the layer loop and
             // spills them across it)
-            int q0 = wn * NG * 16 + pi, gl = glim, RWq = R * W, Wq = W;
-            asm volatile("" : "+v"(q0), "+v"(gl), "+s"(RWq), "+s"(Wq));       // (and the division constants)
+            int tl = threadIdx.x, RWq = R * W, Wq = W;
+            asm volatile("" : "+v"(tl), "+s"(RWq), "+s"(Wq));                  // (and the division constants)
+            const int pi2 = chain16_pi(tl & 15);
+            const int q0 = wn * NG * 16 + pi2, gl = (npix - pi2 + 15) / 16 - wn * NG;
             int i = q0 / RWq, rem = q0 - i * RWq;
             int r = rem / Wq, x = rem - r * Wq;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if (g < gl && b0 + i < p.B && r >= r_lo && r < r_hi)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[g]), out_rsrc,
-                                                           (((b0 + i) * p.H + y_first + r) * W + x) * (C * 2) + cb8 * 2, 0, 16);
+                if (g < gl && b0 + i < p.B && r >= r_lo && r < r_hi) {
+#pragma unroll
+                    for (int c = 0; c < NX; ++c)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[g][c]), out_rsrc,
+                                                               (((b0 + i) * p.H + y_first + r) * W + x) * (C * 2) + cb8 * 2, 16 * c, 16);
+                }
                 x += 16;
 #pragma unroll
                 for (int k = 0; k < 3; ++k)               // a 16-pixel step crosses at most three rows of the narrowest map (6 pixels)
@@ -313,13 +355,16 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
         if (!DUAL) chain16_barrier();                    // in place: every wave has finished reading the image
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            if (g < glim) *reinterpret_cast<uint4*>(wr + pix[g] + wd) = o[g];
+            if (g < glim) {
+#pragma unroll
+                for (int c = 0; c < NX; ++c) *reinterpret_cast<uint4*>(wr + pix[g] + wd + 16 * c) = o[g][c];
+            }
         chain16_barrier();                               // the new image is complete
         RSG_STAMP(6 + 4 * l);
     };
 #pragma unroll 1
     for (int l = 0; l < p.nlayers; l += 2) {             // one BasicBlock per iteration
-        uint4 xr[NG];
+        uint4 xr[NG][NX];
         layer(l, std::false_type{}, xr);
         layer(l + 1, std::true_type{}, xr);
     }

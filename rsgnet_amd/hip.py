@@ -181,6 +181,13 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{path} is missing: build it with `python -m rsgnet_amd.build` (hipcc, gfx950). "
                 "rsgnet_amd has no non-HIP fallback.")
+        # the in-tree library must be the build of the sources in the tree (a failed rebuild leaves the previous .so behind,
+        # and a measurement or a green test of THAT library says nothing about the sources); a library named through
+        # RSGNET_HIP_LIB is another build on purpose (A/B runs)
+        if not os.environ.get("RSGNET_HIP_LIB") and os.environ.get("RSGNET_HIP_ALLOW_STALE") != "1" and _build.stale():
+            raise RuntimeError(
+                f"{path} was not built from the sources, flags and compiler in this tree ({_build.describe()}): "
+                "run `python -m rsgnet_amd.build` (RSGNET_HIP_ALLOW_STALE=1 loads it anyway)")
         l = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)      # AttributeError if the .so does not export it
