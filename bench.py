@@ -37,6 +37,11 @@ GFLOP_PER_IMG = {"hrnet_w32_256x192": 15.29, "rsgnet_w32_256x192_coco": 17.80,  
 PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA, MI355X_MICROARCH.md chip table
 
 
+def hip_lib_path():
+    from rsgnet_amd import hip
+    return hip.lib_path()
+
+
 def pmc_traffic(kernel_key, workload="hrnet_w32_256x192"):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/*_pmc_summary.json:
     FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), or None.  The passes are
@@ -54,6 +59,27 @@ def pmc_traffic(kernel_key, workload="hrnet_w32_256x192"):
     return {"bytes_per_launch": int((d["fetch_mb_per_launch"] + d["write_mb_per_launch"]) * 1e6),
             "fetch_mb": d["fetch_mb_per_launch"], "write_mb": d["write_mb_per_launch"],
             "source": os.path.basename(files[-1])}
+def rocprof_kernel(kernel_prefix, workload, gflop_per_step, launches_per_step):
+    """Average duration of a kernel in the committed `rocprofv3 --kernel-trace --stats` summary of the one-stream bench
+    command (profiles/*_kernel_stats_one_stream.csv, tools/gpu_r04_prof.sh) and the roofline fraction it implies; None when
+    there is none.  Headline workload only."""
+    import csv
+    import glob
+    if workload != "hrnet_w32_256x192":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats_one_stream.csv")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        for r in csv.DictReader(f):
+            if r["Name"].replace("void ", "").startswith(kernel_prefix):
+                us = float(r["AverageNs"]) / 1e3
+                tf = gflop_per_step / (launches_per_step * us) * 1e3
+                return {"avg_us_per_launch": round(us, 2), "tflops": round(tf, 1), "frac": round(tf / PEAK_TFLOPS, 4),
+                        "source": os.path.basename(files[-1])}
+    return None
+
+
 def pmc_mfma_busy(kernel_prefix, workload="hrnet_w32_256x192"):
     """Matrix-pipe utilisation of a kernel from the committed SQ counter pass (profiles/*_sq_summary.json, tools/gpu_sq.sh +
     tools/sq_summary.py): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the fraction of SIMD
@@ -281,12 +307,11 @@ def train_bench(a, rank, world, local, dev, dist):
     """BASELINE configs[3]: HRNet-W32 256x192 training step (forward + backward + Adam), 32 crops per GPU (256 over 8),
     gradients all-reduced over RCCL between backward and step.  A step = the reference's loop body
     (lib/core/function.py:46-64) through rsgnet_amd.parallel.DataParallelStep.  Prints its own JSON line."""
-    from oracle import train_step_oracle as tso            # targets (data) and the cpu_baseline leg only
     from rsgnet_amd import make_cfg, models
     from rsgnet_amd.loss import JointsMSELoss
     from rsgnet_amd.optim import FusedAdam
     from rsgnet_amd.parallel import DataParallelStep
-    from rsgnet_amd.weights import synth_input, synth_state_dict
+    from rsgnet_amd.weights import gaussian_targets, limb_targets, synth_input, synth_state_dict
     rsg = a.workload.startswith("rsgnet")            # --workload rsgnet_w32_256x192_coco --train: the step of `rsgnet_train`
     tag = "rsgnet_w32_256x192_coco" if rsg else "hrnet_w32_256x192"
     batch = a.batch or 32
@@ -303,9 +328,9 @@ def train_bench(a, rank, world, local, dev, dist):
         from rsgnet_amd.loss import relation_target_vector, rsgnet_loss
         crit = JointsMSELoss(True)
         step_fn = DataParallelStep(model, lambda outs, *t: rsgnet_loss(outs, *t, crit), opt)
-        target, tw = tso.gaussian_targets(batch, 17, (128, 96), 200 + rank)
-        all_t, all_w = tso.gaussian_targets(batch, 17, (128, 96), 300 + rank)
-        limbs_t = tso.limb_targets(batch, 18, (128, 96), 400 + rank)
+        target, tw = gaussian_targets(batch, 17, (128, 96), 200 + rank)
+        all_t, all_w = gaussian_targets(batch, 17, (128, 96), 300 + rank)
+        limbs_t = limb_targets(batch, 18, (128, 96), 400 + rank)
         target, tw, all_t, all_w, limbs_t = (t.to(dev) for t in (target, tw, all_t, all_w, limbs_t))
 
         def step():
@@ -313,7 +338,7 @@ def train_bench(a, rank, world, local, dev, dist):
             losses.append(loss)
     else:
         step_fn = DataParallelStep(model, JointsMSELoss(True), opt)
-        target, tw = tso.gaussian_targets(batch, 17, (64, 48), 200 + rank)
+        target, tw = gaussian_targets(batch, 17, (64, 48), 200 + rank)
         target, tw = target.to(dev), tw.to(dev)
 
         def step():
@@ -362,7 +387,7 @@ def train_bench(a, rank, world, local, dev, dist):
     line = {"metric": f"images/sec {'RSGNet' if rsg else 'HRNet'}-W32 256x192 training step (fwd+bwd+Adam)", "value": round(imgs, 1), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": tag + "_train" + (" (backbone HIP, head PyTorch-ROCm operators)" if rsg else ""), "per_gpu_batch": batch, "global_batch": batch * world,
+            "config": {"workload": tag + "_train" + (" (backbone: the HIP training plan; head: autograd nodes on the library's kernels)" if rsg else ""), "per_gpu_batch": batch, "global_batch": batch * world,
                        "image": "256x192", "parallelism": f"dp{world} (bucketed RCCL all-reduce of the flat fp32 gradient buffer)",
                        "optimizer": "Adam lr 1e-3 (FusedAdam)", "loss_first_last": [round(vals[0], 6), round(vals[-1], 6)]},
             "roofline": {"bound": "mfma", "achieved": round(whole, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -372,35 +397,13 @@ def train_bench(a, rank, world, local, dev, dist):
     if not a.no_cpu_baseline and world == 1 and not rsg:
         cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))
         torch.set_num_threads(cores)
+        from oracle import train_step_oracle as tso        # the cpu_baseline leg: the only use of oracle/ on this path
         xs, ts, ws = x[:2].cpu(), target[:2].cpu(), tw[:2].cpu()
         t0 = time.time()
         tso.hrnet_train_step(sd, cfg, xs, ts, ws, dtype=torch.float32)
         dt = time.time() - t0
         line["cpu_baseline"] = {"value": round(2 / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
                                 "sample": f"1 forward+backward of batch 2 (no optimizer), torch {torch.__version__} CPU fp32"}
-        # the same operator graph through PyTorch-ROCm's own GPU kernels (MIOpen / rocBLAS): what the reference's
-        # `model.cuda()` training loop would run on this GPU (forward + loss + autograd backward, no optimizer)
-        try:
-            sdg = {k: v.to(dev) for k, v in sd.items()}
-            res = {}
-            for label, ctxm in (("fp32", None), ("autocast_bf16", torch.autocast("cuda", dtype=torch.bfloat16))):
-                def one():
-                    if ctxm is None:
-                        tso.hrnet_train_step(sdg, cfg, x, target, tw, dtype=torch.float32)
-                    else:
-                        with ctxm:
-                            tso.hrnet_train_step(sdg, cfg, x, target, tw, dtype=torch.float32)
-                one(); one()
-                torch.cuda.synchronize()
-                t0 = time.time()
-                for _ in range(3):
-                    one()
-                torch.cuda.synchronize()
-                res[label] = round(3 * batch / (time.time() - t0), 1)
-            line["torch_rocm_same_gpu"] = {"images_per_s": res, "what": "oracle's functional graph on torch.cuda ops (MIOpen convs, "
-                                           "eager), forward + loss + backward of the same batch, no optimizer"}
-        except Exception as e:      # never let the comparison leg break the bench line
-            line["torch_rocm_same_gpu"] = {"error": repr(e)[:200]}
     print(json.dumps(line), flush=True)
 
 
@@ -564,8 +567,10 @@ def main():
             z1.record()
         torch.cuda.synchronize()
         pair_us = sorted(z0.elapsed_time(z1) for z0, z1 in empty)[len(empty) // 2] * 1e3
-        per_op = [{"op": name, "us": round(max(0.0, sum(evs[r][i][0].elapsed_time(evs[r][i][1]) for r in range(reps)) / reps * 1e3
-                                               - pair_us), 2)}
+        # "us": what the event pair around the launch measured; "us_net": less the empty pair.  `roofline.frac` and the family
+        # table are priced on the RAW figure (rocprofv3's kernel durations sit between the two: profiles/, `rocprof` below)
+        raw = [sum(evs[r][i][0].elapsed_time(evs[r][i][1]) for r in range(reps)) / reps * 1e3 for i in range(len(plan.ops))]
+        per_op = [{"op": name, "us": round(raw[i], 2), "us_net": round(max(0.0, raw[i] - pair_us), 2)}
                   for i, (name, _) in enumerate(plan.ops)]
         fam = family_table(plan, per_op)
         if a.per_op:
@@ -604,17 +609,22 @@ def main():
                          "mfma_util": pmc_mfma_busy("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel", a.workload),
                          "algorithmic_mb_per_launch": dom.get("alg_mb_per_launch"),
                          "kernel": dom_name, "launches": dom["launches"], "kernel_us_per_step": dom["us"],
-                         "empty_event_pair_us": round(pair_us, 2),      # already taken off every launch's figure
+                         # an event pair with nothing between its records takes this long; NOT taken off the figures above
+                         # (`achieved_net_of_event_pair` shows the family figure with it taken off every launch)
+                         "empty_event_pair_us": round(pair_us, 2),
+                         "achieved_net_of_event_pair": round(dom["gflop"] / (max(dom["us"] - dom["launches"] * pair_us, 1e-3) / 1e3), 1),
+                         "rocprof": rocprof_kernel("chain_group_kernel" if "chain" in dom_name else "conv_igemm_kernel", a.workload, dom["gflop"], dom["launches"]),
                          # the kernel figures (achieved, frac, families) are a property of the kernels: measured with the
                          # launch list running alone on one stream; with 2 batches in flight (whole_step, value) kernels of
                          # both batches share the CUs and a profiler's per-kernel durations grow accordingly
-                         "kernel_figures_measured": "launch list alone on one stream (rocprofv3: profiles/r03m_*, --streams 1)",
+                         "kernel_figures_measured": "launch list alone on one stream (HIP event pair around every launch; rocprofv3 of the --streams 1 command: profiles/*_kernel_stats_one_stream.csv)",
                          "kernel_gflop_per_step": dom["gflop"],
                          "whole_step": {"achieved": round(whole, 1), "frac": round(whole / PEAK_TFLOPS, 4),
                                         "device_ms_per_step": round(dev_ms / a.steps, 4),
                                         "algorithmic_gflop_per_image": gflop},
                          "families": fam},
         }
+        mismatch = False
         if side is not None:
             # the same K steps issued one after the other on ONE stream (rounds 1-3 measured `value` this way)
             keep, side = side, None
@@ -645,6 +655,8 @@ def main():
                 line["value"], line["ms_per_step"] = world * line["single_stream"]["value"], line["single_stream"]["ms_per_step"]
                 line["roofline"]["whole_step"]["frac"] = line["single_stream"]["whole_step_frac"]
                 line["config"]["streams"] = 1
+                line["error"] = "forwards overlapping on two streams are not bit-identical to the one-stream forward"
+                mismatch = True
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.workload, cfg, sd, wh, gpu_model=model)
         if world == 1 and not (a.no_other_dtype or a.no_cpu_baseline) and not (a.flip_test or a.pipeline or a.from_host):
@@ -662,7 +674,14 @@ def main():
                                    "whole_step_frac": round(gflop * batch / (dev2 / a.steps) / PEAK_TFLOPS, 4)}
             if ref is not None and torch.is_tensor(out2):
                 line["other_dtype"]["max_abs_vs_" + a.dtype] = float((out2.float() - ref).abs().max())
+        from rsgnet_amd import build as _b
+        line["library"] = {"build": (_b.info().get("hash") or "")[:16], "path": os.path.relpath(hip_lib_path(), ROOT)}
+        print(_b.describe() if not os.environ.get("RSGNET_HIP_LIB") else f"library: {hip_lib_path()}", file=sys.stderr)
         print(json.dumps(line), flush=True)
+        if mismatch:            # a wrong result under overlap is a failure of the run, not a footnote of the line
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
     if dist is not None:
         dist.destroy_process_group()
 

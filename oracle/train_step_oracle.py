@@ -44,19 +44,7 @@ def joints_mse_loss(output: torch.Tensor, target: torch.Tensor, target_weight: t
     return loss / J
 
 
-def gaussian_targets(batch: int, joints: int, hw: Tuple[int, int], seed: int, sigma: float = 2.0):
-    """Seeded training targets shaped like the reference's (lib/dataset/JointsDataset.py generate_target, 'gaussian'):
-    one unnormalised Gaussian per joint and a 0/1 visibility weight [B,J,1].  Data for tests, not a restatement."""
-    r = np.random.RandomState(seed)
-    H, W = hw
-    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
-    t = np.zeros((batch, joints, H, W), np.float32)
-    w = (r.uniform(size=(batch, joints, 1)) > 0.2).astype(np.float32)
-    for b in range(batch):
-        for j in range(joints):
-            cx, cy = r.uniform(2, W - 3), r.uniform(2, H - 3)
-            t[b, j] = np.exp(-((xs - np.round(cx)) ** 2 + (ys - np.round(cy)) ** 2) / (2 * sigma ** 2)) * w[b, j, 0]
-    return torch.from_numpy(t), torch.from_numpy(w)
+from rsgnet_amd.weights import gaussian_targets, limb_targets  # noqa: E402,F401  (synthetic data, shared with bench.py --train)
 
 
 def hrnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor,
@@ -96,12 +84,6 @@ def relation_target_factor(target: torch.Tensor) -> torch.Tensor:
     b, h, w = person.shape
     person = F.interpolate(person.reshape(b, 1, h, w), scale_factor=1 / 2, mode="bilinear", align_corners=True)
     return person.reshape(b, -1)
-
-
-def limb_targets(batch: int, limbs: int, hw: Tuple[int, int], seed: int):
-    """Seeded stand-ins for the data set's limb maps (values in [0,1], a few blobs per channel).  Data, not a restatement."""
-    t, _ = gaussian_targets(batch, limbs, hw, seed, sigma=3.0)
-    return t.clamp(0, 1)
 
 
 def rsgnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, target, target_weight, all_ins_target,

@@ -27,13 +27,20 @@ struct StemArgs {
     int ldo3;
 };
 
+constexpr int stem_pitch_s(int CS, int C1) { return CS * 48 + ((C1 * 48 - CS * 48) % 256 + 256) % 256; }
+constexpr int stem_pitch_1(int C1, int TW2) { return C1 * 144 + ((TW2 * 72 - C1 * 144) % 128 + 128) % 128; }
+
 template <class DT, int TH2, int TW2>
 __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
     constexpr int R1 = 2 * TH2 + 1, C1 = 2 * TW2 + 1;      // conv1 positions held
     constexpr int RS = R1 + 1, CS = C1 + 1;                // s2d pixels staged
     constexpr int PSS = 48;                                // s2d pixel: 16 ch * 2 B + 16 pad
     constexpr int PS1 = 144;                               // conv1 pixel: 64 ch * 2 B + 16 pad
-    constexpr int RPS = CS * PSS, RP1 = C1 * PS1;
+    // Row pitches padded so that a 32-position group which wraps to the next row continues the same bank progression (as the
+    // chain and conv kernels do): conv1 walks the s2d window C1 positions per row (pitch == C1 * PSS mod 256), conv2 walks the
+    // conv1 window TW2 outputs per row, two conv1 rows apart (2 * pitch == TW2 * PS1 mod 256).  Dense pitches cost 42 % of the
+    // LDS cycles in bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r03p_sq_summary.json).
+    constexpr int RPS = stem_pitch_s(CS, C1), RP1 = stem_pitch_1(C1, TW2);
     // conv2 has stride 2: the conv1 window keeps its even and odd columns in two halves of a row (slot = (c & 1) * HW1 +
     // c / 2), so that consecutive output pixels read consecutive slots (no 2-way LDS bank conflict; cf. conv_body `deint`)
     constexpr int HW1 = (C1 + 1) / 2;
@@ -268,7 +275,7 @@ static int stem_launch(const void* xs, const float* x_nchw_f32, const void* w1_p
     a.out = (char*)out16; a.B = batch; a.H1 = h / 2; a.W1 = w / 2; a.H2 = h / 4; a.W2 = w / 4; a.ldo = out_ld;
     a.w3 = (const uint4*)w3_packed; a.b3 = bias3; a.out3 = (char*)out3; a.ldo3 = out3_ld;
     a.tiles_x = ceil_div(a.W2, TW2); a.tiles_y = ceil_div(a.H2, TH2);
-    const int lds = (2 * TH2 + 2) * (2 * TW2 + 2) * 48 + (2 * TH2 + 1) * (2 * TW2 + 1) * 144;
+    const int lds = (2 * TH2 + 2) * stem_pitch_s(2 * TW2 + 2, 2 * TW2 + 1) + (2 * TH2 + 1) * stem_pitch_1(2 * TW2 + 1, TW2);
     const dim3 grid(batch * a.tiles_x * a.tiles_y);
     if (dtype == RSG_BF16) RSG_LAUNCH((stem_kernel<BF16, TH2, TW2>), grid, dim3(256), lds, (hipStream_t)stream, a);
     else RSG_LAUNCH((stem_kernel<F16, TH2, TW2>), grid, dim3(256), lds, (hipStream_t)stream, a);

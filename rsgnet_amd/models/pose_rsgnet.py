@@ -158,8 +158,8 @@ class RSGNet(HipPoseModule):
         from ..plan import RSGNetPlan
         return RSGNetPlan(self, batch, device, self.compute_dtype)
 
-    #: training mode: backbone on the HIP training plan, head on PyTorch-ROCm operators with autograd
-    #: (rsgnet_amd/train_rsgnet.py: interim until the head's HIP kernels have a backward)
+    #: training mode: backbone on the HIP training plan, head as autograd nodes whose forward and backward are
+    #: the library's kernels (rsgnet_amd/train_rsgnet.py, rsgnet_amd/train_ops.py)
     supports_training = True
     train_head_on_torch = True
     train_feat_nhwc16 = True          # the backbone's output map and its gradient cross the boundary as NHWC bf16

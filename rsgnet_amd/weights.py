@@ -132,3 +132,24 @@ def synth_input(batch: int, image_wh, seed: int = 0) -> torch.Tensor:
     """x ~ N(0,1) fp32 NCHW — the statistics of an ImageNet-normalised crop (tools/test.py:105-107)."""
     r = np.random.RandomState(1000 + seed)
     return torch.from_numpy(r.standard_normal((batch, 3, image_wh[1], image_wh[0])).astype(np.float32))
+
+
+def gaussian_targets(batch: int, joints: int, hw: tuple, seed: int, sigma: float = 2.0):
+    """Seeded training targets shaped like the reference's (lib/dataset/JointsDataset.py generate_target, 'gaussian'):
+    one unnormalised Gaussian per joint and a 0/1 visibility weight [B,J,1].  Data for tests, not a restatement."""
+    r = np.random.RandomState(seed)
+    H, W = hw
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    t = np.zeros((batch, joints, H, W), np.float32)
+    w = (r.uniform(size=(batch, joints, 1)) > 0.2).astype(np.float32)
+    for b in range(batch):
+        for j in range(joints):
+            cx, cy = r.uniform(2, W - 3), r.uniform(2, H - 3)
+            t[b, j] = np.exp(-((xs - np.round(cx)) ** 2 + (ys - np.round(cy)) ** 2) / (2 * sigma ** 2)) * w[b, j, 0]
+    return torch.from_numpy(t), torch.from_numpy(w)
+
+
+def limb_targets(batch: int, limbs: int, hw: tuple, seed: int):
+    """Seeded stand-ins for the data set's limb maps (values in [0,1], a few blobs per channel).  Data, not a restatement."""
+    t, _ = gaussian_targets(batch, limbs, hw, seed, sigma=3.0)
+    return t.clamp(0, 1)
