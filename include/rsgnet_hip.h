@@ -319,10 +319,11 @@ int rsg_decode_heatmaps(const float* heat, const float* center, const float* sca
  * values g = conv1x1(x)+b split as g = hi + lo, E out: fp32 [batch,S,C].  C must be 32 or 48. */
 int rsg_trp_attention(const void* x, int32_t ld_x, const void* gT_hi, const void* gT_lo, float* e_out,
                       int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
-/* g projection in transposed, split form: gT_{hi,lo}[b,c,s] from x [batch,S,ld_x] with fp32 weights
- * w[C][C], bias[C] (association.py:288-289) */
+/* g projection (association.py:288-289) from x [batch,S,ld_x] with fp32 weights w[C][C], bias[C]: gT_hi[b,c,s] transposed,
+ * the keys of every 16-block in the order [0-3, 8-11, 4-7, 12-15]; g_rows (or NULL): the same values as rows [batch,S,C]
+ * (what rsg_trp_backward reads) */
 int rsg_trp_project_g(const void* x, int32_t ld_x, const float* w, const float* bias, void* gT_hi,
-                      void* gT_lo, int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
+                      void* g_rows, int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
 /* W: conv1x1(+bias) then GroupNorm(8,C) on E, written 16-bit into out[b,s, 0:C] of a buffer with
  * channel stride out_ld (association.py:298-300).  workspace: rsg_trp_tail_workspace_bytes() of device
  * memory (the fp32 projection and the per-workgroup GroupNorm partials).  S % 256 == 0. */
@@ -361,6 +362,23 @@ int rsg_trp_tail_backward(const void* dout, int32_t ld, const void* fwd_workspac
 int rsg_trp_backward(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
                      const void* xT, const void* deT, const float* p, const float* coef, float* dx, float* dg,
                      int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
+/* The same with the relation target given as the reference's training loop builds it (/root/reference/lib/core/function.py:
+ * 261-272: a [batch,S,S] fp32 tensor, which is p p^T there): read tile by tile, 128 contiguous bytes per lane group and
+ * accumulator register; a lane reads T_ji for T_ij, i.e. the target is taken as SYMMETRIC (for an asymmetric one
+ * dA + dA^T would need (T_ij + T_ji) / 2).  rsg_trp_relation_mse_dense: the forward value, exact for any target. */
+int rsg_trp_backward_dense(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
+                           const void* xT, const void* deT, const float* target, const float* coef, float* dx, float* dg,
+                           int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
+int rsg_trp_relation_mse_dense(const void* x, int32_t ld_x, const float* target, float* mse, int32_t batch,
+                               int32_t S, int32_t C, int32_t dtype, void* stream);
+/* fp32 row products of the training head (autograd of the TRP's 1x1 projections, association.py:288-289, 298), fixed
+ * summation order.  rsg_rows_project_f32: out[n,j] (+)= sum_k a[n,k] m[k,j] (C = 32 or 48; m is [C,C]).
+ * rsg_rows_gram_f32: gram[i,j] = sum_n a[n,i] b[n,j] and, when colsum is not NULL, colsum[i] = sum_n a[n,i] (C = 32);
+ * workspace: rsg_rows_gram_workspace_bytes(C) bytes of device memory. */
+int rsg_rows_project_f32(const float* a, const float* m, float* out, int64_t rows, int32_t C, int32_t accumulate, void* stream);
+size_t rsg_rows_gram_workspace_bytes(int32_t C);
+int rsg_rows_gram_f32(const float* a, const float* b, float* gram, float* colsum, int64_t rows, int32_t C, void* workspace,
+                      void* stream);
 /* optional materialisation of relation_score [batch,S,S] fp32 (association.py:294-295) */
 int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S, int32_t C,
                    int32_t dtype, void* stream);

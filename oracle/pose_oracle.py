@@ -88,6 +88,10 @@ class Ctx:
         # from ANOTHER implementation's activations; a ReLU whose key is present multiplies by that map instead of
         # deciding for itself, so both implementations differentiate the same piecewise-linear function
         self.relu_masks = relu_masks
+        # fault injection for the SENSITIVITY tests of the training parity bars (tests/test_train_step.py): forward values
+        # unchanged, one backward term missing.  "<module>.fuse.<i>.<j>": that addend of a fuse sum passes no gradient;
+        # "<BatchNorm name>": the batch variance passes no gradient (one of the three terms of BatchNorm's backward).
+        self.drop_grad: set = set()
 
     def relu(self, y: torch.Tensor, key: Optional[str]) -> torch.Tensor:
         if self.relu_masks is not None and key is not None and key in self.relu_masks:
@@ -114,6 +118,8 @@ def _bn_coeffs(ctx: Ctx, name: str, x: Optional[torch.Tensor]):
         n = x.numel() // x.shape[1]
         mean = x.mean(dim=dims)
         var_b = x.var(dim=dims, unbiased=False)
+        if name in ctx.drop_grad:
+            var_b = var_b.detach()
         ctx.sd[name + ".running_mean"] = mean.to(torch.float32)
         ctx.sd[name + ".running_var"] = (var_b * (n / max(n - 1, 1))).to(torch.float32)
         inv = torch.rsqrt(var_b + BN_EPS)  # training normalises with the biased variance
@@ -213,6 +219,8 @@ def hr_module(ctx: Ctx, xs: List[torch.Tensor], pre: str, n_out: int):
                 for k in range(i - j):
                     t = conv_unit(ctx, t, f"{fl}.{k}.0", f"{fl}.{k}.1", stride=2,
                                   relu=(k != i - j - 1))
+            if f"{pre}.fuse.{i}.{j}" in ctx.drop_grad:
+                t = t.detach()
             y = t if y is None else y + t
         outs.append(ctx.store(ctx.relu(y, f"{pre}.fuse.{i}")))
     return outs

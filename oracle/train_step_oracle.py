@@ -48,8 +48,9 @@ from rsgnet_amd.weights import gaussian_targets, limb_targets  # noqa: E402,F401
 
 
 def hrnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, target: torch.Tensor, target_weight: torch.Tensor,
-                     use_target_weight: bool = True, dtype=torch.float64, relu_masks=None):
+                     use_target_weight: bool = True, dtype=torch.float64, relu_masks=None, drop_grad=()):
     """One forward/backward of pose_hrnet in train() mode.
+    drop_grad: fault injection for the sensitivity test of the parity bars (pose_oracle.Ctx.drop_grad).
     Returns (loss, heatmaps, {param name: gradient}, {buffer name: running statistic after the step}).
     relu_masks: teacher forcing (pose_oracle.Ctx.relu_masks): every ReLU listed there takes its 0/1 decisions from the
     given map, so the gradient is that of the SAME piecewise-linear function another implementation differentiated."""
@@ -61,6 +62,7 @@ def hrnet_train_step(sd: Mapping[str, torch.Tensor], cfg, x: torch.Tensor, targe
         work[k] = t
     old = {k: v.detach().clone().double() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}
     ctx = po.Ctx(work, dtype=dtype, calibrate=True, relu_masks=relu_masks)   # calibrate = batch statistics (training-mode BatchNorm)
+    ctx.drop_grad = set(drop_grad)
     ctx.sd = dict(work)                                       # the walk overwrites running stats; keep `work` intact
     ys = po.backbone(ctx, x.to(dtype), cfg)
     w, b = ctx.p("final_layer.weight"), ctx.p("final_layer.bias")

@@ -18,6 +18,7 @@
 // E is kept in fp32 (it is ~S times larger than its variation across positions, which is what the
 // GroupNorm after it keeps).
 #include "common.h"
+#include <algorithm>
 
 enum { TRP_ATTN = 0, TRP_SCORES = 1, TRP_MSE = 2 };
 
@@ -32,7 +33,8 @@ struct TrpArgs {
     const char* gT;      // [B,C,S] 16-bit, key-permuted
     float* e;            // [B,S,C] fp32            (ATTN)
     float* scores;       // [B,S,S] fp32            (SCORES)
-    const float* p;      // [B,S] fp32              (MSE)
+    const float* p;      // [B,S] fp32              (MSE: factor of the target, T = p p^T)
+    const float* t;      // [B,S,S] fp32            (MSE: the target itself, read tile by tile; p is null then)
     float* mse;          // [B] fp32, pre-zeroed    (MSE)
     int S, ldx;
     float inv_ss;
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[m][r] = 0.f;
     float pq = 0.f, part = 0.f;
-    if (MODE == TRP_MSE) pq = a.p[(size_t)b * a.S + q0 + n];
+    if (MODE == TRP_MSE && a.p) pq = a.p[(size_t)b * a.S + q0 + n];
 
     // K / G^T tiles of 32 keys are shared by the 4 waves of the workgroup: every thread fetches 16-byte
     // pieces (coalesced) into a double-buffered LDS tile; per-wave scattered global loads of the same
@@ -141,7 +143,10 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = j0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                const float d = pq * a.p[(size_t)b * a.S + key] - pr[r];
+                // the sum over all (i, j) takes every element of T once whichever of T_ij / T_ji a lane reads: row `key`,
+                // columns q0 .. q0 + 31 are 128 contiguous bytes per (r, hh)
+                const float tv = a.t ? a.t[((size_t)b * a.S + key) * a.S + q0 + n] : pq * a.p[(size_t)b * a.S + key];
+                const float d = tv - pr[r];
                 part += d * d;
             }
         }
@@ -220,17 +225,28 @@ extern "C" int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_
     return trp_launch<TRP_SCORES>(a, batch, C, dtype, stream);
 }
 
-extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, int32_t batch,
-                                    int32_t S, int32_t C, int32_t dtype, void* stream) {
+static int trp_mse(const void* x, int32_t ld_x, const float* p, const float* t, float* mse, int32_t batch,
+                   int32_t S, int32_t C, int32_t dtype, void* stream) {
     if (trp_check(x, ld_x, batch, S, C)) return 1;
-    if (!p || !mse) RSG_FAIL("trp_relation_mse: null pointer");
+    if ((!p && !t) || !mse) RSG_FAIL("trp_relation_mse: null pointer");
     if (hipMemsetAsync(mse, 0, sizeof(float) * batch, (hipStream_t)stream) != hipSuccess)
         RSG_FAIL("trp_relation_mse: memset failed");
     TrpArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = (const char*)x; a.p = p; a.mse = mse; a.S = S; a.ldx = ld_x;
+    a.x = (const char*)x; a.p = p; a.t = t; a.mse = mse; a.S = S; a.ldx = ld_x;
     a.inv_ss = 1.0f / ((float)S * (float)S);
     return trp_launch<TRP_MSE>(a, batch, C, dtype, stream);
+}
+
+extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, int32_t batch,
+                                    int32_t S, int32_t C, int32_t dtype, void* stream) {
+    return trp_mse(x, ld_x, p, nullptr, mse, batch, S, C, dtype, stream);
+}
+
+extern "C" int rsg_trp_relation_mse_dense(const void* x, int32_t ld_x, const float* target, float* mse, int32_t batch,
+                                          int32_t S, int32_t C, int32_t dtype, void* stream) {
+    if (!target || ((uintptr_t)target & 3)) RSG_FAIL("trp_relation_mse_dense: the target [batch,S,S] fp32");
+    return trp_mse(x, ld_x, nullptr, target, mse, batch, S, C, dtype, stream);
 }
 
 // ---- TRP backward (training; pose_rsgnet.py:987,1014-1018 under autograd) ---------------------------------------
@@ -247,7 +263,8 @@ extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p,
 struct TrpBwdArgs {
     const char *x, *g, *de;        // [B,S,ld*] 16-bit rows
     const char *xT, *deT;          // [B,C,S] 16-bit, key-permuted
-    const float* p;                // [B,S] factor of the relation target, or null (no relation loss)
+    const float* p;                // [B,S] factor of the relation target, or null
+    const float* t;                // [B,S,S] the relation target itself (symmetric), or null; neither: no relation loss
     const float* coef;             // [B]: dL/dmse_b * 2 / S^2
     float *dx, *dg;                // [B,S,C] fp32
     int S, ldx, ldg, ldd;
@@ -278,7 +295,8 @@ __global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) ydx[r] = ydg[r] = 0.f;
     const float pq = a.p ? a.p[boff + q0 + n] : 0.f;
-    const float c2 = a.p ? 2.f * a.coef[b] : 0.f;
+    const float c2 = (a.p || a.t) ? 2.f * a.coef[b] : 0.f;
+    const float* const trow = a.t ? a.t + boff * a.S + q0 + n : nullptr;      // + key * S: row `key`, this lane's query column
 
     __shared__ uint4 tk[2][KT][3][32 * RSK];          // X, G, dE rows of the key tile
     __shared__ uint4 tg[2][KT][2][C * 5];             // X^T, dE^T of the key tile
@@ -306,7 +324,7 @@ __global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
         tg[buf][su][1][grow * 5 + gpiece] = v4;
         if (threadIdx.x < 32 * KT) tp[buf][threadIdx.x >> 5][threadIdx.x & 31] = pv;
     };
-    auto do_tile = [&](const uint4 (&tkb)[3][32 * RSK], const uint4 (&tgb)[2][C * 5], const float (&pk)[32]) {
+    auto do_tile = [&](const int j0, const uint4 (&tkb)[3][32 * RSK], const uint4 (&tgb)[2][C * 5], const float (&pk)[32]) {
         f32x16 xa, x1, x2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) xa[r] = x1[r] = x2[r] = 0.f;
@@ -321,7 +339,10 @@ __global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float R = sigmoid_f32(xa[r]);
-            const float t = x1[r] + x2[r] + c2 * (R - pq * pk[(r & 3) + 8 * (r >> 2) + 4 * hh]);
+            const int kk = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            // dense target: T_ji for T_ij (the reference's target p p^T is symmetric; dA + dA^T takes (T_ij + T_ji) / 2)
+            const float tv = trow ? trow[(size_t)(j0 + kk) * a.S] : pq * pk[kk];
+            const float t = x1[r] + x2[r] + c2 * (R - tv);
             pr[r] = R;
             mr[r] = R * (1.f - R) * t;
         }
@@ -342,7 +363,7 @@ __global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
         const bool more = t + 1 < nstages;
         if (more) fetch((t + 1) * 32 * KT);
 #pragma unroll
-        for (int u = 0; u < KT; ++u) do_tile(tk[t & 1][u], tg[t & 1][u], tp[t & 1][u]);
+        for (int u = 0; u < KT; ++u) do_tile((t * KT + u) * 32, tk[t & 1][u], tg[t & 1][u], tp[t & 1][u]);
         if (more) stash((t + 1) & 1);
         __syncthreads();
     }
@@ -356,16 +377,33 @@ __global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
     }
 }
 
+static int trp_backward(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
+                        const void* xT, const void* deT, const float* p, const float* t, const float* coef, float* dx, float* dg,
+                        int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
+
 extern "C" int rsg_trp_backward(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
                                 const void* xT, const void* deT, const float* p, const float* coef, float* dx, float* dg,
                                 int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream) {
+    return trp_backward(x, ld_x, g, ld_g, de, ld_de, xT, deT, p, nullptr, coef, dx, dg, batch, S, C, dtype, stream);
+}
+
+extern "C" int rsg_trp_backward_dense(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
+                                      const void* xT, const void* deT, const float* target, const float* coef, float* dx,
+                                      float* dg, int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream) {
+    if (!target || ((uintptr_t)target & 3)) RSG_FAIL("trp_backward_dense: the target [batch,S,S] fp32");
+    return trp_backward(x, ld_x, g, ld_g, de, ld_de, xT, deT, nullptr, target, coef, dx, dg, batch, S, C, dtype, stream);
+}
+
+static int trp_backward(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
+                        const void* xT, const void* deT, const float* p, const float* t, const float* coef, float* dx, float* dg,
+                        int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream) {
     if (trp_check(x, ld_x, batch, S, C) || trp_check(g, ld_g, batch, S, C) || trp_check(de, ld_de, batch, S, C)) return 1;
     if (C != 32) RSG_FAIL("trp_backward: C=%d (the training head is built for 32 channels)", C);
-    if (!xT || !deT || !dx || !dg || (p && !coef)) RSG_FAIL("trp_backward: null pointer");
+    if (!xT || !deT || !dx || !dg || ((p || t) && !coef)) RSG_FAIL("trp_backward: null pointer");
     if ((((uintptr_t)xT | (uintptr_t)deT | (uintptr_t)dx | (uintptr_t)dg) & 15)) RSG_FAIL("trp_backward: pointers must be 16-byte aligned");
     TrpBwdArgs a;
     a.x = (const char*)x; a.g = (const char*)g; a.de = (const char*)de; a.xT = (const char*)xT; a.deT = (const char*)deT;
-    a.p = p; a.coef = coef; a.dx = dx; a.dg = dg; a.S = S; a.ldx = ld_x; a.ldg = ld_g; a.ldd = ld_de;
+    a.p = p; a.t = t; a.coef = coef; a.dx = dx; a.dg = dg; a.S = S; a.ldx = ld_x; a.ldg = ld_g; a.ldd = ld_de;
     dim3 grid(S / 128, batch);
     if (dtype == RSG_BF16) RSG_LAUNCH((trp_backward_kernel<BF16, 32>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else RSG_LAUNCH((trp_backward_kernel<F16, 32>), grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -378,7 +416,7 @@ template <class DT, int C>
 __global__ void __launch_bounds__(256) trp_project_g_kernel(const char* __restrict__ x, int ldx,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
-                                                           char* __restrict__ gT, int S, long total) {
+                                                           char* __restrict__ gT, char* __restrict__ grows, int S, long total) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const long b = i / S;
@@ -401,19 +439,20 @@ __global__ void __launch_bounds__(256) trp_project_g_kernel(const char* __restri
 #pragma unroll
         for (int ci = 0; ci < C; ++ci) acc = fmaf(w[co * C + ci], xv[ci], acc);
         go[(size_t)co * S] = (typename DT::elem)acc;
+        if (grows) reinterpret_cast<typename DT::elem*>(grows)[i * C + co] = (typename DT::elem)acc;    // rows [B,S,C] (training)
     }
 }
 
 extern "C" int rsg_trp_project_g(const void* x, int32_t ld_x, const float* w, const float* bias, void* gT_hi,
-                                 void* gT_lo, int32_t batch, int32_t S, int32_t C, int32_t dtype,
+                                 void* g_rows, int32_t batch, int32_t S, int32_t C, int32_t dtype,
                                  void* stream) {
     if (trp_check(x, ld_x, batch, S, C)) return 1;
     if (!w || !bias || !gT_hi) RSG_FAIL("trp_project_g: null pointer");
-    if (gT_lo) RSG_FAIL("trp_project_g: split values are not built; pass gT_lo = NULL");
+    if ((uintptr_t)g_rows & 15) RSG_FAIL("trp_project_g: g_rows alignment");
     const long total = (long)batch * S;
     const int grid = (int)((total + 255) / 256);
 #define RSG_PG(DT_, C_) RSG_LAUNCH((trp_project_g_kernel<DT_, C_>), dim3(grid), dim3(256), 0, (hipStream_t)stream, \
-                                   (const char*)x, ld_x, w, bias, (char*)gT_hi, S, total)
+                                   (const char*)x, ld_x, w, bias, (char*)gT_hi, (char*)g_rows, S, total)
     if (dtype == RSG_BF16) { if (C == 32) RSG_PG(BF16, 32); else RSG_PG(BF16, 48); }
     else { if (C == 32) RSG_PG(F16, 32); else RSG_PG(F16, 48); }
 #undef RSG_PG
@@ -719,5 +758,111 @@ extern "C" int rsg_trp_tail_backward(const void* dout, int32_t ld, const void* f
         RSG_LAUNCH((trp_tail_bwd_apply_kernel<F16, 32>), grid, dim3(256), 0, (hipStream_t)stream, (const char*)dout, ld, y, part, gn_gamma, w, (const float*)pg, dy, de, S);
     }
     RSG_CHECK_LAUNCH("trp_tail_backward(apply)");
+    return 0;
+}
+
+// ---- small fp32 row products of the training head (autograd of the TRP's 1x1 projections, association.py:288-289,298) ----
+// rows_project:  out[n, j] (+)= sum_k a[n, k] m[k, j]      (data gradient of a 1x1 projection: dx += dg Wg)
+// rows_gram:     gram[i, j] = sum_n a[n, i] b[n, j],  colsum[i] = sum_n a[n, i]   (its weight and bias gradients)
+// One thread per row / fixed-order two-stage sums: no atomics, identical bits from run to run.  C = 32 or 48.
+template <int C>
+__global__ void __launch_bounds__(256) rows_project_kernel(const float* __restrict__ a, const float* __restrict__ m,
+                                                          float* __restrict__ out, long rows, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    float av[C];
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(a + i * C + 4 * k);
+        av[4 * k] = v.x; av[4 * k + 1] = v.y; av[4 * k + 2] = v.z; av[4 * k + 3] = v.w;
+    }
+#pragma unroll 4
+    for (int j4 = 0; j4 < C / 4; ++j4) {
+        float4 o = accumulate ? *reinterpret_cast<const float4*>(out + i * C + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < C; ++k) {                      // m[k][j]: uniform addresses (scalar loads)
+            o.x = fmaf(av[k], m[k * C + 4 * j4], o.x);
+            o.y = fmaf(av[k], m[k * C + 4 * j4 + 1], o.y);
+            o.z = fmaf(av[k], m[k * C + 4 * j4 + 2], o.z);
+            o.w = fmaf(av[k], m[k * C + 4 * j4 + 3], o.w);
+        }
+        *reinterpret_cast<float4*>(out + i * C + 4 * j4) = o;
+    }
+}
+
+extern "C" int rsg_rows_project_f32(const float* a, const float* m, float* out, int64_t rows, int32_t C, int32_t accumulate,
+                                    void* stream) {
+    if (!a || !m || !out || rows < 1) RSG_FAIL("rows_project: bad arguments");
+    if (C != 32 && C != 48) RSG_FAIL("rows_project: C=%d (32 and 48 are built)", C);
+    if (((uintptr_t)a | (uintptr_t)out) & 15) RSG_FAIL("rows_project: alignment");
+    const dim3 grid((unsigned)((rows + 255) / 256));
+    if (C == 32) RSG_LAUNCH((rows_project_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, a, m, out, (long)rows, accumulate);
+    else RSG_LAUNCH((rows_project_kernel<48>), grid, dim3(256), 0, (hipStream_t)stream, a, m, out, (long)rows, accumulate);
+    RSG_CHECK_LAUNCH("rows_project");
+    return 0;
+}
+
+#define RSG_GRAM_BLOCKS 256
+// block k sums its contiguous share of the rows: thread (i = tid / 8, jg = tid % 8) keeps gram[i][jg * C/8 .. + C/8)
+template <int C>
+__global__ void __launch_bounds__(256) rows_gram_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               float* __restrict__ part, long rows) {
+    constexpr int JW = C / 8, TR = 64;                    // columns per thread; rows staged per round
+    __shared__ float sa[TR][C + 1], sb[TR][C + 1];
+    const int tid = threadIdx.x, i = tid >> 3, jg = tid & 7;
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+    float acc[JW], cs = 0.f;
+#pragma unroll
+    for (int j = 0; j < JW; ++j) acc[j] = 0.f;
+    for (long base = r0; base < r1; base += TR) {
+        const int nr = (int)min((long)TR, r1 - base);
+        for (int e = tid; e < TR * C; e += 256) {
+            const int r = e / C, c = e - r * C;
+            sa[r][c] = r < nr ? a[(base + r) * C + c] : 0.f;
+            sb[r][c] = r < nr ? b[(base + r) * C + c] : 0.f;
+        }
+        __syncthreads();
+        if (i < C) {
+#pragma unroll 8
+            for (int r = 0; r < TR; ++r) {
+                const float av = sa[r][i];
+#pragma unroll
+                for (int j = 0; j < JW; ++j) acc[j] = fmaf(av, sb[r][jg * JW + j], acc[j]);
+                if (jg == 0) cs += av;
+            }
+        }
+        __syncthreads();
+    }
+    if (i < C) {
+        float* o = part + (size_t)blockIdx.x * (C * C + C);
+#pragma unroll
+        for (int j = 0; j < JW; ++j) o[i * C + jg * JW + j] = acc[j];
+        if (jg == 0) o[C * C + i] = cs;
+    }
+}
+
+__global__ void __launch_bounds__(256) rows_gram_sum_kernel(const float* __restrict__ part, float* __restrict__ gram,
+                                                           float* __restrict__ colsum, int C, int nblocks) {
+    const int e = blockIdx.x * 256 + threadIdx.x, n = C * C + C;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < nblocks; ++k) s += (double)part[(size_t)k * n + e];     // fixed order
+    if (e < C * C) gram[e] = (float)s;
+    else if (colsum) colsum[e - C * C] = (float)s;
+}
+
+extern "C" size_t rsg_rows_gram_workspace_bytes(int32_t C) { return (size_t)RSG_GRAM_BLOCKS * (C * C + C) * sizeof(float); }
+
+extern "C" int rsg_rows_gram_f32(const float* a, const float* b, float* gram, float* colsum, int64_t rows, int32_t C,
+                                 void* workspace, void* stream) {
+    if (!a || !b || !gram || !workspace || rows < 1) RSG_FAIL("rows_gram: bad arguments");
+    if (C != 32) RSG_FAIL("rows_gram: C=%d (32 is built: 256 threads = 32 rows x 8 column groups)", C);
+    const int nb = (int)std::min<int64_t>(RSG_GRAM_BLOCKS, (rows + 63) / 64);
+    RSG_LAUNCH((rows_gram_partial_kernel<32>), dim3(nb), dim3(256), 0, (hipStream_t)stream, a, b, (float*)workspace, (long)rows);
+    RSG_CHECK_LAUNCH("rows_gram partial");
+    RSG_LAUNCH(rows_gram_sum_kernel, dim3((C * C + C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, gram,
+               colsum, (int)C, nb);
+    RSG_CHECK_LAUNCH("rows_gram sum");
     return 0;
 }

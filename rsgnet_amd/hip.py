@@ -162,6 +162,11 @@ SYMBOLS = {
     "rsg_wgrad_tune": (None, [_i, _i, _i, _i, _i]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
     "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_relation_mse_dense": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_backward_dense": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_rows_project_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i, _i, _vp]),
+    "rsg_rows_gram_workspace_bytes": (C.c_size_t, [_i]),
+    "rsg_rows_gram_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _i, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -386,15 +386,30 @@ def conv1x1_out(owner: nn.Module, key: str, x16: torch.Tensor, w: torch.Tensor, 
     return Conv1x1Out.apply(x16, w.reshape(J, I, 1, 1), bias, st)
 
 
-def rows_gram(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a^T b for two tall fp32 row matrices [N,ca], [N,cb] (N ~ 1e5, c = 32): as ONE GEMM this shape runs on a single
-    workgroup's worth of tiles (283 us measured); as a batched product over row chunks with a fixed-order sum of the chunk
-    results it takes a few microseconds."""
-    n = a.shape[0]
-    ch = 1024
-    while n % ch:
-        ch //= 2
-    return torch.bmm(a.reshape(n // ch, ch, -1).transpose(1, 2), b.reshape(n // ch, ch, -1)).sum(0)
+def rows_gram(a: torch.Tensor, b: torch.Tensor, with_colsum: bool = False):
+    """a^T b for two tall fp32 row matrices [N,32] (N ~ 1e5) on rsg_rows_gram_f32: per-block partial sums over contiguous
+    row ranges, summed in block order by a second launch (fixed order, no atomics).  with_colsum: also sum_n a[n,:]."""
+    lib = hip.lib()
+    n, c = a.shape
+    a, b = a.contiguous(), b.contiguous()
+    gram = torch.empty(c, c, dtype=torch.float32, device=a.device)
+    cs = torch.empty(c, dtype=torch.float32, device=a.device) if with_colsum else None
+    ws = torch.empty(lib.rsg_rows_gram_workspace_bytes(c), dtype=torch.uint8, device=a.device)
+    hip.check(lib.rsg_rows_gram_f32(a.data_ptr(), b.data_ptr(), gram.data_ptr(), cs.data_ptr() if with_colsum else None,
+                                    n, c, ws.data_ptr(), _stream(a)), "rows_gram")
+    return (gram, cs) if with_colsum else gram
+
+
+def rows_project(a: torch.Tensor, m: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a [N,C] @ m [C,C] in fp32 on rsg_rows_project_f32, added to `out` when given."""
+    lib = hip.lib()
+    n, c = a.shape
+    a, m = a.contiguous(), m.contiguous()
+    acc = out is not None
+    if out is None:
+        out = torch.empty_like(a)
+    hip.check(lib.rsg_rows_project_f32(a.data_ptr(), m.data_ptr(), out.data_ptr(), n, c, int(acc), _stream(a)), "rows_project")
+    return out
 
 
 class GroupNormTail(torch.autograd.Function):
@@ -427,9 +442,8 @@ class GroupNormTail(torch.autograd.Function):
         hip.check(lib.rsg_trp_tail_backward(dout.data_ptr(), c, ws.data_ptr(), w32.data_ptr(), g32.data_ptr(), dy.data_ptr(),
                                             de.data_ptr(), part.data_ptr(), b, s, c, BF16, _stream(e32)), "trp_tail_backward")
         pc = part[:b * (s // 256) * 2 * c].reshape(-1, 2, c).sum(0)        # [2,C]: dgamma, dbeta
-        dy2 = dy.reshape(-1, c)
-        dw = rows_gram(dy2, e32.reshape(-1, c)).reshape(c, c, 1, 1)
-        return de, dw, dy2.sum(0), pc[0], pc[1]
+        dw, dbias = rows_gram(dy.reshape(-1, c), e32.reshape(-1, c), with_colsum=True)
+        return de, dw.reshape(c, c, 1, 1), dbias, pc[0], pc[1]
 
 
 class Bilinear2x(torch.autograd.Function):

@@ -54,11 +54,13 @@ def _keys_transposed(rows: torch.Tensor) -> torch.Tensor:
 
 
 class TrpRelation(torch.autograd.Function):
-    """E = sigmoid(X X^T) (X Wg^T + bg) and mse_b = mean_ij (p_i p_j - sigmoid(X X^T)_ij)^2 on the HIP kernels, bf16
-    operands and fp32 accumulation as the backbone's training plan.  x: rows [B,S,C] (bf16, or fp32 rounded here);
-    returns E [B,S,C] fp32 and mse [B].  forward: rsg_trp_project_g + rsg_trp_attention + rsg_trp_relation_mse;
-    backward: rsg_trp_backward (sigmoid recomputed per tile) and three small fp32 matmuls for the g projection's own
-    gradients."""
+    """E = sigmoid(X X^T) (X Wg^T + bg) and mse_b = mean_ij (T_ij - sigmoid(X X^T)_ij)^2 on the HIP kernels, bf16
+    operands and fp32 accumulation as the backbone's training plan.  x: rows [B,S,C] (bf16, or fp32 rounded here); the
+    relation target either as its factor p [B,S] (T = p p^T, rsgnet_amd.loss.relation_target_vector) or as the [B,S,S] tensor
+    the reference's loop builds (function.py:261-272), which the kernels read tile by tile.  Returns E [B,S,C] fp32 and
+    mse [B].  forward: rsg_trp_project_g (values transposed for the attention and as rows for the backward) +
+    rsg_trp_attention + rsg_trp_relation_mse[_dense]; backward: rsg_trp_backward[_dense] (sigmoid recomputed per tile) and
+    the g projection's own gradients on rsg_rows_project_f32 / rsg_rows_gram_f32."""
 
     @staticmethod
     def forward(ctx, x, wg, bg, p):
@@ -72,7 +74,8 @@ class TrpRelation(torch.autograd.Function):
         w32 = wg.detach().reshape(c, c).float().contiguous()
         b32 = bg.detach().float().contiguous()
         g_hi = torch.empty(b, c, s, dtype=torch.bfloat16, device=x.device)
-        hip.check(lib.rsg_trp_project_g(x16.data_ptr(), c, w32.data_ptr(), b32.data_ptr(), g_hi.data_ptr(), None,
+        g16 = torch.empty(b, s, c, dtype=torch.bfloat16, device=x.device)
+        hip.check(lib.rsg_trp_project_g(x16.data_ptr(), c, w32.data_ptr(), b32.data_ptr(), g_hi.data_ptr(), g16.data_ptr(),
                                         b, s, c, hip.RSG_BF16, st), "trp_project_g")
         e = torch.empty(b, s, c, dtype=torch.float32, device=x.device)
         hip.check(lib.rsg_trp_attention(x16.data_ptr(), c, g_hi.data_ptr(), None, e.data_ptr(), b, s, c,
@@ -81,21 +84,26 @@ class TrpRelation(torch.autograd.Function):
         p32 = None
         if p is not None:
             p32 = p.detach().to(x.device, torch.float32).contiguous()
-            hip.check(lib.rsg_trp_relation_mse(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), b, s, c, hip.RSG_BF16, st),
-                      "trp_relation_mse")
-        ctx.save_for_backward(x16, w32, b32, p32)
+            if p32.dim() == 3:
+                if p32.shape != (b, s, s):
+                    raise ValueError(f"relation_target of shape {tuple(p32.shape)} for {s} positions")
+                hip.check(lib.rsg_trp_relation_mse_dense(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), b, s, c,
+                                                         hip.RSG_BF16, st), "trp_relation_mse_dense")
+            else:
+                hip.check(lib.rsg_trp_relation_mse(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), b, s, c, hip.RSG_BF16, st),
+                          "trp_relation_mse")
+        ctx.save_for_backward(x16, g16, w32, p32)
         ctx.in_dtype = x.dtype
         return e, mse
 
     @staticmethod
     def backward(ctx, d_e, d_mse):
         from . import hip
+        from .train_ops import rows_gram, rows_project
         lib = hip.lib()
-        x16, w32, b32, p32 = ctx.saved_tensors
+        x16, g16, w32, p32 = ctx.saved_tensors
         b, s, c = x16.shape
         st = torch.cuda.current_stream(x16.device).cuda_stream
-        xf = x16.float()
-        g16 = torch.addmm(b32, xf.reshape(-1, c), w32.t()).to(torch.bfloat16).reshape(b, s, c)
         de16 = d_e.to(torch.bfloat16).contiguous() if d_e is not None else torch.zeros_like(x16)
         x_t, de_t = _keys_transposed(x16), _keys_transposed(de16)
         coef = None
@@ -103,20 +111,20 @@ class TrpRelation(torch.autograd.Function):
             coef = (torch.zeros(b, device=x16.device) if d_mse is None else d_mse.float() * (2.0 / (s * s))).contiguous()
         dx = torch.empty(b, s, c, dtype=torch.float32, device=x16.device)
         dg = torch.empty_like(dx)
-        hip.check(lib.rsg_trp_backward(x16.data_ptr(), c, g16.data_ptr(), c, de16.data_ptr(), c, x_t.data_ptr(), de_t.data_ptr(),
-                                       None if p32 is None else p32.data_ptr(), None if coef is None else coef.data_ptr(),
-                                       dx.data_ptr(), dg.data_ptr(), b, s, c, hip.RSG_BF16, st), "trp_backward")
+        fn = lib.rsg_trp_backward_dense if (p32 is not None and p32.dim() == 3) else lib.rsg_trp_backward
+        hip.check(fn(x16.data_ptr(), c, g16.data_ptr(), c, de16.data_ptr(), c, x_t.data_ptr(), de_t.data_ptr(),
+                     None if p32 is None else p32.data_ptr(), None if coef is None else coef.data_ptr(),
+                     dx.data_ptr(), dg.data_ptr(), b, s, c, hip.RSG_BF16, st), "trp_backward")
         dg2 = dg.reshape(-1, c)
-        dx = dx + (dg2 @ w32).reshape(b, s, c)                               # g = x Wg^T + bg
-        from .train_ops import rows_gram
-        d_w = rows_gram(dg2, xf.reshape(-1, c)).reshape(c, c, 1, 1)
-        d_b = dg2.sum(0)
-        return dx.to(ctx.in_dtype), d_w, d_b, None
+        rows_project(dg2, w32, out=dx.reshape(-1, c))                        # g = x Wg^T + bg:  dx += dg Wg
+        d_w, d_b = rows_gram(dg2, x16.float().reshape(-1, c), with_colsum=True)
+        return dx.to(ctx.in_dtype), d_w.reshape(c, c, 1, 1), d_b, None
 
 
 def trp_on_hip(rh, channels: int, positions: int, relation_target) -> bool:
-    """The HIP pair covers what training uses: 32 channels, S a multiple of 128, the target given as its factor [B,S]."""
-    if relation_target is None or relation_target.dim() != 2:
+    """The HIP pair covers what training uses: 32 channels, S a multiple of 128, the target as its factor [B,S] or as the
+    [B,S,S] tensor of the reference's loop (function.py:261-272)."""
+    if relation_target is None or relation_target.dim() not in (2, 3):
         return False
     s = positions // (4 if getattr(rh, "sub_sample", False) else 1)
     return channels == 32 and s % 128 == 0

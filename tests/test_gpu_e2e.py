@@ -51,6 +51,9 @@ def _rms(got, ref):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
+BF16_EMU_BAR = (0.30, 0.052)       # x sigma: max-abs, rms of the bf16 path against the bf16-emulating oracle (2 x measured)
+
+
 def _stats(name, got, ref):
     e = maxabs(got, ref)
     sd = float(np.std(ref))
@@ -278,11 +281,11 @@ def test_rsgnet_w32_golden(tag):
     with torch.no_grad():
         model(xc)                                     # fvis / TRP output are pinned buffers: valid after a run
     torch.cuda.synchronize()
-    # final_vis (the contact clue, a sparse post-ReLU map: |max| 1.7 at sigma 0.18): measured 0.11-0.14 sigma max-abs,
-    # 0.013-0.014 sigma rms; relation_feats (TRP output after GroupNorm): 0.010-0.020 sigma.  Bars = 2x the worst.
+    # final_vis (the contact clue, a sparse post-ReLU map: |max| 1.7 at sigma 0.18): measured 0.11-0.144 sigma max-abs over
+    # rounds 3-4 (bar 0.2 sigma), 0.013-0.014 sigma rms (bar 2x); relation_feats (TRP output after GroupNorm): 0.010-0.020 sigma.
     fv = _tap_nchw(plan.fvis.tensor(2))
     ref = gold["final_vis_crop0"]
-    assert _stats("tap final_vis", fv, ref) < 0.3 * float(ref.std()) and _rms(fv, ref) < 0.03 * float(ref.std())
+    assert _stats("tap final_vis", fv, ref) < 0.2 * float(ref.std()) and _rms(fv, ref) < 0.03 * float(ref.std())
     rf = _tap_nchw(plan.fvis.base.tensor(2)[..., :plan.C0])
     ref = gold["relation_feats_crop0"]
     assert _stats("tap relation_feats", rf, ref) < 0.05 * float(ref.std())
@@ -356,6 +359,13 @@ def test_hrnet_w32_bf16_path_runs_and_is_coarser(tag):
     # the bf16-emulating ORACLE is itself 4.7e-2 = 0.16 sigma from the fp32 golden on HRNet-W32 (VERDICT round 2,
     # re-derived on the CPU): the bar is twice that floor (was 0.6 sigma)
     assert torch.isfinite(y).all() and e < 0.32 * float(ref.std()), e / float(ref.std())
+    if tag == "hrnet_w32_256x192":
+        # ... and against the oracle that rounds to bf16 where the kernels do (BASELINE configs[1] names bf16): both sides
+        # carry the same rounding noise in different summation orders, so they differ by about sqrt(2) x one realisation;
+        # measured 0.150 sigma max-abs / 0.026 sigma rms (profiles/r04_parity_measured.txt), bars at 2x
+        emu = po.hrnet_forward(sd, cfg, x, ctx=po.Ctx(sd, emulate="bf16"))
+        e2 = _stats(f"{tag} bf16 heatmaps vs bf16-emulating oracle", y[0], emu[0].numpy())
+        assert e2 < BF16_EMU_BAR[0] * float(ref.std()) and _rms(y[0], emu[0].numpy()) < BF16_EMU_BAR[1] * float(ref.std())
 
 
 @pytest.mark.parametrize("tag", ["hrnet_w32_256x192", "hrnet_w48_384x288"])

@@ -1089,6 +1089,96 @@ def test_trp_relation_function_matches_materialised_autograd():
     assert errs["dX"] < 2 ** -6 and errs["dW"] < 2 ** -6 and errs["db"] < 2 ** -6
 
 
+@pytest.mark.gpu
+def test_trp_dense_relation_target_equals_the_factored_one_and_autograd():
+    """The reference's training loop hands the model the relation target as a [B,S,S] tensor (function.py:261-272: p p^T).
+    rsg_trp_relation_mse_dense / rsg_trp_backward_dense read it tile by tile: (a) given p p^T they reproduce the factored
+    kernels bit for bit; (b) given a symmetric target that is NOT rank one they match fp64 autograd of the materialised
+    formula; (c) through TrpRelation, model-level: the [B,S,S] form gives the factored form's outputs and gradients."""
+    from rsgnet_amd.train_rsgnet import TrpRelation
+    lib = hip.lib()
+    B, S, Cc = 2, 384, 32
+    g = torch.Generator().manual_seed(23)
+    x = (torch.randn(B, S, Cc, generator=g).abs() * 0.35).to(torch.bfloat16)
+    x[:, ::3] *= -1
+    gg = torch.randn(B, S, Cc, generator=g).to(torch.bfloat16)
+    de = (torch.randn(B, S, Cc, generator=g) * 0.01).to(torch.bfloat16)
+    p = torch.rand(B, S, generator=g)
+    dmse = torch.tensor([0.7, 1.3]) * 50
+    perm = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+    tr = lambda t: t.transpose(1, 2).reshape(B, Cc, S // 16, 16)[..., perm].reshape(B, Cc, S).contiguous()
+    dev = lambda t: t.contiguous().to(DEV)
+    xd, gd, ded, xtd, detd, pd = map(dev, (x, gg, de, tr(x), tr(de), p))
+    coef = dev(dmse * 2.0 / (S * S))
+    dt = hip.DTYPES["bf16"]
+
+    def run(target, dense):
+        dx = torch.full((B, S, Cc), float("nan"), device=DEV)
+        dg = torch.full((B, S, Cc), float("nan"), device=DEV)
+        mse = torch.full((B,), float("nan"), device=DEV)
+        fb = lib.rsg_trp_backward_dense if dense else lib.rsg_trp_backward
+        fm = lib.rsg_trp_relation_mse_dense if dense else lib.rsg_trp_relation_mse
+        hip.check(fb(xd.data_ptr(), Cc, gd.data_ptr(), Cc, ded.data_ptr(), Cc, xtd.data_ptr(), detd.data_ptr(), target.data_ptr(),
+                     coef.data_ptr(), dx.data_ptr(), dg.data_ptr(), B, S, Cc, dt, _stream()), "trp_backward")
+        hip.check(fm(xd.data_ptr(), Cc, target.data_ptr(), mse.data_ptr(), B, S, Cc, dt, _stream()), "trp_relation_mse")
+        torch.cuda.synchronize()
+        return dx.cpu(), dg.cpu(), mse.cpu()
+
+    # (a) p p^T in fp32 is what the factored kernels multiply out per element
+    t1 = dev(p[:, :, None] * p[:, None, :])
+    dx_f, dg_f, mse_f = run(pd, False)
+    dx_d, dg_d, mse_d = run(t1, True)
+    assert torch.equal(dx_f, dx_d) and torch.equal(dg_f, dg_d)
+    assert float((mse_f - mse_d).abs().max()) <= 1e-6 * float(mse_f.abs().max())      # (atomic sum order)
+    # (b) a symmetric target of full rank against fp64 autograd
+    a = torch.rand(B, S, S, generator=g)
+    t2 = 0.5 * (a + a.transpose(1, 2))
+    dx2, dg2, mse2 = run(dev(t2), True)
+    X, G = x.double().requires_grad_(True), gg.double().requires_grad_(True)
+    R = torch.sigmoid(X @ X.transpose(1, 2))
+    M = ((t2.double() - R) ** 2).mean(dim=(1, 2))
+    wx, wg = torch.autograd.grad((de.double() * (R @ G)).sum() + (dmse.double() * M).sum(), [X, G])
+    ex = float((dx2.double() - wx).abs().max()) / float(wx.abs().max())
+    eg = float((dg2.double() - wg).abs().max()) / float(wg.abs().max())
+    em = float((mse2.double() - M.detach()).abs().max()) / float(M.abs().max())
+    print(f"  dense relation target: dX err {ex:.2e}  dG err {eg:.2e}  mse err {em:.2e}")
+    assert ex < 2 * 2.0 ** -7 and eg < 2 * 2.0 ** -7 and em < 1e-4
+    # (c) the autograd node with either form of the target
+    wgt, bgt = (torch.randn(Cc, Cc, 1, 1, generator=g) * 0.2).to(DEV), (torch.randn(Cc, generator=g) * 0.1).to(DEV)
+    outs = []
+    for tgt in (pd, t1):
+        xr = xd.float().requires_grad_(True)
+        w_, b_ = wgt.clone().requires_grad_(True), bgt.clone().requires_grad_(True)
+        e, mse = TrpRelation.apply(xr, w_, b_, tgt)
+        grads = torch.autograd.grad((e * ded.float()).sum() + (mse * dmse.to(DEV)).sum(), [xr, w_, b_])
+        outs.append((e.detach(), *[t.detach() for t in grads]))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+
+
+@pytest.mark.gpu
+def test_rows_gram_and_rows_project_match_fp64():
+    """rsg_rows_gram_f32 / rsg_rows_project_f32 (the TRP projections' own gradients in training) against fp64, and bit for
+    bit the same from run to run (fixed-order sums)."""
+    from rsgnet_amd.train_ops import rows_gram, rows_project
+    g = torch.Generator().manual_seed(3)
+    n, c = 98304 + 37, 32                       # not a multiple of the row tile
+    a, b = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+    m = torch.randn(c, c, generator=g)
+    ad, bd, md = a.to(DEV), b.to(DEV), m.to(DEV)
+    gram, cs = rows_gram(ad, bd, with_colsum=True)
+    gram2, cs2 = rows_gram(ad, bd, with_colsum=True)
+    assert torch.equal(gram, gram2) and torch.equal(cs, cs2)
+    ref = a.double().t() @ b.double()
+    assert float((gram.cpu().double() - ref).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-3
+    assert float((cs.cpu().double() - a.double().sum(0)).abs().max()) < 1e-3
+    out = torch.ones(n, c, device=DEV)
+    rows_project(ad, md, out=out)
+    ref = 1.0 + a.double() @ m.double()
+    assert float((out.cpu().double() - ref).abs().max()) < 1e-4
+    assert float((rows_project(ad, md).cpu().double() - (ref - 1.0)).abs().max()) < 1e-4
+
+
 def test_fuse_classifier_and_head4_equal_the_separate_launches():
     """rsg_fuse_classifier (the last module's fuse sum inside the classifier's launch) and rsg_fuse_head4 (that module's 1x1
     convs as well) against the separate launches (grouped 1x1 convs, fuse sum, rsg_conv_igemm classifier), bit for bit,
