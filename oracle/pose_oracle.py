@@ -92,6 +92,10 @@ class Ctx:
         # unchanged, one backward term missing.  "<module>.fuse.<i>.<j>": that addend of a fuse sum passes no gradient;
         # "<BatchNorm name>": the batch variance passes no gradient (one of the three terms of BatchNorm's backward).
         self.drop_grad: set = set()
+        # precision study (tests/test_precision_floor.py): which of the two 16-bit roundings of the emulation to apply -- the
+        # folded weights' (MFMA A operand) and the stored activations' (the next conv's B operand)
+        self.emu_weights = True
+        self.emu_acts = True
 
     def relu(self, y: torch.Tensor, key: Optional[str]) -> torch.Tensor:
         if self.relu_masks is not None and key is not None and key in self.relu_masks:
@@ -106,7 +110,7 @@ class Ctx:
 
     def store(self, x: torch.Tensor) -> torch.Tensor:
         """Where the HIP path writes an activation in 16 bits."""
-        if self.emu is None:
+        if self.emu is None or not self.emu_acts:
             return x
         return x.to(self.emu).to(self.dtype)
 
@@ -163,7 +167,9 @@ def conv_unit(ctx: Ctx, x, conv: str, bn: Optional[str] = None, *, stride=1, rel
     else:
         s, t = torch.ones(w.shape[1 if transposed else 0], dtype=ctx.dtype), 0.0
     shape = (1, -1, 1, 1) if transposed else (-1, 1, 1, 1)
-    wq = (w * s.view(shape)).to(ctx.emu).to(ctx.dtype)
+    wq = w * s.view(shape)
+    if ctx.emu_weights:
+        wq = wq.to(ctx.emu).to(ctx.dtype)
     bias = t if b is None else (b * s + t)
     y = run(x, wq, None) + (bias.view(1, -1, 1, 1) if torch.is_tensor(bias) else bias)
     if residual is not None:
@@ -276,7 +282,7 @@ def hrnet_forward(sd, cfg, x, **kw) -> torch.Tensor:
     with torch.no_grad():
         ys = backbone(ctx, x, cfg)
         w, b = ctx.p("final_layer.weight"), ctx.p("final_layer.bias")
-        if ctx.emu is not None:
+        if ctx.emu is not None and ctx.emu_weights:
             w = w.to(ctx.emu).to(ctx.dtype)
         return F.conv2d(ys[0], w, b, padding=(w.shape[-1] - 1) // 2)
 
