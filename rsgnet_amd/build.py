@@ -4,7 +4,7 @@ The build is keyed on what it builds: a hash over every csrc/* file, the public 
 environment switches that change flags and `hipcc --version` is stored beside the library (`<lib>.buildinfo`, JSON);
 `stale()` compares that hash, `info()` returns it with the per-file extra flags (smoke() and bench.py print it), and
 `audit_packed_fp32()` disassembles the library's code objects and counts the packed fp32 VALU ops per source file
-(tests/test_boundary.py asserts 0 for trp.hip: DESIGN 9b').
+(the build fails on a hit and tests/test_boundary.py asserts 0 for every source: DESIGN 9b').
 
     python -m rsgnet_amd.build [--force]
     RSGNET_HIP_BUILD_NAME=base RSGNET_HIP_EXTRA_CFLAGS="-DRSG_CHAIN16=0" python -m rsgnet_amd.build
@@ -30,26 +30,27 @@ LIB = os.path.join(LIBDIR, "librsgnet_hip.so")
 HEADER = os.path.join(os.path.dirname(PKG), "include", "rsgnet_hip.h")
 ARCH = "gfx950"
 
-BASE_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+# No packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) anywhere in the library.  The TRP's W projection dropped
+# FMA terms beside another stream's kernels in a form whose packed FMAs read 64-bit operands fed by uniform-address LDS reads
+# (DESIGN 9b').  What round 4 established about the cause: four wait states between the v_mov_b32 that assembles an operand
+# and the v_pk_fma_f32 that reads it change NOTHING (155 of 600 contended runs differ, as the plain build:
+# profiles/r04_trp_nop_discriminator.txt), so it is not that read-after-write window; the builds that do not fail are the one
+# without packed ops (-O1) and the one without single-address LDS reads.  Both ingredients are gone from the product: the
+# per-position kernels read their tables through the scalar cache, and no source is built with packed fp32 ops -- measured
+# free (same-visit A/B 1.260 / 1.400 ms against 1.262 / 1.402, profiles/r04_ab_no_packed_fp32.txt; beside MFMAs packed fp32
+# is slower than two scalar ops anyway, MI355X_MICROARCH.md).  audit_packed_fp32() disassembles every code object at build
+# time and fails the build on a hit.
+_NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+BASE_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", *_NO_PK_F32]
 # MFMA accumulators in VGPRs (gfx950 has one unified register file): the default AGPR form costs
 # v_accvgpr moves wherever VALU code touches an accumulator (64 per tile in trp.hip's sigmoid loop,
 # 16 per tile in every conv epilogue).  Measured in one visit: TRP loop -18 registers; HRNet step -1.8 %.
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
-# No packed fp32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  The TRP's W projection dropped FMA terms beside
-# another stream's kernels in a form whose v_pk_fma_f32 operands were assembled by v_mov_b32 (DESIGN 9b'; the build
-# without packed ops never failed).  Every source with fp32 per-element VALU kernels that can run beside another stream's
-# kernels is built this way (inference: trp; training, whose weight gradients run on a side stream: train, train_tail,
-# elementwise); they are latency- or bandwidth-bound, not VALU-bound.  audit_packed_fp32() checks the code objects.
-_NO_PK_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-NO_PACKED_FP32 = ("trp.hip", "train.hip", "train_tail.hip", "elementwise.hip")
 EXTRA_FLAGS: Dict[str, List[str]] = {
-    "trp.hip": _VGPR_FORM + _NO_PK_F32,
+    "trp.hip": _VGPR_FORM,
     "chain.hip": _VGPR_FORM,
     "group.hip": _VGPR_FORM,
     "conv_igemm.hip": _VGPR_FORM,
-    "train.hip": _NO_PK_F32,
-    "train_tail.hip": _NO_PK_F32,
-    "elementwise.hip": _NO_PK_F32,
     # the crop producer reproduces OpenCV's separately rounded double arithmetic: no fused multiply-adds there
     # (-ffp-contract=fast fuses in the backend and ignores `#pragma clang fp contract(off)`)
     "crops.hip": ["-ffp-contract=off"],
@@ -191,10 +192,10 @@ def build(force: bool = False, verbose: bool = False, name: Optional[str] = None
 
     with cf.ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(cc, srcs))
-    # build step, not a tool: the sources listed in NO_PACKED_FP32 must hold no packed fp32 VALU op (DESIGN 9b')
-    hits = {k: v for k, v in audit_packed_fp32(objs).items() if k in NO_PACKED_FP32 and v}
+    # build step, not a tool: no code object may hold a packed fp32 VALU op (DESIGN 9b')
+    hits = {k: v for k, v in audit_packed_fp32(objs).items() if v}
     if hits:
-        raise RuntimeError(f"packed fp32 VALU ops in sources built with -packed-fp32-ops: {hits}")
+        raise RuntimeError(f"packed fp32 VALU ops in the library (built with -packed-fp32-ops): {hits}")
     tmp = lib + ".tmp"
     r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", tmp],
                        capture_output=True, text=True)
