@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64 * NWAVES) probe32(const uint4* __restrict__
 // lane (col, q): pixel pi(col) of the group, input channels 8 sigma(q) .. + 7 (pi: columns {0-3, 12-15} take the even
 // pixels, {4-11} the odd ones; sigma = [0, 2, 1, 3]: with an 80-byte pixel stride every 16-lane phase of a ds_read_b128
 // then covers all 64 banks once)
-template <int NG, int NWAVES, int APRE>
+template <int NG, int NWAVES, int APRE, int NB = NG>
 __global__ void __launch_bounds__(64 * NWAVES) probe16(const uint4* __restrict__ w, const uint4* __restrict__ rnd, float* out,
                                                         int layers, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,10 +105,11 @@ __global__ void __launch_bounds__(64 * NWAVES) probe16(const uint4* __restrict__
         for (int m = 0; m < 2; ++m) acc[g][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     auto boff = [&](int t) { return (t / 3 - 1) * RPITCH + (t % 3 - 1) * PS; };
+    constexpr int NJ = TAPS * NG;              // B ring of NB fragments over the layer's (tap, group) sequence
     for (int l = 0; l < layers; ++l) {
-        uint4 bq[NG];
+        uint4 bq[NB];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) bq[g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(0));
+        for (int j = 0; j < NB; ++j) bq[j] = *reinterpret_cast<const uint4*>(smem + pixoff[j % NG] + boff(j / NG));
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const h8_t a0 = __builtin_bit_cast(h8_t, aq[t % NPF][0]), a1 = __builtin_bit_cast(h8_t, aq[t % NPF][1]);
@@ -116,10 +117,11 @@ __global__ void __launch_bounds__(64 * NWAVES) probe16(const uint4* __restrict__
             aq[t % NPF][1] = ap[((2 * (l * TAPS + t + NPF) + 1) % (16 * TAPS)) * 64];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                const h8_t b = __builtin_bit_cast(h8_t, bq[g]);
+                const int j = t * NG + g;
+                const h8_t b = __builtin_bit_cast(h8_t, bq[j % NB]);
                 acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b, acc[g][0], 0, 0, 0);
                 acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b, acc[g][1], 0, 0, 0);
-                if (t + 1 < TAPS) bq[g] = *reinterpret_cast<const uint4*>(smem + pixoff[g] + boff(t + 1));
+                if (j + NB < NJ) bq[j % NB] = *reinterpret_cast<const uint4*>(smem + pixoff[(j + NB) % NG] + boff((j + NB) / NG));
             }
             __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 #pragma unroll
@@ -157,6 +159,8 @@ extern "C" int probe_run(int variant, const void* w, const void* rnd, void* out,
         case 4: GO((probe16<14, 8, 2>), 512); break;
         case 5: GO((probe32<6, 8>), 512); break;
         case 6: GO((probe16<12, 8, 3>), 512); break;
+        case 7: GO((probe16<14, 8, 3, 7>), 512); break;
+        case 8: GO((probe16<14, 8, 3, 10>), 512); break;
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : 2;

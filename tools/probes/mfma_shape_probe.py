@@ -18,10 +18,10 @@ rnd = (torch.zeros if zero else torch.randn)(4096 * 8, device="cuda").half()
 out = torch.zeros(blocks * 512, device="cuda")
 clk = torch.zeros(blocks * 2, dtype=torch.int64, device="cuda")
 names = {0: "32x32x16 NT=7, 8 waves", 1: "16x16x32 NG=14, 8 waves, ring 3 taps", 2: "32x32x16 NT=7, 4 waves",
-         3: "16x16x32 NG=14, 4 waves", 4: "16x16x32 NG=14, 8 waves, ring 2 taps", 5: "32x32x16 NT=6, 8 waves", 6: "16x16x32 NG=12, 8 waves"}
+         3: "16x16x32 NG=14, 4 waves", 4: "16x16x32 NG=14, 8 waves, ring 2 taps", 5: "32x32x16 NT=6, 8 waves", 6: "16x16x32 NG=12, 8 waves", 7: "16x16x32 NG=14, 8 waves, B ring 7", 8: "16x16x32 NG=14, 8 waves, B ring 10"}
 layers = 4000
 for rep in range(2):
-    for v in (0, 1, 4, 5, 6, 2, 3):
+    for v in (0, 1, 7, 8, 4, 5, 6, 2, 3):
         for _ in range(2):
             assert lib.probe_run(v, C.c_void_p(w.data_ptr()), C.c_void_p(rnd.data_ptr()), C.c_void_p(out.data_ptr()), layers,
                                  C.c_void_p(clk.data_ptr()), blocks) == 0
@@ -33,10 +33,10 @@ for rep in range(2):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         c = clk.cpu().numpy().reshape(blocks, 2).astype(np.float64)
-        nw = 8 if v in (0, 1, 4, 5, 6) else 4
-        px = {0: 7 * 32, 1: 14 * 16, 2: 7 * 32, 3: 14 * 16, 4: 14 * 16, 5: 6 * 32, 6: 12 * 16}[v]
+        nw = 8 if v in (0, 1, 4, 5, 6, 7, 8) else 4
+        px = {0: 7 * 32, 1: 14 * 16, 2: 7 * 32, 3: 14 * 16, 4: 14 * 16, 5: 6 * 32, 6: 12 * 16, 7: 14 * 16, 8: 14 * 16}[v]
         flop = blocks * nw * px * 32 * 32 * 9 * 2.0 * layers
         cyc = np.median(c[:, 0])
         ideal = px / 32 * 18 * 32 * (nw / 4) * layers          # MFMA cycles per SIMD
         print(f"{names[v]:42s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s  clock {np.median(c[:, 0] / c[:, 1]) * 100:6.0f} MHz  "
-              f"cycles {cyc:.3e} (matrix pipe {ideal / cyc * 100:.1f} % busy)  out finite {bool(torch.isfinite(out).all())}", flush=True)
+              f"wave-0 cycles {cyc:.3e}; matrix pipe busy {flop / 32768 * 32 / 1024 / (ms * 1e-3 * np.median(c[:, 0] / c[:, 1]) * 1e8) * 100:.1f} % of the held clock  out finite {bool(torch.isfinite(out).all())}", flush=True)
