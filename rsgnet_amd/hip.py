@@ -190,9 +190,11 @@ def lib() -> C.CDLL:
         # and a measurement or a green test of THAT library says nothing about the sources); a library named through
         # RSGNET_HIP_LIB is another build on purpose (A/B runs)
         if not os.environ.get("RSGNET_HIP_LIB") and os.environ.get("RSGNET_HIP_ALLOW_STALE") != "1" and _build.stale():
-            raise RuntimeError(
-                f"{path} was not built from the sources, flags and compiler in this tree ({_build.describe()}): "
-                "run `python -m rsgnet_amd.build` (RSGNET_HIP_ALLOW_STALE=1 loads it anyway)")
+            if os.environ.get("RSGNET_HIP_NO_AUTOBUILD") == "1":
+                raise RuntimeError(
+                    f"{path} was not built from the sources, flags and compiler in this tree ({_build.describe()}): "
+                    "run `python -m rsgnet_amd.build` (RSGNET_HIP_ALLOW_STALE=1 loads it anyway)")
+            _build.build()          # rebuilds (about 90 s) or raises hipcc's error: never the previous build in silence
         l = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)      # AttributeError if the .so does not export it
