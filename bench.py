@@ -67,7 +67,8 @@ def rocprof_kernel(kernel_prefix, workload, gflop_per_step, launches_per_step):
     import glob
     if workload != "hrnet_w32_256x192":
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats_one_stream.csv")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats_one_stream.csv"))
+                   if "w48" not in os.path.basename(f) and "rsgnet" not in os.path.basename(f))
     if not files:
         return None
     with open(files[-1]) as f:
