@@ -523,6 +523,7 @@ __global__ void __launch_bounds__(C == 128 ? 512 : 64 * WM * WN) chain16_kernel(
 #ifdef RSG_CHAIN16_PROBE    // register budgets of the bodies the grouped kernel inlines (diagnostic compile only)
 template __global__ void chain16_kernel<F16, 64, 1, 8, 6, false, 24>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 128, 2, 2, 6, false, 12>(const ChainArgs);
+template __global__ void chain16_kernel<F16, 128, 2, 2, 6, true, 12>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 256, 8, 1, 3, true, 6>(const ChainArgs);
 template __global__ void chain16_kernel<F16, 256, 8, 1, 6, false, 6>(const ChainArgs);
 #endif
@@ -600,7 +601,10 @@ __global__ void __launch_bounds__(512) chain_group_kernel(const ChainGroupArgs g
             // waves (profiles/r02m_ab_w4_c128.txt); 2 x 2 waves of 64 output channels x 6 pixel groups
             if (threadIdx.x >= 256) return;
 #if RSG_CHAIN16_128
-            if (a.W == 12 && a.RP == chain16_row_pitch(128, 12)) chain16_body<DT, 128, 2, 2, 6, false, 12>(a, bid, smem, pf);
+            if (a.W == 12 && a.RP == chain16_row_pitch(128, 12)) {
+                if (a.dual) chain16_body<DT, 128, 2, 2, 6, true, 12>(a, bid, smem, pf);
+                else chain16_body<DT, 128, 2, 2, 6, false, 12>(a, bid, smem, pf);
+            } else if (a.dual) chain16_body<DT, 128, 2, 2, 6, true>(a, bid, smem, pf);
             else chain16_body<DT, 128, 2, 2, 6>(a, bid, smem, pf);
 #else
             if (a.dual) chain_body<DT, 128, 4, 1, 6, true>(a, bid, smem, pf);
@@ -731,7 +735,7 @@ static chain_fn chain_lookup(int C, int npix, int dual) {
         case 32: return npix <= 1536 ? chain16_kernel<DT, 32, 1, 8, 12> : chain16_kernel<DT, 32, 1, 8, 14, false, 48>;
         case 64: return chain16_kernel<DT, 64, 1, 8, 6>;
 #if RSG_CHAIN16_128
-        case 128: return chain16_kernel<DT, 128, 2, 2, 6>;
+        case 128: return dual ? chain16_kernel<DT, 128, 2, 2, 6, true> : chain16_kernel<DT, 128, 2, 2, 6>;
 #endif
         case 256:
             if (npix <= 48) return dual ? chain16_kernel<DT, 256, 8, 1, 3, true> : chain16_kernel<DT, 256, 8, 1, 3>;
@@ -790,9 +794,7 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
         lds = bytes(ni, H);
         // two images (ping-pong) where they fit: 16x12x128 and 8x6x256 (73 / 45 KB each)
         const int image = ni * (H + 2) * RP;
-        // (chain16_body<128> runs in place: its ping-pong form does not fit 256 registers with four output-channel tiles per
-        // wave, and one more barrier per layer among four waves is cheap)
-        a.dual = g_chain_dual && ((C == 128 && !chain_is16(C)) || (C == 256 && ni * H * W <= 64)) && lds + image <= CHAIN_LDS_LIMIT ? 1 : 0;
+        a.dual = g_chain_dual && (C == 128 || (C == 256 && ni * H * W <= 64)) && lds + image <= CHAIN_LDS_LIMIT ? 1 : 0;
         if (a.dual) lds += image;
         return 0;
     }

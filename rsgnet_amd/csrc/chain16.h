@@ -29,6 +29,9 @@
 // image's odd pixel stride of (2 C + 16) / 16 chunks; the 8-lane phases of the ds_write_b128 of the epilogue cover the 32
 // store banks once.  LDS image, borders, staging, hand-off and final store are chain_body's.
 #pragma once
+#ifndef RSG_CHAIN16_NB128
+#define RSG_CHAIN16_NB128 3          // B fragments in flight of the ping-pong 128-channel chain (3 x 64 matrix-pipe cycles)
+#endif
 
 __device__ __forceinline__ int chain16_pi(int col) {
     return col < 4 ? 2 * col : (col >= 12 ? 2 * (col - 8) : 2 * (col - 4) + 1);
@@ -175,7 +178,7 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
     // A ring: NPF k-steps ahead (a step is NG x 32 matrix-pipe cycles per wave); B ring: NB fragments in flight.  Both
     // wrap at the end of a 32-channel block (9 taps x NG groups), so the body of one block can be a loop iteration.
     constexpr int NPF = (C == 256 && NG <= 3) ? 9 : 3;
-    constexpr int NB = NG % 7 == 0 ? 7 : (NG % 6 == 0 && (NG > 6 || MT == 4) ? 6 : 9);
+    constexpr int NB = (C == 128 && DUAL) ? RSG_CHAIN16_NB128 : (NG % 7 == 0 ? 7 : (NG % 6 == 0 && (NG > 6 || MT == 4) ? 6 : 9));   // (ping-pong C = 128: 3 x 64 pipe cycles in flight fit 256 registers)
     constexpr int NJ = 9 * NG;                           // (tap, pixel group) pairs of a channel block, in issue order
     static_assert(9 % NPF == 0 && NJ % NB == 0, "the fragment rings wrap at the end of a channel block");
     uint4 aq[NPF][MT];
