@@ -369,7 +369,7 @@ int rsg_trp_backward(const void* x, int32_t ld_x, const void* g, int32_t ld_g, c
 int rsg_trp_backward_dense(const void* x, int32_t ld_x, const void* g, int32_t ld_g, const void* de, int32_t ld_de,
                            const void* xT, const void* deT, const float* target, const float* coef, float* dx, float* dg,
                            int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream);
-int rsg_trp_relation_mse_dense(const void* x, int32_t ld_x, const float* target, float* mse, int32_t batch,
+int rsg_trp_relation_mse_dense(const void* x, int32_t ld_x, const float* target, float* mse, void* workspace, int32_t batch,
                                int32_t S, int32_t C, int32_t dtype, void* stream);
 /* fp32 row products of the training head (autograd of the TRP's 1x1 projections, association.py:288-289, 298), fixed
  * summation order.  rsg_rows_project_f32: out[n,j] (+)= sum_k a[n,k] m[k,j] (C = 32 or 48; m is [C,C]).
@@ -383,8 +383,11 @@ int rsg_rows_gram_f32(const float* a, const float* b, float* gram, float* colsum
 int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S, int32_t C,
                    int32_t dtype, void* stream);
 /* training tail (pose_rsgnet.py:1014-1018) with the target kept factored, T = p p^T:
- * mse[b] = mean_ij (p_i p_j - sigmoid(<x_i,x_j>))^2 ; p: fp32 [batch,S] */
-int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, int32_t batch,
+ * mse[b] = mean_ij (p_i p_j - sigmoid(<x_i,x_j>))^2 ; p: fp32 [batch,S].  mse is overwritten (no pre-zeroing): every wave
+ * writes one partial sum into `workspace` (rsg_trp_mse_workspace_bytes(batch, S) bytes of device memory) and a second
+ * launch adds an image's partials in index order -- the same bits on every run, no atomics. */
+size_t rsg_trp_mse_workspace_bytes(int32_t batch, int32_t S);
+int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, void* workspace, int32_t batch,
                          int32_t S, int32_t C, int32_t dtype, void* stream);
 
 /* ---- training tail ------------------------------------------------------------

@@ -35,7 +35,7 @@ struct TrpArgs {
     float* scores;       // [B,S,S] fp32            (SCORES)
     const float* p;      // [B,S] fp32              (MSE: factor of the target, T = p p^T)
     const float* t;      // [B,S,S] fp32            (MSE: the target itself, read tile by tile; p is null then)
-    float* mse;          // [B] fp32, pre-zeroed    (MSE)
+    float* mse_part;     // [B][S/32] fp32: one partial sum of squared differences per wave (MSE)
     int S, ldx;
     float inv_ss;
 };
@@ -180,7 +180,9 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
     } else if (MODE == TRP_MSE) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if (lane == 0) atomicAdd(a.mse + b, part * a.inv_ss);
+        // one partial per wave, summed in a fixed order by trp_mse_sum_kernel: no atomics, no pre-zeroed output, the
+        // same bits on every run (and inside a replayed graph)
+        if (lane == 0) a.mse_part[(size_t)b * (a.S / 32) + blockIdx.x * 4 + wave] = part;
     }
 }
 
@@ -225,28 +227,46 @@ extern "C" int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_
     return trp_launch<TRP_SCORES>(a, batch, C, dtype, stream);
 }
 
-static int trp_mse(const void* x, int32_t ld_x, const float* p, const float* t, float* mse, int32_t batch,
+// mse[b] = inv_ss * sum of the image's S/32 per-wave partials, in index order (double accumulator)
+__global__ void __launch_bounds__(64) trp_mse_sum_kernel(const float* __restrict__ part, float* __restrict__ mse, int nper,
+                                                         int batch, float inv_ss) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    double acc = 0.0;
+    for (int i = 0; i < nper; ++i) acc += (double)part[(size_t)b * nper + i];
+    mse[b] = (float)(acc * (double)inv_ss);
+}
+
+extern "C" size_t rsg_trp_mse_workspace_bytes(int32_t batch, int32_t S) {
+    if (batch < 1 || S < 128 || S % 128) return 0;
+    return (size_t)batch * (S / 32) * sizeof(float);
+}
+
+static int trp_mse(const void* x, int32_t ld_x, const float* p, const float* t, float* mse, void* workspace, int32_t batch,
                    int32_t S, int32_t C, int32_t dtype, void* stream) {
     if (trp_check(x, ld_x, batch, S, C)) return 1;
     if ((!p && !t) || !mse) RSG_FAIL("trp_relation_mse: null pointer");
-    if (hipMemsetAsync(mse, 0, sizeof(float) * batch, (hipStream_t)stream) != hipSuccess)
-        RSG_FAIL("trp_relation_mse: memset failed");
+    if (!workspace || ((uintptr_t)workspace & 3)) RSG_FAIL("trp_relation_mse: workspace (rsg_trp_mse_workspace_bytes) missing");
     TrpArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = (const char*)x; a.p = p; a.t = t; a.mse = mse; a.S = S; a.ldx = ld_x;
+    a.x = (const char*)x; a.p = p; a.t = t; a.mse_part = (float*)workspace; a.S = S; a.ldx = ld_x;
     a.inv_ss = 1.0f / ((float)S * (float)S);
-    return trp_launch<TRP_MSE>(a, batch, C, dtype, stream);
+    if (trp_launch<TRP_MSE>(a, batch, C, dtype, stream)) return 1;
+    RSG_LAUNCH(trp_mse_sum_kernel, dim3(ceil_div(batch, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, mse,
+               S / 32, batch, a.inv_ss);
+    RSG_CHECK_LAUNCH("trp_relation_mse(sum)");
+    return 0;
 }
 
-extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, int32_t batch,
+extern "C" int rsg_trp_relation_mse(const void* x, int32_t ld_x, const float* p, float* mse, void* workspace, int32_t batch,
                                     int32_t S, int32_t C, int32_t dtype, void* stream) {
-    return trp_mse(x, ld_x, p, nullptr, mse, batch, S, C, dtype, stream);
+    return trp_mse(x, ld_x, p, nullptr, mse, workspace, batch, S, C, dtype, stream);
 }
 
-extern "C" int rsg_trp_relation_mse_dense(const void* x, int32_t ld_x, const float* target, float* mse, int32_t batch,
-                                          int32_t S, int32_t C, int32_t dtype, void* stream) {
+extern "C" int rsg_trp_relation_mse_dense(const void* x, int32_t ld_x, const float* target, float* mse, void* workspace,
+                                          int32_t batch, int32_t S, int32_t C, int32_t dtype, void* stream) {
     if (!target || ((uintptr_t)target & 3)) RSG_FAIL("trp_relation_mse_dense: the target [batch,S,S] fp32");
-    return trp_mse(x, ld_x, nullptr, target, mse, batch, S, C, dtype, stream);
+    return trp_mse(x, ld_x, nullptr, target, mse, workspace, batch, S, C, dtype, stream);
 }
 
 // ---- TRP backward (training; pose_rsgnet.py:987,1014-1018 under autograd) ---------------------------------------

@@ -161,8 +161,9 @@ SYMBOLS = {
     "rsg_pack_chain16_weights_host": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "rsg_wgrad_tune": (None, [_i, _i, _i, _i, _i]),
     "rsg_crop_warp_affine": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _vp]),
-    "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "rsg_trp_relation_mse_dense": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_mse_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "rsg_trp_relation_mse": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_trp_relation_mse_dense": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_backward_dense": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_rows_project_f32": (C.c_int, [_vp, _vp, _vp, C.c_int64, _i, _i, _vp]),
     "rsg_rows_gram_workspace_bytes": (C.c_size_t, [_i]),

@@ -249,16 +249,17 @@ def record_rsgnet(p: Plan, model) -> None:
         return out
 
     def relation_mse(target: torch.Tensor) -> torch.Tensor:
+        """pose_rsgnet.py:1014-1018 for the factored target p [B,S] (T = p p^T) or the reference's [B,S,S] tensor
+        (lib/core/function.py:269), read tile by tile: nothing S x S is materialised either way."""
         st = torch.cuda.current_stream(dev).cuda_stream
-        if target.dim() == 2:          # factored target p (T = p p^T): fused, nothing materialised
-            pv = target.to(dev, torch.float32).contiguous()
-            out = torch.empty(B, **f32)
-            hip.check(lib.rsg_trp_relation_mse(xr.ptr(), xr.ld, pv.data_ptr(), out.data_ptr(), B, Sr, c0,
-                                               dt, st), "trp_relation_mse")
-            return out
-        # reference-shaped [B,S,S] target (lib/core/function.py:269): compatibility path, materialises R
-        r = relation_scores()
-        return ((target.to(dev, torch.float32) - r) ** 2).mean(dim=(1, 2))
+        tv = target.to(dev, torch.float32).contiguous()
+        if tv.dim() not in (2, 3) or tuple(tv.shape) != (B,) + (Sr,) * (tv.dim() - 1):
+            raise ValueError(f"relation_target of shape {tuple(tv.shape)} for batch {B} and {Sr} positions")
+        out = torch.empty(B, **f32)
+        ws = torch.empty(int(lib.rsg_trp_mse_workspace_bytes(B, Sr)), dtype=torch.uint8, device=dev)
+        fn = lib.rsg_trp_relation_mse if tv.dim() == 2 else lib.rsg_trp_relation_mse_dense
+        hip.check(fn(xr.ptr(), xr.ld, tv.data_ptr(), out.data_ptr(), ws.data_ptr(), B, Sr, c0, dt, st), "trp_relation_mse")
+        return out
 
     p.relation_scores = relation_scores
     p.relation_mse = relation_mse

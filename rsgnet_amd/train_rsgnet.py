@@ -84,14 +84,15 @@ class TrpRelation(torch.autograd.Function):
         p32 = None
         if p is not None:
             p32 = p.detach().to(x.device, torch.float32).contiguous()
+            ws = torch.empty(int(lib.rsg_trp_mse_workspace_bytes(b, s)), dtype=torch.uint8, device=x.device)
             if p32.dim() == 3:
                 if p32.shape != (b, s, s):
                     raise ValueError(f"relation_target of shape {tuple(p32.shape)} for {s} positions")
-                hip.check(lib.rsg_trp_relation_mse_dense(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), b, s, c,
+                hip.check(lib.rsg_trp_relation_mse_dense(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), ws.data_ptr(), b, s, c,
                                                          hip.RSG_BF16, st), "trp_relation_mse_dense")
             else:
-                hip.check(lib.rsg_trp_relation_mse(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), b, s, c, hip.RSG_BF16, st),
-                          "trp_relation_mse")
+                hip.check(lib.rsg_trp_relation_mse(x16.data_ptr(), c, p32.data_ptr(), mse.data_ptr(), ws.data_ptr(), b, s, c,
+                                                   hip.RSG_BF16, st), "trp_relation_mse")
         ctx.save_for_backward(x16, g16, w32, p32)
         ctx.in_dtype = x.dtype
         return e, mse
@@ -211,10 +212,57 @@ def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Te
     return multi, kpt, limbs, rel
 
 
+class _Head(torch.nn.Module):
+    """head_forward as a module of tensors in, tensors out (what torch.cuda.make_graphed_callables captures)."""
+
+    def __init__(self, model, with_target: bool):
+        super().__init__()
+        self.model = model
+        self.with_target = with_target
+
+    def forward(self, feat16, *target):
+        return head_forward(self.model, feat16, target[0] if self.with_target else None)
+
+
+def _head_buffers(model):
+    return [b for b in model.buffers() if b.is_cuda]
+
+
+def graphed_head(model, feat16: torch.Tensor, relation_target: Optional[torch.Tensor]):
+    """The head's forward and backward as two HIP graphs (torch.cuda.make_graphed_callables), built once per input
+    geometry and replayed afterwards: ~110 launches forward and ~190 backward become two graph launches.  The capture's
+    three warm-up passes would apply the BatchNorm momentum update three extra times, so the buffers are put back as they
+    were before the first real step.  (Round 3 recorded a segmentation fault in hipStreamEndCapture here; it does not
+    occur with this head -- tools/head_capture_probe.py, profiles/r04_head_capture.txt.  Slower than the eager head at
+    batch 8 and 32 on this runtime, hence opt-in.)"""
+    key = (tuple(feat16.shape), feat16.dtype, feat16.device,
+           None if relation_target is None else (tuple(relation_target.shape), relation_target.dtype))
+    cache = model.__dict__.setdefault("_head_graphs", {})
+    fn = cache.get(key)
+    if fn is None:
+        bufs = _head_buffers(model)
+        keep = [b.clone() for b in bufs]
+        sample = [feat16.detach().clone().requires_grad_(True)]
+        if relation_target is not None:
+            sample.append(relation_target.detach().clone())
+        fn = torch.cuda.make_graphed_callables(_Head(model, relation_target is not None), tuple(sample), allow_unused_input=True)
+        with torch.no_grad():
+            for b, k in zip(bufs, keep):
+                b.copy_(k)
+        cache[key] = fn
+    return fn(feat16) if relation_target is None else fn(feat16, relation_target)
+
+
 def train_forward(model, x: torch.Tensor, relation_target: Optional[torch.Tensor] = None):
-    """`model(x, relation_target)` under `model.train()` for pose_rsgnet.  The head's ~300 launches per step are enqueued
-    eagerly: capturing them (forward and autograd backward) with torch.cuda.make_graphed_callables ends in a segmentation
-    fault inside hipStreamEndCapture on ROCm 7.2 (the backward's launches come from autograd's device thread)."""
+    """`model(x, relation_target)` under `model.train()` for pose_rsgnet.  RSGNET_HIP_TRAIN_HEAD_GRAPH=1 replays the head
+    (forward and backward) as HIP graphs (`graphed_head`); by default its ~300 launches per step are enqueued eagerly, which
+    the host hides behind the backbone's graphs at the shipped batch sizes (profiles/r04_head_capture.txt)."""
+    import os
     from .train import train_forward as backbone_forward
     feat16 = backbone_forward(model, x)                                   # HIP: one autograd node for the whole backbone
+    mode = os.environ.get("RSGNET_HIP_TRAIN_HEAD_GRAPH", "0")
+    if mode not in ("0", "1"):
+        raise ValueError(f"RSGNET_HIP_TRAIN_HEAD_GRAPH={mode!r}: 0 or 1")
+    if mode == "1" and getattr(model, "_train_taps", None) is None and torch.is_grad_enabled():
+        return graphed_head(model, feat16, relation_target)
     return head_forward(model, feat16, relation_target)

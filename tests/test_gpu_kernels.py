@@ -269,9 +269,13 @@ def test_trp_attention_project_tail_scores_mse():
     hip.check(lib.rsg_trp_scores(xptr, ld, scores.data_ptr(), B, S, Cc, 0, st))
     p = torch.rand(B, S, generator=g)
     pd = p.to(DEV)
-    mse = torch.zeros(B, device=DEV)
-    hip.check(lib.rsg_trp_relation_mse(xptr, ld, pd.data_ptr(), mse.data_ptr(), B, S, Cc, 0, st))
+    mse = torch.full((B,), float("nan"), device=DEV)          # overwritten, not accumulated into
+    mse2 = torch.full((B,), float("nan"), device=DEV)
+    mws = torch.empty(lib.rsg_trp_mse_workspace_bytes(B, S), dtype=torch.uint8, device=DEV)
+    hip.check(lib.rsg_trp_relation_mse(xptr, ld, pd.data_ptr(), mse.data_ptr(), mws.data_ptr(), B, S, Cc, 0, st))
+    hip.check(lib.rsg_trp_relation_mse(xptr, ld, pd.data_ptr(), mse2.data_ptr(), mws.data_ptr(), B, S, Cc, 0, st))
     torch.cuda.synchronize()
+    assert torch.equal(mse, mse2)                             # fixed summation order: the same bits every time
     # CPU restatement (association.py:288-300) in fp64 on the same 16-bit-rounded x
     xd = xq.double()
     gref = xd @ wg.double().t() + bg.double()
@@ -1120,7 +1124,8 @@ def test_trp_dense_relation_target_equals_the_factored_one_and_autograd():
         fm = lib.rsg_trp_relation_mse_dense if dense else lib.rsg_trp_relation_mse
         hip.check(fb(xd.data_ptr(), Cc, gd.data_ptr(), Cc, ded.data_ptr(), Cc, xtd.data_ptr(), detd.data_ptr(), target.data_ptr(),
                      coef.data_ptr(), dx.data_ptr(), dg.data_ptr(), B, S, Cc, dt, _stream()), "trp_backward")
-        hip.check(fm(xd.data_ptr(), Cc, target.data_ptr(), mse.data_ptr(), B, S, Cc, dt, _stream()), "trp_relation_mse")
+        mws = torch.empty(lib.rsg_trp_mse_workspace_bytes(B, S), dtype=torch.uint8, device=DEV)
+        hip.check(fm(xd.data_ptr(), Cc, target.data_ptr(), mse.data_ptr(), mws.data_ptr(), B, S, Cc, dt, _stream()), "trp_relation_mse")
         torch.cuda.synchronize()
         return dx.cpu(), dg.cpu(), mse.cpu()
 
@@ -1129,7 +1134,7 @@ def test_trp_dense_relation_target_equals_the_factored_one_and_autograd():
     dx_f, dg_f, mse_f = run(pd, False)
     dx_d, dg_d, mse_d = run(t1, True)
     assert torch.equal(dx_f, dx_d) and torch.equal(dg_f, dg_d)
-    assert float((mse_f - mse_d).abs().max()) <= 1e-6 * float(mse_f.abs().max())      # (atomic sum order)
+    assert torch.equal(mse_f, mse_d)                  # per-wave partials summed in index order: no atomics
     # (b) a symmetric target of full rank against fp64 autograd
     a = torch.rand(B, S, S, generator=g)
     t2 = 0.5 * (a + a.transpose(1, 2))
