@@ -64,6 +64,20 @@ for m in members:
         print(f"  {m:26s} cin {t['cin']:3d} cout {t['cout']:3d} k{t['k']} s{t['s']} tile {t['tile'][:6]}: {n:4d} wgs, median {np.median(d[ok]):6.0f} clk = "
               f"args {np.median(b[:, 1] - b[:, 0]):5.0f} + stage {np.median(b[:, 2] - b[:, 1]):5.0f} + mfma {np.median(b[:, 3] - b[:, 2]):5.0f} + store {np.median(b[:, 4] - b[:, 3]):5.0f}")
     first += n
+# the launch's timeline: when each item's first workgroup starts and its last one ends, from the launch's first stamp
+t0 = st[st[:, 4] > 0, 0].min()
+print(f"  launch span {st[:, 4].max() - t0:.0f} clk")
+first = 0
+for m in members:
+    t = tiles.get(m)
+    if t is None:
+        continue
+    n = t["tile"][7] if len(t["tile"]) > 7 else 0
+    blk = st[first:first + n]
+    blk = blk[blk[:, 4] > 0]
+    if len(blk):
+        print(f"  {m:26s} first start {blk[:, 0].min() - t0:6.0f}  last start {blk[:, 0].max() - t0:6.0f}  last end {blk[:, 4].max() - t0:6.0f}")
+    first += n
 xcc = (raw[:, 7] >> 32) & 0xf
 hwid = raw[:, 7] & 0xffffffff
 cu = ((hwid >> 8) & 0xf) | (((hwid >> 13) & 0x7) << 4) | (xcc << 8)
