@@ -24,7 +24,9 @@ enum { RSG_F16 = 0, RSG_BF16 = 1 };
 
 const char* rsg_last_error(void);
 int rsg_version(void);
-/* tuning knobs for experiments (process-wide): "chain_max_ni" = images per workgroup cap of the chain kernel */
+/* tuning knobs for experiments (process-wide): "chain_max_ni" = images per workgroup cap of the chain kernel;
+ * "conv_spread" = n: a conv whose grid would have fewer than n workgroups is re-tiled into more, smaller ones (default 128,
+ * 0 = off; the tiling never changes a result bit); the others are listed at rsg_tune in csrc/chain.hip */
 int rsg_tune(const char* key, int32_t value);
 
 /* ---- convolution family ---------------------------------------------------------------------

@@ -703,6 +703,7 @@ static int chain_row_pitch(int C, int W) {
 }   // rsg_tune("chain_max_ni", n): images per workgroup cap in whole-image mode
 extern int g_conv_lds_limit;
 extern int g_conv_full_k;
+extern int g_conv_spread;
 extern int g_bottleneck_head;
 #ifdef RSG_DEBUG
 extern int g_bottleneck_debug;
@@ -713,6 +714,7 @@ extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "bottleneck_debug")) { g_bottleneck_debug = value; return 0; }
 #endif
     if (key && !strcmp(key, "conv_full_k")) { g_conv_full_k = value ? 1 : 0; return 0; }
+    if (key && !strcmp(key, "conv_spread") && value >= 0 && value <= 4096) { g_conv_spread = value; return 0; }
     if (key && !strcmp(key, "conv_lds_limit") && value >= 8192 && value <= 64 * 1024) { g_conv_lds_limit = value; return 0; }
     if (key && !strcmp(key, "chain_max_ni") && value >= 1) { g_chain_max_ni = value; return 0; }
     if (key && !strcmp(key, "chain_pitch_pad")) { g_chain_pitch_pad = value ? 1 : 0; return 0; }

@@ -79,6 +79,7 @@ static void tile_geometry(const rsg_conv_desc* d, TilePlan& t) {
 
 int g_conv_full_k = 1;                 // rsg_tune("conv_full_k", 0|1)
 int g_conv_lds_limit = 52 * 1024;      // rsg_tune("conv_lds_limit", bytes): LDS cap of the tile chooser
+int g_conv_spread = 128;               // rsg_tune("conv_spread", n): re-tile a conv whose grid has fewer than n workgroups (0 = off)
 #define LDS_LIMIT g_conv_lds_limit
 
 static int choose_tile(const rsg_conv_desc* d, TilePlan& best) {
@@ -103,42 +104,77 @@ static int choose_tile(const rsg_conv_desc* d, TilePlan& best) {
         if (best.lds > LDS_LIMIT) RSG_FAIL("conv: tile_hint needs %d B of LDS", best.lds);
         return 0;
     }
-    int WM = 1;
     // 128 output channels per workgroup for tiny maps, and for wide outputs (>= 256 channels: measured on
     // layer1's 64->256 1x1 convs, 53 -> 43 us: the input tile is staged half as often)
-    if (cout_pad % 128 == 0 && (d->out_h * d->out_w <= 64 || cout_pad >= 256)) WM = 4;
-    else if (cout_pad % 64 == 0) WM = 2;
-    const int WN = 4 / WM;
-    static const int nts[3][3] = {{3, 1, 0}, {3, 1, 0}, {2, 0, 0}};   // per WM = 1, 2, 4
-    const int* ntl = nts[WM == 1 ? 0 : (WM == 2 ? 1 : 2)];
-    static const int tws[] = {0, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4};
-    double best_score = -1e30;
-    bool found = false;
-    for (int i = 0; i < 3 && ntl[i]; ++i) {
-        const int NT = ntl[i], cap = 32 * NT * WN;
-        for (int tw : tws) {
-            TilePlan t;
-            t.CINB = cinb; t.WM = WM; t.WN = WN; t.NT = NT;
-            t.TW = tw ? tw : d->out_w;
-            if (t.TW > d->out_w || t.TW > cap) continue;
-            t.TH = cap / t.TW;
-            if (t.TH > d->out_h) t.TH = d->out_h;
-            if (t.TH < 1) continue;
-            tile_geometry(d, t);
-            if (t.lds > LDS_LIMIT) {     // shrink the tile height until it fits
-                while (t.TH > 1 && t.lds > LDS_LIMIT) { --t.TH; tile_geometry(d, t); }
-                if (t.lds > LDS_LIMIT) continue;
+    int WM0 = 1;
+    if (cout_pad % 128 == 0 && (d->out_h * d->out_w <= 64 || cout_pad >= 256)) WM0 = 4;
+    else if (cout_pad % 64 == 0) WM0 = 2;
+    // the best tile for a given split of the four waves (WM output-channel tiles x WN pixel columns) and the pixel
+    // groups per wave allowed; returns false when nothing fits
+    auto search = [&](int WM, int max_nt, TilePlan& out) -> bool {
+        const int WN = 4 / WM;
+        static const int nts[3][3] = {{3, 1, 0}, {3, 1, 0}, {2, 0, 0}};   // per WM = 1, 2, 4
+        const int* ntl = nts[WM == 1 ? 0 : (WM == 2 ? 1 : 2)];
+        static const int tws[] = {0, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4};
+        double best_score = -1e30;
+        bool found = false;
+        for (int i = 0; i < 3 && ntl[i]; ++i) {
+            const int NT = ntl[i], cap = 32 * NT * WN;
+            if (NT > max_nt) continue;
+            for (int tw : tws) {
+                TilePlan t;
+                t.CINB = cinb; t.WM = WM; t.WN = WN; t.NT = NT;
+                t.TW = tw ? tw : d->out_w;
+                if (t.TW > d->out_w || t.TW > cap) continue;
+                t.TH = cap / t.TW;
+                if (t.TH > d->out_h) t.TH = d->out_h;
+                if (t.TH < 1) continue;
+                tile_geometry(d, t);
+                if (t.lds > LDS_LIMIT) {     // shrink the tile height until it fits
+                    while (t.TH > 1 && t.lds > LDS_LIMIT) { --t.TH; tile_geometry(d, t); }
+                    if (t.lds > LDS_LIMIT) continue;
+                }
+                const double useful = (double)d->out_h * d->out_w;
+                const double spent = (double)t.tiles_y * t.tiles_x * cap;
+                // MFMA utilisation, with a mild preference for less halo re-read and conflict-free widths
+                const double halo = (double)(t.TIH * t.TIW) / (t.TH * t.TW * d->stride * d->stride);
+                double score = useful / spent - 0.02 * halo + (t.TW >= 16 ? 0.01 : 0.0);
+                if (score > best_score) { best_score = score; out = t; found = true; }
             }
-            const double useful = (double)d->out_h * d->out_w;
-            const double spent = (double)t.tiles_y * t.tiles_x * cap;
-            // MFMA utilisation, with a mild preference for less halo re-read and conflict-free widths
-            const double halo = (double)(t.TIH * t.TIW) / (t.TH * t.TW * d->stride * d->stride);
-            double score = useful / spent - 0.02 * halo + (t.TW >= 16 ? 0.01 : 0.0);
-            if (score > best_score) { best_score = score; best = t; found = true; }
+        }
+        return found;
+    };
+    if (!search(WM0, 3, best))
+        RSG_FAIL("conv: no tile fits (cin=%d cout=%d %dx%d k%d s%d)", d->in_c, d->out_c, d->out_h, d->out_w, d->kh, d->stride);
+    // A grid that leaves most CUs without a workgroup (the low-resolution, wide convs of a training batch: 32 crops of
+    // 8x6 pixels x 256 channels are 64 workgroups of 12 us each) is latency, not throughput: its workgroups run their
+    // whole K alone on a CU, so halving what one of them owns halves the launch.  Spread such a conv over more, smaller
+    // workgroups -- fewer output channels, then fewer pixel groups per wave -- until it has a workgroup for half the CUs
+    // (same-visit A/B on the training step, profiles/r04_ab_train_conv_spread.txt: 128 is -1.7 %, 256 and 512 are slower
+    // than off; results are bit-identical in every tiling).
+    if (g_conv_spread) {
+        auto nwg = [&](const TilePlan& t) { return (long)d->batch * t.tiles_y * t.tiles_x * (cout_pad / (32 * t.WM)); };
+        const long want = g_conv_spread;
+        if (nwg(best) < want) {
+            // every split of the waves and both pixel-group limits: the coarsest tiling that reaches `want` workgroups,
+            // else the finest there is
+            TilePlan pick = best;
+            bool reached = false;
+            for (int WM = 4; WM >= 1; WM >>= 1) {
+                if (cout_pad % (32 * WM)) continue;
+                for (int max_nt = 3; max_nt >= 1; max_nt -= 2) {
+                    TilePlan t;
+                    if (!search(WM, max_nt, t)) continue;
+                    const long n = nwg(t);
+                    if (n >= want ? (!reached || n < nwg(pick)) : (!reached && n > nwg(pick))) {
+                        pick = t;
+                        reached = reached || n >= want;
+                    }
+                }
+            }
+            best = pick;
         }
     }
-    if (!found) RSG_FAIL("conv: no tile fits (cin=%d cout=%d %dx%d k%d s%d)", d->in_c, d->out_c,
-                                 d->out_h, d->out_w, d->kh, d->stride);
     return 0;
 }
 

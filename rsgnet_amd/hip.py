@@ -203,7 +203,7 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad"),
                          ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit"), ("RSGNET_HIP_CHAIN_PREFETCH", b"chain_prefetch"),
-                         ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
+                         ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_CONV_SPREAD", b"conv_spread"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
                          ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual"),
                          ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows")):
             if os.environ.get(env):

@@ -139,6 +139,30 @@ def test_conv_igemm_matches_cpu(case):
         assert float(got16[:, Cout:].abs().max()) == 0.0, "padding channels must be written as zeros"
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] >= 32 and c[3] * c[4] >= 48][:12], ids=lambda c: "x".join(map(str, c)))
+def test_conv_spread_changes_the_tiling_not_the_bits(case):
+    """rsg_tune("conv_spread", n) re-tiles a conv whose grid has fewer than n workgroups (smaller output-channel and pixel
+    tiles: more, shorter workgroups).  The contraction order per output element is the same in every tiling, so the
+    results are equal bit for bit; rsg_conv_plan shows that the tiling did change for the small grids of this test."""
+    B, Cin, Cout, H, W, k, stride, relu, use_res = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+    outs = []
+    lib = hip.lib()
+    try:
+        for n in (0, 4096):
+            hip.check(lib.rsg_tune(b"conv_spread", n))
+            outs.append(run_conv(x, w, scale, shift, None, stride=stride, relu=relu, residual=res, want_f32=True))
+    finally:
+        hip.check(lib.rsg_tune(b"conv_spread", 128))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_conv_stride2_shape_sweep():
     """Stride-2 3x3 convs keep even and odd input columns in separate LDS halves (conv_body `deint`): seeded random
     shapes with odd/even sizes, tiles narrower than the map, every channel-block width."""
