@@ -57,7 +57,13 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
         const int py = q / p.TW, px = q - py * p.TW;
         const bool in_tile = q < p.TH * p.TW;
         const bool valid = in_tile && (y0 + py) < p.Hout && (x0 + px) < p.Wout;
-        pixoff[g] = (in_tile ? (py * p.SI) * p.RP + px * PS : 0) + hh * 16;     // columns: see `deint` below
+        // A lane past the end of the tile reads the pixel TH*TW positions back (its product is discarded).  With every idle
+        // lane on ONE address, that address shared a bank with one of the live lanes of its 16-lane read group in half of
+        // the groups (a 48-pixel tile in 64 lanes: the 8x6 maps); a tile of a multiple of 16 pixels is a whole number of
+        // 256-byte bank rows, so the wrapped lanes continue the live lanes' conflict-free slot progression instead.
+        const int qw = in_tile ? q : q % (p.TH * p.TW);
+        const int pyw = qw / p.TW, pxw = qw - pyw * p.TW;
+        pixoff[g] = (pyw * p.SI) * p.RP + pxw * PS + hh * 16;     // columns: see `deint` below
         opix[g] = valid ? ((b * p.Hp + (y0 + py) * p.up + p.upy) * p.Wp + (x0 + px) * p.up + p.upx) : -1;
     }
 
