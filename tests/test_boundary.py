@@ -111,6 +111,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.rsg_version() >= 1
 
 
+def test_entry_points_reject_bad_arguments_before_any_launch():
+    """Argument checks of the C ABI run on the host (no GPU needed): a bad call returns non-zero and rsg_last_error says
+    why; nothing is launched."""
+    lib = hip.lib()
+    assert lib.rsg_trp_mse_workspace_bytes(2, 3072) == 2 * (3072 // 32) * 4 and lib.rsg_trp_mse_workspace_bytes(2, 100) == 0
+    buf = (ctypes.c_char * 4096)()
+    a = ctypes.addressof(buf) & ~15 | 16                    # any aligned non-null address: the call fails before it is read
+    assert lib.rsg_trp_relation_mse(a, 32, a, a, None, 2, 3072, 32, 0, None) != 0
+    assert b"workspace" in lib.rsg_last_error()
+    assert lib.rsg_trp_relation_mse(a, 32, a, a, a, 2, 3000, 32, 0, None) != 0 and b"S=3000" in lib.rsg_last_error()
+    assert lib.rsg_trp_relation_mse_dense(a, 32, None, a, a, 2, 3072, 32, 0, None) != 0
+    assert lib.rsg_tune(b"conv_spread", -1) != 0 and lib.rsg_tune(b"no_such_key", 1) != 0
+    assert lib.rsg_tune(b"conv_spread", 128) == 0
+
+
 def test_product_package_never_imports_oracle():
     bad = []
     for dp, _d, files in os.walk(os.path.join(ROOT, "rsgnet_amd")):
