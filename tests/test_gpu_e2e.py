@@ -196,6 +196,31 @@ def test_full_size_batches_of_the_baseline_configs(name, batch, sample):
     assert e_ref < REL_TOL * sd_ref, e_ref / sd_ref
 
 
+def test_full_size_batch_of_rsgnet_w32():
+    """RSGNet-W32 256x192 at 64 crops (the batch bench.py times for the RSGNet configs; TRP at S = 3072 over a full grid):
+    quarters equal the whole bit for bit on all three score maps, and two sampled crops agree with the fp32 oracle at
+    the golden test's bars (limb maps on their logits)."""
+    name = "rsgnet_w32_256x192_coco"
+    cfg, model, sd, x, gold = load_case(name)
+    from rsgnet_amd.weights import synth_input
+    xb = synth_input(64, TAGS[name][2], 23)
+    model = model.cuda()
+    with torch.no_grad():
+        full = [t.clone() for t in model(xb.cuda())[:3]]
+        parts = [torch.cat(ts) for ts in zip(*[[t.clone() for t in model(xb[i * 16:(i + 1) * 16].cuda())[:3]] for i in range(4)])]
+    for a, b in zip(full, parts):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    sample = [9, 58]
+    ref = po.rsgnet_forward(sd, cfg, xb[sample], want_scores=False)
+    for nm, got, r in zip(("multi", "kpt"), full[:2], ref[:2]):
+        e = _stats(f"{name} batch 64, crops {sample}, {nm} vs fp32 oracle", got[sample].cpu().numpy(), r.numpy())
+        assert e < REL_TOL * float(r.std()), nm
+    logit = lambda p: np.log(np.clip(p, 1e-7, 1 - 1e-7)) - np.log1p(-np.clip(p, 1e-7, 1 - 1e-7))
+    rl, gl = logit(ref[2].double().numpy()), logit(full[2][sample].cpu().double().numpy())
+    e = _stats(f"{name} batch 64, crops {sample}, limb logits vs fp32 oracle", gl, rl)
+    assert e < LIMB_LOGIT_TOL * float(rl.std())
+
+
 @pytest.mark.parametrize("name", ["hrnet_w32_256x192", "rsgnet_w32_256x192_coco", "hrnet_w48_384x288"])
 def test_ragged_batches_agree_with_each_other(name):
     """Batches of 1, 3 and 7 crops (fewer workgroups than XCDs, odd tile counts, the last workgroup of a two-image
