@@ -288,6 +288,58 @@ int rsg_conv_fuse_group_plan(const rsg_conv_desc* convs, int32_t n_convs, const 
                              int32_t n_fuses, int32_t dtype, void* table_host, int32_t* launch2);
 int rsg_conv_fuse_group_run(const void* table_host, int32_t blocks, int32_t lds, int32_t dtype, void* stream);
 
+/* ---- level 0 of a HighResolutionModule's fuse layers in ONE launch of row bands (csrc/fuse_module.hip) ---------------
+ * Replaces, of x_fuse[i] = relu(sum_j fuse_layers[i][j](x[j])) (/root/reference/lib/models/pose_hrnet.py:190-268, forward
+ * :250-268): every conv that reads a branch map x[j] directly -- the 1x1 "up" convs j -> i (:199-213) and the first 3x3
+ * stride-2 conv of every "down" chain (:217-243) -- and the sums of outputs 0 and 1 (:259-266).  Branch i is
+ * [batch, h >> i, w >> i, x_ld[i]] 16-bit NHWC with 32 << i channels (HRNet-W32's widths); h, w multiples of 8.
+ * A conv: w_packed / bias from rsg_pack_conv_weights_host(cin = 32 << src, cout, k x k) with the BatchNorm folded;
+ *   k = 1: 1x1 at the resolution of branch src; k = 3: 3x3 stride 2 pad 1, output at the resolution of branch src + 1
+ *   (src 0 or 1);  role says where the result goes:
+ *     RSG_FM_TO_GLOBAL  out16 [batch, h >> l, w >> l, out_ld] (l = the output's level), ReLU if `relu` (the module's later
+ *                       fuse levels read it: grouped launches as before)
+ *     RSG_FM_UP_Y0      1x1, cout 32, one per branch 1..n-1: the up-sampled addends of y0 (stay in LDS, 16-bit as the
+ *                       grouped path stored them)
+ *     RSG_FM_UP_Y1      1x1, cout 64, one per branch 2..n-1: the up-sampled addends of y1
+ *     RSG_FM_DOWN_Y1    the 0 -> 1 conv (k = 3, cout 64), exactly one: its epilogue is the y1 sum
+ * y[0] = relu(x0 + up(t10) + up(t20) + up(t30)), y[1] = relu(round16(conv01(x0)) + x1 + up(t21) + up(t31)) in the
+ * operand order and rounding of rsg_hr_fuse_sum; y1_fold = 1 (two branches only): y[1] = relu(conv01(x0) + x1) in fp32, the
+ * residual epilogue of rsg_conv_igemm (the module's LAST output, whose sum the grouped path folds into the conv).
+ * Results are bit-identical to the grouped launches.  _plan (HOST) validates, chooses the band height (16 or 8 rows of
+ * branch 0 by what fits the 160 KB of LDS), deals the conv jobs to the 16 waves and writes the launch table
+ * (rsg_fuse_module_table_bytes bytes of HOST memory the caller keeps) and launch2 = {grid blocks, LDS bytes}; it fails
+ * (status 1, rsg_last_error) for shapes the kernel does not cover: the caller keeps the grouped path for those. */
+#define RSG_FM_MAX_CONVS 12
+#define RSG_FM_TO_GLOBAL 0
+#define RSG_FM_UP_Y0 1
+#define RSG_FM_UP_Y1 2
+#define RSG_FM_DOWN_Y1 3
+typedef struct rsg_fm_conv {
+    const void* w_packed;
+    const float* bias;
+    void* out16;
+    int32_t out_ld;
+    int32_t src, k, cout, relu, role;
+    int32_t reserved;
+} rsg_fm_conv;
+typedef struct rsg_fuse_module_desc {
+    const void* x[4];
+    void* y[2];
+    int32_t x_ld[4], y_ld[2];
+    int32_t batch, h, w, n_branches, dtype;
+    int32_t y1_fold;
+    int32_t n_convs;
+    int32_t reserved;
+    rsg_fm_conv convs[RSG_FM_MAX_CONVS];
+} rsg_fuse_module_desc;
+size_t rsg_fuse_module_table_bytes(void);
+int rsg_fuse_module_plan(const rsg_fuse_module_desc* d, void* table_host, int32_t* launch2);
+int rsg_fuse_module_run(const void* table_host, int32_t blocks, int32_t lds, int32_t dtype, void* stream);
+/* what _plan decided (tests, logs): info4 = {band rows of branch 0, jobs, LDS offset of the last image, 0}; first17[w] ..
+ * first17[w + 1]: wave w's jobs in jobs4 (96 x {conv, 32-channel tile, first 32-pixel group, groups}; conv 255 = the
+ * barrier between the 1x1 convs whose results stay in LDS and everything that reads them) */
+int rsg_fuse_module_table_jobs(const void* table_host, int32_t* info4, int32_t* first17, uint8_t* jobs4);
+
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) [+ sigmoid] on fp32 NCHW
  * (pose_rsgnet.py:1009-1013) */
 int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t planes, int32_t h, int32_t w,

@@ -50,6 +50,7 @@ EXTRA_FLAGS: Dict[str, List[str]] = {
     "trp.hip": _VGPR_FORM,
     "chain.hip": _VGPR_FORM,
     "group.hip": _VGPR_FORM,
+    "fuse_module.hip": _VGPR_FORM,
     "conv_igemm.hip": _VGPR_FORM,
     # the crop producer reproduces OpenCV's separately rounded double arithmetic: no fused multiply-adds there
     # (-ffp-contract=fast fuses in the backend and ignores `#pragma clang fp contract(off)`)

@@ -38,6 +38,24 @@ class FuseItem(C.Structure):
                 ("low_ld", C.c_int32 * 3), ("reserved", C.c_int32)]
 
 
+class FmConv(C.Structure):
+    """struct rsg_fm_conv (include/rsgnet_hip.h)."""
+    _fields_ = [("w_packed", C.c_void_p), ("bias", C.c_void_p), ("out16", C.c_void_p), ("out_ld", C.c_int32),
+                ("src", C.c_int32), ("k", C.c_int32), ("cout", C.c_int32), ("relu", C.c_int32), ("role", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+FM_MAX_CONVS = 12
+FM_TO_GLOBAL, FM_UP_Y0, FM_UP_Y1, FM_DOWN_Y1 = 0, 1, 2, 3
+
+
+class FuseModuleDesc(C.Structure):
+    """struct rsg_fuse_module_desc (include/rsgnet_hip.h)."""
+    _fields_ = [("x", C.c_void_p * 4), ("y", C.c_void_p * 2), ("x_ld", C.c_int32 * 4), ("y_ld", C.c_int32 * 2),
+                ("batch", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("n_branches", C.c_int32), ("dtype", C.c_int32),
+                ("y1_fold", C.c_int32), ("n_convs", C.c_int32), ("reserved", C.c_int32), ("convs", FmConv * FM_MAX_CONVS)]
+
+
 class ChainItem(C.Structure):
     """struct rsg_chain_item (include/rsgnet_hip.h)."""
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
@@ -106,6 +124,10 @@ SYMBOLS = {
     "rsg_basic_chain_handoff_max_waiters": (C.c_int, []),
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_conv_groupable": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rsg_fuse_module_table_bytes": (C.c_size_t, []),
+    "rsg_fuse_module_plan": (C.c_int, [C.POINTER(FuseModuleDesc), _vp, C.POINTER(C.c_int32)]),
+    "rsg_fuse_module_run": (C.c_int, [_vp, _i, _i, _i, _vp]),
+    "rsg_fuse_module_table_jobs": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _vp]),
     "rsg_group_table_bytes": (C.c_size_t, []),
     "rsg_conv_fuse_group_plan": (C.c_int, [C.POINTER(ConvDesc), _i, C.POINTER(FuseItem), _i, _i, _vp,
                                            C.POINTER(C.c_int32)]),

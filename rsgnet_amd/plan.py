@@ -1312,6 +1312,20 @@ class _BackboneMixin:
                 and last <= 3 and depth.get((last, 0), 0) == last and depth[(last, 0)] == max_depth:
             fold_into = (last, 0)
             ready[last] = -1                              # no separate sum for it
+        # level 0 as ONE launch of row bands (rsg_fuse_module: every conv that reads a branch map, and the sums of outputs 0
+        # and 1); a level-0 conv it does not take (the weight-heavy 2 -> 3 conv) runs one level later, in the grouped
+        # launch of the paths' second convs
+        shift = {ij: 0 for ij in depth}                  # levels a path's convs run later than their index
+        done0 = self._fuse_module(xs, rows, name, cur, depth, outs, fold_into)
+        if done0 is not None:
+            for ij in depth:
+                if ij not in done0:
+                    shift[ij] = 1
+            for i in range(n_out):
+                ready[i] = -1 if i < 2 or ready[i] < 0 else max(d + shift[ij] for ij, d in depth.items() if ij[0] == i)
+            if fold_into == (1, 0):
+                fold_into = None                          # the two-branch module: the band launch folded y1's sum itself
+            max_depth = max(d + shift[ij] for ij, d in depth.items())
         for level in range(max_depth + 1):
             if fold_into is not None and level == max_depth and not any(r == level for r in ready.values()):
                 break                                     # nothing left for a last, sum-only level
@@ -1320,17 +1334,18 @@ class _BackboneMixin:
             # to each other in the launch (their workgroups share the staged lines in L2)
             buckets: Dict[tuple, list] = {}
             for (i, j), dep in depth.items():
-                if level < dep:
+                k = level - shift[(i, j)]                # which conv of the path runs at this level
+                if 0 <= k < dep and not (k == 0 and done0 is not None and (i, j) in done0):
                     fl = rows[i][j]
-                    conv, bnm = (fl[0], fl[1]) if j > i else (fl[level][0], fl[level][1])
-                    relu = False if j > i else (level != dep - 1)
+                    conv, bnm = (fl[0], fl[1]) if j > i else (fl[k][0], fl[k][1])
+                    relu = False if j > i else (k != dep - 1)
                     xin = cur[(i, j)]
                     key = (id(xin.base), xin.coff, xin.C, conv.kernel_size, conv.stride)
-                    buckets.setdefault(key, []).append(((i, j), xin, conv, bnm, relu))
+                    buckets.setdefault(key, []).append(((i, j), xin, conv, bnm, relu, k))
             for items in buckets.values():
-                for ij, xin, conv, bnm, relu in items:
-                    nm = f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{level}")
-                    if ij == fold_into and level == depth[ij] - 1:
+                for ij, xin, conv, bnm, relu, k in items:
+                    nm = f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else f".{k}")
+                    if ij == fold_into and k == depth[ij] - 1:
                         # the sum of the lowest-resolution output rides on the last conv that feeds it: every other
                         # addend (the identity and the shorter strided chains) was finished at an earlier level
                         i = ij[0]
@@ -1354,6 +1369,116 @@ class _BackboneMixin:
                 self._rider_out = rider(outs[last])       # y_last was finished by an EARLIER launch: independent of this one
             self.end_group(f"{name}.fuse.level{level}")
         return outs
+
+    def _fuse_module(self: Plan, xs: List[VT], rows, name: str, cur: dict, depth: dict, outs: list, fold_into):
+        """Record level 0 of a module's fuse layers as one rsg_fuse_module launch (csrc/fuse_module.hip;
+        pose_hrnet.py:190-268).  Fills outs[0], outs[1] and cur[(i, j)] of the level-0 convs it computes and returns their
+        set; None (nothing recorded) when the module is not one it covers -- the caller then records level 0 as before."""
+        nbr = len(xs)
+        if os.environ.get("RSGNET_HIP_FUSE_MODULE", "1") == "0" or not self.use_group or not 2 <= nbr <= 4 or len(rows) != nbr:
+            return None
+        if getattr(self, "_defer_sum0", None) == name:
+            return None                                  # the last module of pose_hrnet: its y0 sum rides on the classifier
+        if any(x.C != 32 << j or x.coff or x.planes or x.H != xs[0].H >> j or x.W != xs[0].W >> j for j, x in enumerate(xs)):
+            return None
+        if fold_into not in (None, (1, 0), (nbr - 1, 0)):
+            return None
+        # the convs of level 0: (i, j) -> (conv, bn, k, role)
+        take = {}
+        for (i, j), dep in depth.items():
+            fl = rows[i][j]
+            conv, bnm = (fl[0], fl[1]) if j > i else (fl[0][0], fl[0][1])
+            if conv.bias is not None or conv.in_channels != 32 << j:
+                return None
+            if j > i:                                    # 1x1, BatchNorm, up-sampled by the reader
+                if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.out_channels != 32 << i:
+                    return None
+                role = hip.FM_UP_Y0 if i == 0 else hip.FM_UP_Y1 if i == 1 else hip.FM_TO_GLOBAL
+                take[(i, j)] = (conv, bnm, 1, role, False)
+            else:
+                if conv.kernel_size != (3, 3) or conv.stride != (2, 2) or conv.padding != (1, 1):
+                    return None
+                if j > 1:
+                    continue                             # 2 -> 3 (590 KB of weights for 12 pixels of a band): grouped launch
+                if dep > 1 and conv.out_channels != 32 << j:
+                    return None
+                role = hip.FM_DOWN_Y1 if (i, j) == (1, 0) else hip.FM_TO_GLOBAL
+                take[(i, j)] = (conv, bnm, 3, role, dep > 1)
+        # a conv left out runs one level later: its path must end there, and a folded sum must still find it finished
+        for ij, dep in depth.items():
+            if ij not in take and (dep != 1 or (fold_into is not None and fold_into[0] == ij[0] and depth[fold_into] < 3)):
+                return None
+        if (1, 0) not in take or len(take) > hip.FM_MAX_CONVS:
+            return None
+        y1_fold = fold_into == (1, 0)
+        if y1_fold and nbr != 2:
+            return None
+        H, W, B, dt, lib = xs[0].H, xs[0].W, self.batch, self.dtype, self.lib
+        packed, glob, ys = {}, {}, []
+
+        def desc(fake: bool) -> "hip.FuseModuleDesc":
+            d = hip.FuseModuleDesc()
+            for j, x in enumerate(xs):
+                d.x[j] = 0x10000 if fake else x.ptr()
+                d.x_ld[j] = x.ld
+            for i in range(2):
+                d.y[i] = 0x10000 if fake else ys[i].ptr()
+                d.y_ld[i] = 32 << i
+            d.batch, d.h, d.w, d.n_branches, d.dtype, d.y1_fold = B, H, W, nbr, dt, 1 if y1_fold else 0
+            d.n_convs = len(take)
+            for c, (ij, (conv, bnm, k, role, relu)) in enumerate(take.items()):
+                e = d.convs[c]
+                e.w_packed = 0x10000 if fake else packed[ij][0].data_ptr()
+                e.bias = 0x10000 if fake else packed[ij][1].data_ptr()
+                e.src, e.k, e.cout, e.relu, e.role = ij[1], k, conv.out_channels, 1 if relu else 0, role
+                if role == hip.FM_TO_GLOBAL:
+                    e.out16 = 0x10000 if fake else glob[ij].ptr()
+                    e.out_ld = conv.out_channels
+            return d
+
+        nbytes = lib.rsg_fuse_module_table_bytes()
+        launch2 = (C.c_int32 * 2)()
+        probe = np.zeros(nbytes, np.uint8)
+        if any(conv.out_channels % 32 for conv, *_ in take.values()) or \
+                lib.rsg_fuse_module_plan(C.byref(desc(True)), probe.ctypes.data, launch2):
+            return None                                  # a shape the band kernel does not cover (LDS): grouped launches
+        for ij, (conv, bnm, k, role, relu) in take.items():
+            sc, sh = self.bn_fold(bnm)
+            wp, bo, _i, _o = self.pack_conv(conv.weight, sc, sh, None)
+            packed[ij] = (wp, bo)
+        y0 = self.new(H, W, 32, name=f"{name}.fuse.0")
+        y1 = self.new(H >> 1, W >> 1, 64, name=f"{name}.fuse.1.0.0+sum" if y1_fold else f"{name}.fuse.1")
+        ys += [y0, y1]
+        for ij, (conv, bnm, k, role, relu) in take.items():
+            if role == hip.FM_TO_GLOBAL:
+                lvl = ij[1] + (1 if k == 3 else 0)
+                glob[ij] = self.new(H >> lvl, W >> lvl, conv.out_channels,
+                                    name=f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else ".0"))
+
+        def make():
+            table = np.zeros(nbytes, np.uint8)
+            l2 = (C.c_int32 * 2)()
+            hip.check(lib.rsg_fuse_module_plan(C.byref(desc(False)), table.ctypes.data, l2), name)
+            self._keep.append(table)                     # the table is the kernel ARGUMENT: read from host memory at every launch
+            tptr, blocks, lds = table.ctypes.data, l2[0], l2[1]
+
+            def launch(stream):
+                rc = lib.rsg_fuse_module_run(tptr, blocks, lds, dt, stream)
+                if rc:
+                    hip.check(rc, name)
+            return launch
+
+        self.custom(f"{name}.fuse.band", list(xs), [y0, y1, *glob.values()], make)
+        fl = 0
+        for ij, (conv, bnm, k, role, relu) in take.items():
+            lvl = ij[1] + (1 if k == 3 else 0)
+            fl += 2 * B * (H >> lvl) * (W >> lvl) * conv.out_channels * conv.in_channels * k * k
+        self.flops += fl
+        self.conv_log.append(dict(name=f"{name}.fuse.band", flops=float(fl), band_convs=[f"{i}.{j}" for i, j in take]))
+        outs[0], outs[1] = y0, y1
+        for ij, v in glob.items():
+            cur[ij] = v
+        return set(take)
 
     def _record_backbone(self: Plan, m, H: int, W: int) -> List[VT]:
         if os.environ.get("RSGNET_HIP_S2D", "1") != "0" and H % 2 == 0 and W % 2 == 0:

@@ -1,0 +1,107 @@
+"""rsg_fuse_module (csrc/fuse_module.hip): level 0 of every HighResolutionModule's fuse layers as one launch of row bands,
+against the grouped launches it replaces (csrc/group.hip) -- the reference's `fuse_layers` / `HighResolutionModule.forward`
+(/root/reference/lib/models/pose_hrnet.py:190-268).  The bar is bit-identity of every 16-bit map either path stores."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rsgnet_amd import hip
+from tests.util import load_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _plans(model, batch, **env):
+    """(plan with the band launch, plan with the grouped launches) of one model."""
+    out = []
+    for v in ("1", "0"):
+        old = {k: os.environ.get(k) for k in ("RSGNET_HIP_FUSE_MODULE", *env)}
+        os.environ["RSGNET_HIP_FUSE_MODULE"] = v
+        os.environ.update(env)
+        try:
+            out.append(model._build_plan(batch, torch.device(DEV)))
+        finally:
+            for k, o in old.items():
+                if o is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = o
+    return out
+
+
+def _fuse_maps(plan):
+    return sorted({v.name for w in plan._op_writes for v in w if ".fuse." in v.name and "band" not in v.name})
+
+
+@pytest.mark.parametrize("tag,dtype,batch", [("hrnet_w32_256x192", "fp16", 3), ("hrnet_w32_256x192", "bf16", 2),
+                                             ("rsgnet_w32_256x192_crowdpose", "fp16", 2)])
+def test_fuse_module_equals_the_grouped_launches(tag, dtype, batch):
+    """Every fuse map of every module (outputs, and the intermediate maps of the strided chains) and the model's outputs:
+    the same bits from the band launch + the remaining grouped levels as from the grouped launches alone.  Batch 3 / 2:
+    bands of different pictures share a workgroup index range; 256x192 crops: 4 bands of 16 rows per picture."""
+    from rsgnet_amd.weights import synth_input
+    cfg, model, sd, x, gold = load_case(tag)
+    model = model.to(DEV)
+    model.compute_dtype = dtype
+    x = synth_input(batch, (192, 256), 11).to(DEV)
+    new, old = _plans(model, batch)
+    names_new = [n for n, _ in new.ops]
+    assert any(n.endswith(".fuse.band") for n in names_new), names_new
+    assert not any(n.endswith(".fuse.band") for n, _ in old.ops)
+    assert len(new.ops) < len(old.ops) + 2          # (the two-branch module's transition conv gets a launch of its own)
+    maps = [n for n in _fuse_maps(new) if n in set(_fuse_maps(old))]
+    assert len(maps) >= 20, maps
+    with torch.no_grad():
+        a = new.run_with_taps(x, maps)
+        ya = [t.clone() for t in _outputs(new)]
+        b = old.run_with_taps(x, maps)
+        yb = [t.clone() for t in _outputs(old)]
+    torch.cuda.synchronize()
+    bad = [n for n in maps if not torch.equal(a[n].view(torch.int16), b[n].view(torch.int16))]
+    for n in bad[:6]:
+        d = (a[n].float() - b[n].float()).abs()
+        print(f"   {n}: {int((d > 0).sum())} of {d.numel()} differ, max {float(d.max()):.3e}, first at "
+              f"{[int(v) for v in (d > 0).nonzero()[0]]}, nan {int(torch.isnan(a[n].float()).sum())}")
+    assert not bad, bad
+    for p, q in zip(ya, yb):
+        assert torch.equal(p, q)
+
+
+def _outputs(plan):
+    outs = []
+    for v in vars(plan).values():
+        if type(v).__name__ == "OutSlot":
+            outs.append(v.static)
+    assert outs
+    return outs
+
+
+def test_fuse_module_replays_inside_the_graph_and_on_two_streams():
+    """The captured graph (what a forward runs) gives the eager pass's bits, twice, and on a side stream's plan."""
+    cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
+    model = model.to(DEV)
+    x = x.to(DEV)
+    with torch.no_grad():
+        y1 = model(x).clone()
+        y2 = model(x).clone()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            y3 = model(x).clone()
+        s.synchronize()
+    torch.cuda.synchronize()
+    plan = model.plan_for(x)
+    assert any(n.endswith(".fuse.band") for n, _ in plan.ops)
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
+    os.environ["RSGNET_HIP_FUSE_MODULE"] = "0"
+    try:
+        model.invalidate_plan()
+        with torch.no_grad():
+            y0 = model(x).clone()
+    finally:
+        os.environ.pop("RSGNET_HIP_FUSE_MODULE", None)
+        model.invalidate_plan()
+    assert torch.equal(y0, y1)
