@@ -55,6 +55,7 @@ struct FmArgs {
     int off_x[4], rp[4], halo[4];
     // staging slot s of a thread: chunk (slot_q[s] rows, slot_m[s] chunks) + its own (tid / rowc, tid % rowc) of branch slot_br[s]
     int slot_br[FM_SLOTS], slot_q[FM_SLOTS], slot_m[FM_SLOTS];
+    int pre_total, pre_first[FM_MAX_CONVS];   // weight prefetch: 128-byte lines of all convs / first line of conv c (0 lines = off)
     int first[FM_WAVES + 1];         // wave w runs job[first[w] .. first[w + 1]): phase A jobs, FM_SYNC, phase B jobs
     FmConv conv[FM_MAX_CONVS];
     FmJob job[2 * FM_MAX_JOBS];
@@ -243,6 +244,27 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
     const int blk = rsg_xcd_tile(blockIdx.x, gridDim.x);        // the bands of a picture (shared halo rows) on one XCD
     const int b = blk / bands, band = blk - b * bands;
 
+    // ---- 0. weight prefetch: nothing of the module's fuse weights (0.3 - 0.6 MB) is cached when its turn comes, every
+    // workgroup streams all of them, and the workgroups run in lockstep -- each fragment's first request would come from all
+    // 256 CUs at once and wait for HBM behind the staging traffic (stamps: both conv phases ran at the ~27 B/clk per CU that
+    // a 4-6 deep fragment ring gets at an HBM miss's latency).  The first workgroups touch one dword per 128-byte line before
+    // anything else is requested (chain.hip, chain_prefetch_weights); the loads are waited for behind the staging barrier.
+    unsigned pf = 0;
+    if (p.pre_total) {
+        // line f of the concatenated weight tensors belongs to thread f / grid of workgroup f % grid: ~20 loads per workgroup
+        const int f = blockIdx.x + gridDim.x * tid;
+        if (f < p.pre_total) {
+            int c = 0;
+#pragma unroll
+            for (int k = 1; k < FM_MAX_CONVS; ++k) c += (k < p.n_conv && f >= p.pre_first[k]) ? 1 : 0;
+            const char* w = nullptr;
+            int base = 0;
+#pragma unroll
+            for (int k = 0; k < FM_MAX_CONVS; ++k)
+                if (k == c) { w = reinterpret_cast<const char*>(p.conv[k].w); base = p.pre_first[k]; }
+            pf = *reinterpret_cast<const unsigned*>(w + (size_t)(f - base) * 128);
+        }
+    }
     // ---- 1. every byte of the band in one round of requests -----------------------------------------------------------
     // A row of EVERY branch is W * 4 chunks of 16 B (C doubles as W halves).  Slot s of a thread is chunk
     // (slot_q[s] rows + slot_m[s] chunks) + (tid / rowc, tid % rowc) of branch slot_br[s]: the host's table, so the slots
@@ -285,6 +307,7 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
             if (lo[s] >= 0) *reinterpret_cast<uint4*>(smem + lo[s]) = v[s];
     }
     __syncthreads();
+    asm volatile("" ::"v"(pf));                          // the prefetch loads end here
     FM_STAMP(1);
 
     // ---- 2. this wave's jobs: phase A (1x1 convs into LDS), FM_SYNC, phase B ------------------------------------------------
@@ -332,6 +355,7 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
 // host
 // ---------------------------------------------------------------------------------------------------------------------------
 extern "C" size_t rsg_fuse_module_table_bytes(void) { return sizeof(FmArgs); }
+int g_fm_prefetch = 1;                 // rsg_tune("fm_prefetch", 0|1)
 
 static int fm_row_pitch(int slots, int ps, int out_w) {
     // row pitch == (out_w * ps / 2) (mod 128 B): an output row of a stride-2 conv ends out_w slots on and the next one starts
@@ -482,6 +506,11 @@ extern "C" int rsg_fuse_module_plan(const rsg_fuse_module_desc* d, void* table_h
             for (const FmJob& j : pb[w]) a.job[k++] = j;
         }
         a.first[FM_WAVES] = k;
+    }
+    if (g_fm_prefetch) {
+        int n = 0;
+        for (int c = 0; c < d->n_convs; ++c) { a.pre_first[c] = n; n += (a.conv[c].cout >> 5) * a.conv[c].ks * 8; }
+        a.pre_total = n;
     }
     launch2[0] = d->batch * (d->h / a.R0);
     launch2[1] = lds;

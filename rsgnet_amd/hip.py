@@ -227,7 +227,7 @@ def lib() -> C.CDLL:
                          ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit"), ("RSGNET_HIP_CHAIN_PREFETCH", b"chain_prefetch"),
                          ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_CONV_SPREAD", b"conv_spread"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
                          ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual"),
-                         ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows")):
+                         ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows"), ("RSGNET_HIP_FM_PREFETCH", b"fm_prefetch")):
             if os.environ.get(env):
                 if l.rsg_tune(key, int(os.environ[env])):       # the library validates the value
                     raise RuntimeError(f"{env}={os.environ[env]}: {l.rsg_last_error().decode(errors='replace')}")
