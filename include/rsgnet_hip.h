@@ -23,6 +23,12 @@ extern "C" {
 enum { RSG_F16 = 0, RSG_BF16 = 1 };
 
 const char* rsg_last_error(void);
+/* The version of THIS header's entry points and structs; rsg_version() returns the one the library was built with, and a
+ * caller compares the two before its first call (rsgnet_amd/hip.py does).  Bumped with every incompatible change:
+ *   1  rounds 1-3
+ *   2  round 5 (covers round 4's changes, which shipped under 1: rsg_trp_relation_mse[_dense] gained a workspace pointer,
+ *      rsg_chain_item lost its tail fields, rsg_fuse_band and the chain tails were removed; round 5 adds rsg_fuse_module) */
+#define RSG_ABI_VERSION 2
 int rsg_version(void);
 /* tuning knobs for experiments (process-wide): "chain_max_ni" = images per workgroup cap of the chain kernel;
  * "conv_spread" = n: a conv whose grid would have fewer than n workgroups is re-tiled into more, smaller ones (default 128,

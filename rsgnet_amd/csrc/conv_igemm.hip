@@ -20,7 +20,7 @@
 
 thread_local char g_rsg_err[512] = "";
 extern "C" const char* rsg_last_error(void) { return g_rsg_err; }
-extern "C" int rsg_version(void) { return 1; }
+extern "C" int rsg_version(void) { return RSG_ABI_VERSION; }
 
 
 #ifdef RSG_CONV_STAMPS

@@ -316,7 +316,10 @@ __global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
     for (int r = 0; r < 16; ++r) ydx[r] = ydg[r] = 0.f;
     const float pq = a.p ? a.p[boff + q0 + n] : 0.f;
     const float c2 = (a.p || a.t) ? 2.f * a.coef[b] : 0.f;
-    const float* const trow = a.t ? a.t + boff * a.S + q0 + n : nullptr;      // + key * S: row `key`, this lane's query column
+    // dense target T [B,S,S]: d/dX of sum_ij (R_ij - T_ij)^2 with R symmetric takes (T_ij + T_ji) / 2 -- both entries are read
+    // (the reference's p p^T is symmetric, then this is T_ij exactly; any other target gets its true gradient: advisor, round 4)
+    const float* const trow = a.t ? a.t + boff * a.S + q0 + n : nullptr;      // + key * S: T[key][query]
+    const float* const tcol = a.t ? a.t + (boff + q0 + n) * a.S : nullptr;    // + key:     T[query][key]
 
     __shared__ uint4 tk[2][KT][3][32 * RSK];          // X, G, dE rows of the key tile
     __shared__ uint4 tg[2][KT][2][C * 5];             // X^T, dE^T of the key tile
@@ -360,8 +363,7 @@ __global__ void __launch_bounds__(256) trp_backward_kernel(const TrpBwdArgs a) {
         for (int r = 0; r < 16; ++r) {
             const float R = sigmoid_f32(xa[r]);
             const int kk = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            // dense target: T_ji for T_ij (the reference's target p p^T is symmetric; dA + dA^T takes (T_ij + T_ji) / 2)
-            const float tv = trow ? trow[(size_t)(j0 + kk) * a.S] : pq * pk[kk];
+            const float tv = trow ? 0.5f * (trow[(size_t)(j0 + kk) * a.S] + tcol[j0 + kk]) : pq * pk[kk];
             const float t = x1[r] + x2[r] + c2 * (R - tv);
             pr[r] = R;
             mr[r] = R * (1.f - R) * t;

@@ -193,6 +193,9 @@ SYMBOLS = {
 }
 
 _lib: Optional[C.CDLL] = None
+# include/rsgnet_hip.h, RSG_ABI_VERSION: bumped with every incompatible change of an entry point's arguments or of a struct
+# (2 = round 5: rsg_trp_relation_mse's workspace argument and the slimmer rsg_chain_item of round 4, rsg_fuse_module)
+ABI_VERSION = 2
 
 
 def lib_path() -> str:
@@ -212,13 +215,21 @@ def lib() -> C.CDLL:
         # the in-tree library must be the build of the sources in the tree (a failed rebuild leaves the previous .so behind,
         # and a measurement or a green test of THAT library says nothing about the sources); a library named through
         # RSGNET_HIP_LIB is another build on purpose (A/B runs)
-        if not os.environ.get("RSGNET_HIP_LIB") and os.environ.get("RSGNET_HIP_ALLOW_STALE") != "1" and _build.stale():
+        # (name="": the library that is CHECKED is the one that is LOADED, whatever RSGNET_HIP_BUILD_NAME says -- that
+        # variable names the variant `python -m rsgnet_amd.build` writes, for RSGNET_HIP_LIB to pick up)
+        if not os.environ.get("RSGNET_HIP_LIB") and os.environ.get("RSGNET_HIP_ALLOW_STALE") != "1" and _build.stale(name=""):
             if os.environ.get("RSGNET_HIP_NO_AUTOBUILD") == "1":
                 raise RuntimeError(
-                    f"{path} was not built from the sources, flags and compiler in this tree ({_build.describe()}): "
+                    f"{path} was not built from the sources, flags and compiler in this tree ({_build.describe('')}): "
                     "run `python -m rsgnet_amd.build` (RSGNET_HIP_ALLOW_STALE=1 loads it anyway)")
-            _build.build()          # rebuilds (about 90 s) or raises hipcc's error: never the previous build in silence
+            # rebuilds (about 90 s) or raises hipcc's error: never the previous build in silence.  Ranks / workers that get
+            # here together are serialised by build()'s lock file; all but the first find a fresh library behind it.
+            _build.build(name="")
         l = C.CDLL(path)
+        l.rsg_version.restype = C.c_int
+        if l.rsg_version() != ABI_VERSION:
+            raise RuntimeError(f"{path} speaks C-ABI version {l.rsg_version()}, this package binds version {ABI_VERSION} "
+                               "(include/rsgnet_hip.h): rebuild with `python -m rsgnet_amd.build --force`")
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)      # AttributeError if the .so does not export it
             fn.restype = res

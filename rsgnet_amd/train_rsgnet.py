@@ -235,9 +235,15 @@ def graphed_head(model, feat16: torch.Tensor, relation_target: Optional[torch.Te
     were before the first real step.  (Round 3 recorded a segmentation fault in hipStreamEndCapture here; it does not
     occur with this head -- tools/head_capture_probe.py, profiles/r04_head_capture.txt.  Slower than the eager head at
     batch 8 and 32 on this runtime, hence opt-in.)"""
-    key = (tuple(feat16.shape), feat16.dtype, feat16.device,
+    # the captured graphs freeze more than the input geometry: the mode (train-mode BatchNorm updates its buffers inside the
+    # graph) and WHICH tensors are the parameters / which of them take gradients (a replaced or frozen parameter would be
+    # read, or have its gradient written, through the pointer captured for the old one) -- advisor, round 4
+    params = tuple((id(q), q.data_ptr(), q.requires_grad) for q in model.parameters())
+    key = (tuple(feat16.shape), feat16.dtype, feat16.device, bool(model.training), hash(params),
            None if relation_target is None else (tuple(relation_target.shape), relation_target.dtype))
     cache = model.__dict__.setdefault("_head_graphs", {})
+    for k in [k for k in cache if k[:3] == key[:3] and k != key]:
+        del cache[k]                                  # a stale capture of the same geometry holds its pools for nothing
     fn = cache.get(key)
     if fn is None:
         bufs = _head_buffers(model)

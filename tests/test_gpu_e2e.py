@@ -51,6 +51,7 @@ def _rms(got, ref):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
+BF16_EMU_BAR_W48 = (0.40, 0.07)   # HRNet-W48 384x288 at batch 32 (round 5: measured below, bars 2 x)
 BF16_EMU_BAR = (0.30, 0.052)       # x sigma: max-abs, rms of the bf16 path against the bf16-emulating oracle (2 x measured)
 
 
@@ -140,6 +141,28 @@ def test_hrnet_w32_random_init_regime_meets_1e3():
     assert e < ABS_TOL
 
 
+@pytest.mark.parametrize("joints", [17, 14], ids=["coco17", "crowdpose14"])
+def test_rsgnet_random_init_regime_meets_1e3(joints):
+    """north_star's tolerance on the path it names (HRNet backbone -> TRP -> SGM heat maps), in the regime BASELINE
+    configs[0] states it for: random-init RSGNet-W32 256x192 (what the reference holds after get_pose_net(cfg,
+    is_train=False); pose_rsgnet.py:955-1021, 1023-1063), batch 4, all three score maps against the fp32 CPU forward
+    within 1e-3 max-abs -- the limb maps as the probabilities the reference returns (torch.sigmoid, :1013)."""
+    from rsgnet_amd import make_cfg, models
+    from rsgnet_amd.weights import synth_input, synth_state_dict
+    cfg = make_cfg("pose_rsgnet", 32, (192, 256), joints)
+    model = models.pose_rsgnet.get_pose_net(cfg, False)
+    sd = synth_state_dict(model.state_dict(), 0, regime="init")
+    model.load_state_dict(sd)
+    x = synth_input(4, (192, 256), 3)
+    ref = po.rsgnet_forward(sd, cfg, x, want_scores=False)
+    with torch.no_grad():
+        out = model.eval().cuda()(x.cuda())
+    for nm, got, r in zip(("multi", "kpt", "limbs"), out[:3], ref[:3]):
+        assert got.shape == r.shape and got.dtype == torch.float32
+        e = _stats(f"random-init RSGNet J={joints} {nm}", got.cpu(), r.numpy())
+        assert torch.isfinite(got).all() and e < ABS_TOL, (nm, e)
+
+
 def test_hrnet_w48_384x288_golden():
     """BASELINE configs[2] backbone (channels 48/96/192/384, maps 96x72 ... 12x9): the 12-wave LDS-resident chains
     (csrc/chain.hip, the 48-channel branch on csrc/chain48.h), 48-channel maps in 64-channel buffers."""
@@ -194,13 +217,29 @@ def test_full_size_batches_of_the_baseline_configs(name, batch, sample):
     bar = {"hrnet_w32_256x192": EMU_BARS["hrnet_w32_256x192"]["heatmaps"], "hrnet_w48_384x288": 0.06}[name]
     assert e_emu < bar * sd_ref, e_emu / sd_ref
     assert e_ref < REL_TOL * sd_ref, e_ref / sd_ref
+    # (d) the dtype configs[1] / configs[2] NAME: the bf16 plan of the same full batch -- quarters == whole bit for bit, and the
+    # sampled crops against the oracle that rounds to bf16 where the kernels do, at the 2-crop test's bars (W32; W48, 2 x
+    # what round 5 measured) and the bf16 floor's bar against fp32
+    model.compute_dtype = "bf16"
+    model.invalidate_plan()
+    with torch.no_grad():
+        fb = model(xb.cuda()).clone()
+        pb = torch.cat([model(xb[i * q:(i + 1) * q].cuda()).clone() for i in range(4)])
+    assert torch.isfinite(fb).all() and torch.equal(fb, pb)
+    emu_b = po.hrnet_forward(sd, cfg, xs, ctx=po.Ctx(sd, emulate="bf16")).numpy()
+    got_b = fb[list(sample)].cpu().numpy()
+    e_b = _stats(f"{name} bf16 batch {batch}, crops {sample} vs bf16-emulating oracle", got_b, emu_b)
+    e_bf = _stats(f"{name} bf16 batch {batch}, crops {sample} vs fp32 oracle", got_b, ref)
+    bars = {"hrnet_w32_256x192": BF16_EMU_BAR, "hrnet_w48_384x288": BF16_EMU_BAR_W48}[name]
+    assert e_b < bars[0] * sd_ref and _rms(got_b, emu_b) < bars[1] * sd_ref, (e_b / sd_ref, _rms(got_b, emu_b) / sd_ref)
+    assert e_bf < 0.32 * sd_ref, e_bf / sd_ref
 
 
-def test_full_size_batch_of_rsgnet_w32():
-    """RSGNet-W32 256x192 at 64 crops (the batch bench.py times for the RSGNet configs; TRP at S = 3072 over a full grid):
-    quarters equal the whole bit for bit on all three score maps, and two sampled crops agree with the fp32 oracle at
-    the golden test's bars (limb maps on their logits)."""
-    name = "rsgnet_w32_256x192_coco"
+@pytest.mark.parametrize("name", ["rsgnet_w32_256x192_coco", "rsgnet_w32_256x192_crowdpose"])
+def test_full_size_batch_of_rsgnet_w32(name):
+    """RSGNet-W32 256x192 at 64 crops, COCO (17 joints) and CrowdPose (14 joints, BASELINE configs[4]) -- the batch bench.py
+    times for the RSGNet configs; TRP at S = 3072 over a full grid: quarters equal the whole bit for bit on all three score
+    maps, and two sampled crops agree with the fp32 oracle at the golden test's bars (limb maps on their logits)."""
     cfg, model, sd, x, gold = load_case(name)
     from rsgnet_amd.weights import synth_input
     xb = synth_input(64, TAGS[name][2], 23)

@@ -1172,6 +1172,19 @@ def test_trp_dense_relation_target_equals_the_factored_one_and_autograd():
     em = float((mse2.double() - M.detach()).abs().max()) / float(M.abs().max())
     print(f"  dense relation target: dX err {ex:.2e}  dG err {eg:.2e}  mse err {em:.2e}")
     assert ex < 2 * 2.0 ** -7 and eg < 2 * 2.0 ** -7 and em < 1e-4
+    # (b') a target that is NOT symmetric: the gradient takes (T_ij + T_ji) / 2, the loss value T itself (advisor, round 4:
+    # the kernel read T_ji alone, exact only for the reference's symmetric p p^T)
+    t3 = torch.rand(B, S, S, generator=g)
+    dx3, dg3, mse3 = run(dev(t3), True)
+    X, G = x.double().requires_grad_(True), gg.double().requires_grad_(True)
+    R = torch.sigmoid(X @ X.transpose(1, 2))
+    M = ((t3.double() - R) ** 2).mean(dim=(1, 2))
+    wx, wg = torch.autograd.grad((de.double() * (R @ G)).sum() + (dmse.double() * M).sum(), [X, G])
+    ex = float((dx3.double() - wx).abs().max()) / float(wx.abs().max())
+    eg = float((dg3.double() - wg).abs().max()) / float(wg.abs().max())
+    em = float((mse3.double() - M.detach()).abs().max()) / float(M.abs().max())
+    print(f"  asymmetric dense relation target: dX err {ex:.2e}  dG err {eg:.2e}  mse err {em:.2e}")
+    assert ex < 2 * 2.0 ** -7 and eg < 2 * 2.0 ** -7 and em < 1e-4
     # (c) the autograd node with either form of the target
     wgt, bgt = (torch.randn(Cc, Cc, 1, 1, generator=g) * 0.2).to(DEV), (torch.randn(Cc, generator=g) * 0.1).to(DEV)
     outs = []
