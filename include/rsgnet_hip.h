@@ -217,11 +217,18 @@ typedef struct rsg_chain_item {
     void* workspace;               /* rsg_basic_chain_workspace_bytes(c,h,w,nlayers,batch) bytes, own per item */
     void* done_flags;              /* NULL, or 3 x int32 per workgroup (see above) */
     const void* wait_flags;        /* NULL, or the done_flags of an earlier item */
-    int32_t reserved[2];           /* 0 */
+    int32_t split_rows;            /* 1: a map whose images fit LDS whole is cut into TWO row tiles all the same (halo = nlayers
+                                      rows, recomputed): 1.5x the work of a 32-row map's 8-layer chain on twice the CUs, for
+                                      the chain that is a launch's critical path; rsg_basic_chain_supported_split says whether
+                                      the shape allows it.  0: the library's own choice */
+    int32_t reserved;              /* 0 */
     int32_t in_ld, out_ld;         /* pixel stride (elements) of in / out; 0 = dense (= c).  Only c = 48 takes other strides
                                       (HRNet-W48 keeps its 48-channel maps in 64-channel buffers) */
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
+/* rsg_basic_chain_supported for an item with split_rows = 1: 1 and info4 = {rows per tile, 1, LDS bytes, workgroups} when
+ * the map can run as two row tiles, else 0 */
+int rsg_basic_chain_supported_split(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch, int32_t* info4);
 /* Sticky error word of the hand-off: the number of polls that gave up since the library was loaded on the current
  * device.  An increase means a consumer chain staged without its producer's data: that launch's output is wrong and
  * the flag words it was waiting on must be re-zeroed by the caller before the next launch.

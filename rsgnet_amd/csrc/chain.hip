@@ -769,7 +769,7 @@ static chain_fn chain_lookup(int C, int npix, int dual) {
 // Picks (tile rows, images per workgroup) for a chain; returns 0 when the shape is supported.
 // ni_want: images per workgroup asked for in whole-image mode (0 = the process-wide default, rsg_tune)
 static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs& a, int& lds, int& nthr,
-                          bool grouped = false, int ni_want = 0) {
+                          bool grouped = false, int ni_want = 0, bool force_split = false) {
     const ChainCfg* cfg = nullptr;
     for (const ChainCfg& c : (grouped ? kChainGroupCfgs : kChainCfgs)) if (c.C == C) cfg = &c;
     if (ni_want < 1) ni_want = g_chain_max_ni;
@@ -789,8 +789,12 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     // Same-visit A/B at batch 32: neutral (5.152 vs 5.153 ms per step) while the 48-channel chain made a stage-4 launch
     // work-bound; with that branch on the 16x16x32 MFMA (chain48.h) the 384-channel workgroups are the critical path again
     // and the split pays: 4.545 -> 4.449 ms.
-    const bool split_rows = g_chain_split_rows && C == 384 && nlayers == 2 && H >= 8 && batch * 4 <= 256 &&
-                            (H / 2 + nlayers) * W <= 96;
+    // (rsg_chain_item.split_rows, round 5: the same for the whole-image 32x24x64 chain of the two-branch module -- 8 layers,
+    // 72 us on 64 of 256 CUs while the launch's other branch is done after 60; two row tiles with an 8-row halo each hold
+    // 24 of the 32 rows)
+    const bool split_rows = (g_chain_split_rows && C == 384 && nlayers == 2 && H >= 8 && batch * 4 <= 256 &&
+                             (H / 2 + nlayers) * W <= 96) ||
+                            (force_split && H >= 16 && H / 2 + nlayers < H);
     if (!split_rows && H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
         int ni = cap / (H * W);
         while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > ni_want)) --ni;
@@ -870,6 +874,15 @@ static size_t chain_ws_bytes(int C, const ChainArgs& a, int batch, int nlayers, 
     return (size_t)blocks * nthr * kChainMaxNT * 32;
 }
 
+extern "C" int rsg_basic_chain_supported_split(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch, int32_t* info4) {
+    ChainArgs a;
+    int lds = 0, nthr = 0;
+    if (nlayers < 2 || nlayers > RSG_CHAIN_MAX_LAYERS || (nlayers & 1)) return 0;
+    if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr, true, 0, true) || a.tiles_y != 2) return 0;
+    if (info4) { info4[0] = a.TH; info4[1] = a.NI; info4[2] = lds; info4[3] = ceil_div(batch, a.NI) * a.tiles_y; }
+    return 1;
+}
+
 extern "C" size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch) {
     ChainArgs a;
     int lds = 0, nthr = 0;
@@ -926,7 +939,8 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         if (it.nlayers < 2 || it.nlayers > RSG_CHAIN_MAX_LAYERS || (it.nlayers & 1)) RSG_FAIL("chain_group: nlayers=%d", it.nlayers);
         ChainArgs& a = g.a[i];
         int lds = 0, nthr = 0;
-        if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr, true, it.images_per_workgroup))
+        if (it.split_rows & ~1) RSG_FAIL("chain_group: item %d: split_rows = %d (0 or 1)", i, it.split_rows);
+        if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr, true, it.images_per_workgroup, it.split_rows != 0))
             RSG_FAIL("chain_group: unsupported shape C=%d %dx%d L=%d", it.c, it.h, it.w, it.nlayers);
         if ((!it.workspace || ((uintptr_t)it.workspace & 15))) RSG_FAIL("chain_group: item %d needs a workspace", i);
         if ((long long)it.batch * it.h * it.w * it.c * 2 >= (1LL << 31))

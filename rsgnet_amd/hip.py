@@ -61,7 +61,7 @@ class ChainItem(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
                 ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
                 ("w", C.c_int32), ("c", C.c_int32), ("images_per_workgroup", C.c_int32), ("workspace", C.c_void_p),
-                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("reserved", C.c_int32 * 2),
+                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("split_rows", C.c_int32), ("reserved", C.c_int32),
                 ("in_ld", C.c_int32), ("out_ld", C.c_int32)]
 
 
@@ -123,6 +123,7 @@ SYMBOLS = {
     "rsg_chain_handoff_timeouts_async": (C.c_int, [_vp, _vp]),
     "rsg_basic_chain_handoff_max_waiters": (C.c_int, []),
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
+    "rsg_basic_chain_supported_split": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_conv_groupable": (C.c_int, [C.POINTER(ConvDesc)]),
     "rsg_fuse_module_table_bytes": (C.c_size_t, []),
     "rsg_fuse_module_plan": (C.c_int, [C.POINTER(FuseModuleDesc), _vp, C.POINTER(C.c_int32)]),

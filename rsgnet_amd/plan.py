@@ -415,11 +415,12 @@ class Plan:
             n0 = layers[0][0].numel()
             layers = [(allw[k * n0:(k + 1) * n0], b) for k, (_, b) in enumerate(layers)]
             out = self.new(x.H, x.W, x.C, name=name)
+            split = bool(item[2]) if len(item) > 2 else False
             cc = blocks[0].conv1.in_channels             # 48 of a 64-channel buffer for HRNet-W48's first branch
             # position k of every grouped launch shares one scratch buffer per size; it is named among the op's
             # writes, so every scheduler (lanes, explicit graph) keeps the sharers in order
             ws = self._chain_workspace(len(subs), x, len(layers), cc)
-            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, c=cc))
+            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, c=cc, split=split))
             outs.append(out)
             self.flops += 2 * self.batch * x.H * x.W * cc * cc * 9 * len(layers)
         self._record(dict(kind="chain_group", subs=subs, name=name),
@@ -749,6 +750,7 @@ class Plan:
             it.bias = C.cast(bps, C.POINTER(C.c_void_p))
             it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, cc
             it.workspace = d["ws"].data_ptr() if d["ws"] is not None else None
+            it.split_rows = 1 if d.get("split") else 0
             log.append((cc, x.H, x.W, n))
         for k, d in enumerate(subs):
             if d.get("after") is not None:
@@ -772,7 +774,8 @@ class Plan:
             info = (C.c_int32 * 4)()
             blocks = []
             for it in items:
-                self.lib.rsg_basic_chain_supported(it.c, it.h, it.w, it.nlayers, it.batch, info)
+                (self.lib.rsg_basic_chain_supported_split if it.split_rows else self.lib.rsg_basic_chain_supported)(
+                    it.c, it.h, it.w, it.nlayers, it.batch, info)
                 blocks.append((info[3], info[0] == it.h))
             total = sum(b for b, _ in blocks)
             for k in sorted(range(len(subs)), key=lambda k: items[k].h * items[k].w):
@@ -1222,11 +1225,19 @@ class _BackboneMixin:
         if handoff:
             order = sorted(steps, key=lambda b: (not whole(b), -xs[b].C))       # whole-image chains first, widest first
             items, where = [], {}
+            # the whole-image 64-channel chain as two row tiles (rsg_chain_item.split_rows): it is the launch's critical path
+            # in the two-branch module (8 layers on 64 CUs).  RSGNET_HIP_CHAIN_SPLIT64: 0 off (default), 1 two-branch modules,
+            # 2 all.  Measured (round 5, profiles/r05_ab_chain_split64.txt): bit-identical; 1 changes nothing (the tiles' 1.5x
+            # work gives back what the second 64 CUs buy), 2 costs a lone forward 14 %
+            split64 = _env_int("RSGNET_HIP_CHAIN_SPLIT64", 0, 0, 2)
             for b in order:
                 blocks = list(mod.branches[b])
                 if whole(b):
                     where[b] = len(items)
-                    items.append((xs[b], blocks))
+                    sp = chan[b] == 64 and xs[b].C == 64 and (split64 == 2 or (split64 == 1 and len(mod.branches) == 2)) \
+                        and self.batch * 2 <= 256 and not self.throughput and \
+                        bool(self.lib.rsg_basic_chain_supported_split(64, xs[b].H, xs[b].W, 2 * len(blocks), self.batch, info))
+                    items.append((xs[b], blocks, sp))
             for b in order:                      # first halves, then second halves: a producer precedes its consumer
                 if not whole(b):
                     where[b] = len(items)
