@@ -311,10 +311,10 @@ int rsg_conv_fuse_group_run(const void* table_host, int32_t blocks, int32_t lds,
  *   (src 0 or 1);  role says where the result goes:
  *     RSG_FM_TO_GLOBAL  out16 [batch, h >> l, w >> l, out_ld] (l = the output's level), ReLU if `relu` (the module's later
  *                       fuse levels read it: grouped launches as before)
- *     RSG_FM_UP_Y0      1x1, cout 32, one per branch 1..n-1: the up-sampled addends of y0 (stay in LDS, 16-bit as the
+ *     RSG_FM_UP_Y0      1x1, cout c0, one per branch 1..n-1: the up-sampled addends of y0 (stay in LDS, 16-bit as the
  *                       grouped path stored them)
- *     RSG_FM_UP_Y1      1x1, cout 64, one per branch 2..n-1: the up-sampled addends of y1
- *     RSG_FM_DOWN_Y1    the 0 -> 1 conv (k = 3, cout 64), exactly one: its epilogue is the y1 sum
+ *     RSG_FM_UP_Y1      1x1, cout 2 c0, one per branch 2..n-1: the up-sampled addends of y1
+ *     RSG_FM_DOWN_Y1    the 0 -> 1 conv (k = 3, cout 2 c0), exactly one: its epilogue is the y1 sum
  * y[0] = relu(x0 + up(t10) + up(t20) + up(t30)), y[1] = relu(round16(conv01(x0)) + x1 + up(t21) + up(t31)) in the
  * operand order and rounding of rsg_hr_fuse_sum; y1_fold = 1 (two branches only): y[1] = relu(conv01(x0) + x1) in fp32, the
  * residual epilogue of rsg_conv_igemm (the module's LAST output, whose sum the grouped path folds into the conv).
@@ -342,7 +342,8 @@ typedef struct rsg_fuse_module_desc {
     int32_t batch, h, w, n_branches, dtype;
     int32_t y1_fold;
     int32_t n_convs;
-    int32_t reserved;
+    int32_t c0;                /* channels of branch 0: 32 (HRNet-W32; 0 means 32) or 48 (HRNet-W48: 48 / 96 / 192 / 384, the
+                                  48-channel maps in 64-channel buffers, x_ld[0] = y_ld[0] = 64) */
     rsg_fm_conv convs[RSG_FM_MAX_CONVS];
 } rsg_fuse_module_desc;
 size_t rsg_fuse_module_table_bytes(void);

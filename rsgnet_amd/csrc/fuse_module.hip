@@ -29,7 +29,7 @@
 #define FM_MAX_JOBS 48
 #define FM_WAVES 16
 #define FM_THREADS (64 * FM_WAVES)
-#define FM_SLOTS 8                 // staging loads in flight per thread
+#define FM_SLOTS 10                // staging loads in flight per thread
 #define FM_SYNC 255                // pseudo-job: barrier (phase A's results are in LDS), then this thread's share of the y0 sum
 
 struct FmConv {
@@ -42,6 +42,7 @@ struct FmConv {
     int role;
     int t_off;             // LDS byte offset of the 16-bit result [pixel][cout] (roles UP_Y0 / UP_Y1)
     int ks;                // k-steps of 16
+    int cout_pad;          // cout rounded up to the 32-channel output tiles (48 -> 64: the upper half of tile 1 is padding)
 };
 struct FmJob { unsigned char conv, ct, g0, ng; };
 struct FmArgs {
@@ -49,6 +50,7 @@ struct FmArgs {
     char* y[2];
     int ldx[4], ldy[2];
     int B, H, W, nbr, R0;
+    int C0;                          // channels of branch 0 (32: HRNet-W32, 48: HRNet-W48); branch i has C0 << i
     int y1_fold, conv_y1;
     int t0_off[3], t1_off[3];        // LDS offsets of the 1x1 results j -> 0 / j -> 1 by j - 1
     int n_conv;
@@ -84,33 +86,34 @@ extern "C" int rsg_fuse_module_set_stamp_buffer(void* dev_ptr) {
 __device__ __forceinline__ int fm_slot(int x, int hws) { return ((x + 1) & 1) * hws + ((x + 1) >> 1); }
 
 // One job: NG groups of 32 output pixels x one 32-channel output tile of one conv, operands from the LDS images.
-template <class DT, int TAPS, int KS, int NG>
+// k order of rsg_pack_conv_weights_host: input-channel block (CINB = 16 KPT channels: 64, 48 or 32 by the conv's cin), then
+// tap, then the KPT k-steps of the block.  NCH blocks; KS = NCH * TAPS * KPT.
+template <class DT, int TAPS, int NCH, int KPT, int NG>
 __device__ __forceinline__ void fm_job(const FmArgs& p, const FmConv& cv, const int ct, const int g0, char* smem,
                                        const int b, const int band, const int lane) {
-    constexpr int KPT = KS / TAPS;                       // k-steps per tap
+    constexpr int KS = TAPS * NCH * KPT;
     constexpr int NPF = KS < 6 ? KS : (NG == 3 ? 4 : 6);  // weight fragments in flight
     const int n = lane & 31, hh = lane >> 5;
     const int lvl = cv.lvl, s = cv.src;
     const int OW = p.W >> lvl, OR = p.R0 >> lvl, npx = OW * OR;
-    const int PSs = (64 << s) + 16, RPs = p.rp[s], HWs = ((p.W >> s) + 2) >> 1, hs = p.halo[s];
+    const int PSs = ((2 * p.C0) << s) + 16, RPs = p.rp[s], HWs = ((p.W >> s) + 2) >> 1, hs = p.halo[s];
     const char* const src = smem + p.off_x[s];
     const uint4* const ap = cv.w + (size_t)ct * KS * 64 + lane;
     uint4 aq[NPF];
 #pragma unroll
     for (int k = 0; k < NPF; ++k) aq[k] = ap[k * 64];
 
-    int pixoff[NG], qq[NG], py[NG], px[NG];
+    int pixoff[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        qq[g] = (g0 + g) * 32 + n;
-        const int qw = qq[g] < npx ? qq[g] : qq[g] % npx;   // idle lanes: a live pixel's address (product discarded)
-        py[g] = qw / OW;
-        px[g] = qw - py[g] * OW;
+        const int q = (g0 + g) * 32 + n;
+        const int qw = q < npx ? q : q % npx;            // idle lanes: a live pixel's address (product discarded)
+        const int y = qw / OW, x = qw - y * OW;
         if constexpr (TAPS == 9) {
-            pixoff[g] = (2 * py[g]) * RPs + px[g] * PSs + hh * 16;       // tap (ky, kx) adds ky rows / the column half
+            pixoff[g] = (2 * y) * RPs + x * PSs + hh * 16;               // tap (ky, kx) adds ky rows / the column half
         } else {
-            const int slot = hs ? fm_slot(px[g], HWs) : px[g];
-            pixoff[g] = (py[g] + hs) * RPs + slot * PSs + hh * 16;
+            const int slot = hs ? fm_slot(x, HWs) : x;
+            pixoff[g] = (y + hs) * RPs + slot * PSs + hh * 16;
         }
     }
     const int cbase = ct * 32 + hh * 16;
@@ -128,10 +131,11 @@ __device__ __forceinline__ void fm_job(const FmArgs& p, const FmConv& cv, const 
             for (int r = 0; r < 16; ++r) acc[g][r] = bias[r];
     }
     auto boff = [&](int ks) {
-        if constexpr (TAPS == 1) return ks * 32;
+        const int ch = ks / (TAPS * KPT), rem = ks % (TAPS * KPT), t = rem / KPT, c = rem % KPT;
+        if constexpr (TAPS == 1) return (ch * KPT + c) * 32;
         else {
-            const int t = ks / KPT, c = ks % KPT, ky = t / 3, kx = t % 3;
-            return ky * RPs + ((kx & 1) * HWs + (kx >> 1)) * PSs + c * 32;
+            const int ky = t / 3, kx = t % 3;
+            return ky * RPs + ((kx & 1) * HWs + (kx >> 1)) * PSs + (ch * KPT + c) * 32;
         }
     };
     uint4 bq[2][NG];
@@ -152,7 +156,17 @@ __device__ __forceinline__ void fm_job(const FmArgs& p, const FmConv& cv, const 
     }
 
     // ---- epilogue by role (wave-uniform) ----------------------------------------------------------------------------------
+    // (the pixel coordinates are divided out again here: held across the k-loop they cost three registers per group)
     const int role = cv.role;
+    int qq[NG], py[NG], px[NG];
+    int ow2 = OW;
+    asm volatile("" : "+s"(ow2));                        // opaque: keeps the divisions behind the k-loop
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        qq[g] = (g0 + g) * 32 + n;
+        py[g] = qq[g] / ow2;
+        px[g] = qq[g] - py[g] * ow2;
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (qq[g] >= npx) continue;
@@ -163,7 +177,8 @@ __device__ __forceinline__ void fm_job(const FmArgs& p, const FmConv& cv, const 
                 f32x8 f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] = acc[g][k * 8 + e];
-                *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
+                if (cbase + k * 8 < cv.cout)
+                    *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
             }
             continue;
         }
@@ -179,14 +194,16 @@ __device__ __forceinline__ void fm_job(const FmArgs& p, const FmConv& cv, const 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
                 }
+                // (the padding channels of a 48-channel result -- zero weights, zero bias -- are written like rsg_conv_igemm
+                // writes them: the map's buffer has round_up(cout, 32) channels)
                 *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
             }
             continue;
         }
         // role DOWN_Y1: the sum of output 1 (lvl == 1).  Folded form (the module's LAST output, rsg_conv_igemm's residual
         // epilogue): relu(acc + x1) in fp32; item form (fuse_body): 0 + round16(conv) + x1 + up(t21) + up(t31)
-        const int h1 = p.halo[1];
-        const char* x1p = smem + p.off_x[1] + (py[g] + h1) * p.rp[1] + (h1 ? fm_slot(px[g], ((p.W >> 1) + 2) >> 1) : px[g]) * 144 + cbase * 2;
+        const int h1 = p.halo[1], C1 = 2 * p.C0;
+        const char* x1p = smem + p.off_x[1] + (py[g] + h1) * p.rp[1] + (h1 ? fm_slot(px[g], ((p.W >> 1) + 2) >> 1) : px[g]) * (2 * C1 + 16) + cbase * 2;
         char* dst = p.y[1] + ((size_t)gpix * p.ldy[1] + cbase) * 2;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -206,7 +223,7 @@ __device__ __forceinline__ void fm_job(const FmArgs& p, const FmConv& cv, const 
 #pragma unroll
                 for (int j = 2; j < 4; ++j) {
                     if (j >= p.nbr) break;
-                    const char* tp = smem + p.t1_off[j - 1] + (((py[g] >> (j - 1)) * (p.W >> j) + (px[g] >> (j - 1))) * 64 + cbase) * 2;
+                    const char* tp = smem + p.t1_off[j - 1] + (((py[g] >> (j - 1)) * (p.W >> j) + (px[g] >> (j - 1))) * C1 + cbase) * 2;
                     const f32x8 tf = __builtin_convertvector(__builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(tp + k * 16)), f32x8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f[e] += tf[e];
@@ -220,15 +237,22 @@ __device__ __forceinline__ void fm_job(const FmArgs& p, const FmConv& cv, const 
 template <class DT>
 __device__ __forceinline__ void fm_run(const FmArgs& p, const FmJob jb, char* smem, const int b, const int band, const int lane) {
     const FmConv cv = p.conv[jb.conv];      // a batch of scalar loads from the kernel-argument segment
-    const int key = (cv.taps == 9 ? 100 : 0) + cv.ks * 4 + jb.ng;
-#define FM_CASE(T, K, N) case ((T) == 9 ? 100 : 0) + (K) * 4 + (N): fm_job<DT, T, K, N>(p, cv, jb.ct, jb.g0, smem, b, band, lane); break;
-#define FM_CASE3(T, K) FM_CASE(T, K, 1) FM_CASE(T, K, 2) FM_CASE(T, K, 3)
+    const int key = (cv.taps == 9 ? 1000 : 0) + cv.ks * 4 + jb.ng;
+#define FM_CASE(T, NCH, KPT, N) case ((T) == 9 ? 1000 : 0) + (T) * (NCH) * (KPT) * 4 + (N): fm_job<DT, T, NCH, KPT, N>(p, cv, jb.ct, jb.g0, smem, b, band, lane); break;
+#define FM_CASE3(T, NCH, KPT) FM_CASE(T, NCH, KPT, 1) FM_CASE(T, NCH, KPT, 2) FM_CASE(T, NCH, KPT, 3)
     switch (key) {
-        FM_CASE3(1, 4)
-        FM_CASE3(1, 8)
-        FM_CASE3(1, 16)
-        FM_CASE3(9, 18)
-        FM_CASE(9, 36, 1) FM_CASE(9, 36, 2)
+        // HRNet-W32: 1x1 over 64 / 128 / 256 channels (blocks of 64), 3x3 stride 2 over 32 / 64
+        FM_CASE3(1, 1, 4)
+        FM_CASE3(1, 2, 4)
+        FM_CASE3(1, 4, 4)
+        FM_CASE3(9, 1, 2)
+        FM_CASE(9, 1, 4, 1) FM_CASE(9, 1, 4, 2)
+        // HRNet-W48: 1x1 over 96 (3 blocks of 32) / 192 / 384 (blocks of 64), 3x3 stride 2 over 48 (one block) / 96 (3 x 32)
+        FM_CASE3(1, 3, 2)
+        FM_CASE3(1, 3, 4)
+        FM_CASE3(1, 6, 4)
+        FM_CASE3(9, 1, 3)
+        FM_CASE(9, 3, 2, 1) FM_CASE(9, 3, 2, 2)
     }
 #undef FM_CASE3
 #undef FM_CASE
@@ -266,11 +290,12 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
         }
     }
     // ---- 1. every byte of the band in one round of requests -----------------------------------------------------------
-    // A row of EVERY branch is W * 4 chunks of 16 B (C doubles as W halves).  Slot s of a thread is chunk
+    // A row of EVERY branch is W * C0 / 8 chunks of 16 B (C doubles as W halves).  Slot s of a thread is chunk
     // (slot_q[s] rows + slot_m[s] chunks) + (tid / rowc, tid % rowc) of branch slot_br[s]: the host's table, so the slots
     // are static registers and a thread divides once.
     {
-        const int rowc = p.W * 4;
+        const int cpp0 = p.C0 >> 3;                     // 16-byte chunks per pixel of branch 0
+        const int rowc = p.W * cpp0;
         const int r_t = tid / rowc, c_t = tid - r_t * rowc;
         uint4 v[FM_SLOTS];
         int lo[FM_SLOTS];
@@ -281,12 +306,12 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
             v[s] = make_uint4(0, 0, 0, 0);
             if (i < 0) continue;                        // wave-uniform
             const int hi = p.halo[i], rows = (p.R0 >> i) + hi, Wi = p.W >> i, Hi = p.H >> i;
-            const int PSi = (64 << i) + 16, HWi = (Wi + 2) >> 1, ld2 = p.ldx[i] * 2;
+            const int cpp = cpp0 << i, PSi = cpp * 16 + 16, HWi = (Wi + 2) >> 1, ld2 = p.ldx[i] * 2;
             const int row0 = band * (p.R0 >> i) - hi;
             int r = r_t + p.slot_q[s], c = c_t + p.slot_m[s];
             if (c >= rowc) { c -= rowc; ++r; }
             if (r < rows) {
-                const int x = c >> (2 + i), cg = c & ((4 << i) - 1);
+                const int x = c / cpp, cg = c - x * cpp;
                 lo[s] = p.off_x[i] + r * p.rp[i] + (hi ? fm_slot(x, HWi) : x) * PSi + cg * 16;
                 if (row0 + r >= 0)
                     v[s] = *reinterpret_cast<const uint4*>(p.x[i] + ((size_t)(b * Hi + row0 + r) * Wi + x) * ld2 + cg * 16);
@@ -296,7 +321,7 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (!p.halo[i]) continue;
-            const int rows = (p.R0 >> i) + 1, cpp = 4 << i;
+            const int rows = (p.R0 >> i) + 1, cpp = (p.C0 >> 3) << i;
             for (int id = tid; id < rows * cpp; id += FM_THREADS) {
                 const int r = id / cpp, cg = id - r * cpp;
                 *reinterpret_cast<uint4*>(smem + p.off_x[i] + r * p.rp[i] + cg * 16) = make_uint4(0, 0, 0, 0);
@@ -320,15 +345,20 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
         __syncthreads();
         FM_STAMP(2);
         // ---- y0 = relu(x0 + up(t10) + up(t20) + up(t30)): fuse_body's order and rounding, LDS -> memory ------------------
-        const int W = p.W, h0 = p.halo[0], HW0 = (W + 2) >> 1;
-        const int total = p.R0 * W * 4;
+        const int W = p.W, h0 = p.halo[0], HW0 = (W + 2) >> 1, cpp0 = p.C0 >> 3, PS0 = 2 * p.C0 + 16;
+        const int cppo = (p.C0 + 31) >> 5 << 2;         // chunks of the output pixel incl. the padding of a 48-in-64 buffer
+        const int total = p.R0 * W * cppo;
         for (int id = tid; id < total; id += FM_THREADS) {
-            const int pl = id >> 2, cg = id & 3;
+            const int pl = id / cppo, cg = id - pl * cppo;
             const int y = pl / W, x = pl - y * W;
+            if (cg >= cpp0) {                            // channels 48..63: zeros, as the grouped path's sum of zero paddings
+                *reinterpret_cast<uint4*>(p.y[0] + ((size_t)((b * p.H + band * p.R0 + y) * W + x) * p.ldy[0]) * 2 + cg * 16) = make_uint4(0, 0, 0, 0);
+                continue;
+            }
             float acc[8];
             {
                 const typename DT::vec8 xv = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(
-                    smem + p.off_x[0] + (y + h0) * p.rp[0] + (h0 ? fm_slot(x, HW0) : x) * 80 + cg * 16));
+                    smem + p.off_x[0] + (y + h0) * p.rp[0] + (h0 ? fm_slot(x, HW0) : x) * PS0 + cg * 16));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] = 0.f + (float)xv[e];
             }
@@ -336,7 +366,7 @@ __global__ void __launch_bounds__(FM_THREADS) fuse_module_kernel(const FmArgs p)
             for (int jj = 1; jj < 4; ++jj) {
                 if (jj >= p.nbr) break;
                 const typename DT::vec8 tv = __builtin_bit_cast(typename DT::vec8, *reinterpret_cast<const uint4*>(
-                    smem + p.t0_off[jj - 1] + ((y >> jj) * (W >> jj) + (x >> jj)) * 64 + cg * 16));
+                    smem + p.t0_off[jj - 1] + ((y >> jj) * (W >> jj) + (x >> jj)) * (2 * p.C0) + cg * 16));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += (float)tv[e];
             }
@@ -368,28 +398,31 @@ extern "C" int rsg_fuse_module_plan(const rsg_fuse_module_desc* d, void* table_h
     if (!d || !table_host || !launch2) RSG_FAIL("fuse_module: null pointer");
     const int nbr = d->n_branches;
     if (nbr < 2 || nbr > 4 || d->batch < 1 || d->n_convs < 2 || d->n_convs > FM_MAX_CONVS) RSG_FAIL("fuse_module: %d branches, %d convs", nbr, d->n_convs);
-    if (d->w < 8 || (d->w & 7) || (d->h & 7) || d->w * 4 > FM_THREADS) RSG_FAIL("fuse_module: %dx%d map (multiples of 8, width <= %d)", d->h, d->w, FM_THREADS / 4);
+    const int C0 = d->c0 ? d->c0 : 32;
+    if (C0 != 32 && C0 != 48) RSG_FAIL("fuse_module: %d channels in branch 0 (32: HRNet-W32, 48: HRNet-W48)", C0);
+    if (d->w < 8 || (d->w & 7) || (d->h & 7) || d->w * (C0 / 8) > FM_THREADS) RSG_FAIL("fuse_module: %dx%d map (multiples of 8, at most %d channels per row)", d->h, d->w, FM_THREADS * 8);
     for (int i = 0; i < nbr; ++i)
-        if (!d->x[i] || ((uintptr_t)d->x[i] & 15) || d->x_ld[i] < (32 << i) || (d->x_ld[i] & 7)) RSG_FAIL("fuse_module: branch %d operand", i);
+        if (!d->x[i] || ((uintptr_t)d->x[i] & 15) || d->x_ld[i] < (C0 << i) || (d->x_ld[i] & 7)) RSG_FAIL("fuse_module: branch %d operand", i);
     for (int i = 0; i < 2; ++i)
-        if (!d->y[i] || ((uintptr_t)d->y[i] & 15) || d->y_ld[i] < (32 << i) || (d->y_ld[i] & 7)) RSG_FAIL("fuse_module: output %d", i);
+        if (!d->y[i] || ((uintptr_t)d->y[i] & 15) || d->y_ld[i] < round_up(C0 << i, 32) || (d->y_ld[i] & 7)) RSG_FAIL("fuse_module: output %d", i);
     if ((long long)d->batch * d->h * d->w * std::max(d->y_ld[0], d->x_ld[0]) * 2 >= (1LL << 31)) RSG_FAIL("fuse_module: map too large");
     FmArgs& a = *(FmArgs*)table_host;
     memset(&a, 0, sizeof(a));
     for (int i = 0; i < nbr; ++i) { a.x[i] = (const char*)d->x[i]; a.ldx[i] = d->x_ld[i]; }
     for (int i = 0; i < 2; ++i) { a.y[i] = (char*)d->y[i]; a.ldy[i] = d->y_ld[i]; }
-    a.B = d->batch; a.H = d->h; a.W = d->w; a.nbr = nbr; a.y1_fold = d->y1_fold ? 1 : 0; a.n_conv = d->n_convs;
+    a.B = d->batch; a.H = d->h; a.W = d->w; a.nbr = nbr; a.y1_fold = d->y1_fold ? 1 : 0; a.n_conv = d->n_convs; a.C0 = C0;
     a.conv_y1 = -1;
     int up0[3] = {-1, -1, -1}, up1[3] = {-1, -1, -1};
     for (int c = 0; c < d->n_convs; ++c) {
         const rsg_fm_conv& s = d->convs[c];
         FmConv& o = a.conv[c];
         if (!s.w_packed || !s.bias || (((uintptr_t)s.w_packed | (uintptr_t)s.bias) & 15)) RSG_FAIL("fuse_module: conv %d weights", c);
-        if (s.src < 0 || s.src >= nbr || (s.k != 1 && s.k != 3) || s.cout < 32 || s.cout > 256 || (s.cout & 31)) RSG_FAIL("fuse_module: conv %d shape", c);
+        if (s.src < 0 || s.src >= nbr || (s.k != 1 && s.k != 3) || s.cout < C0 || s.cout > 8 * C0 || (s.cout % C0)) RSG_FAIL("fuse_module: conv %d shape", c);
         o.w = (const uint4*)s.w_packed; o.bias = s.bias; o.out = (char*)s.out16; o.ldo = s.out_ld;
         o.src = s.src; o.taps = s.k == 3 ? 9 : 1; o.cout = s.cout; o.relu = s.relu ? 1 : 0; o.role = s.role;
         o.lvl = s.k == 3 ? s.src + 1 : s.src;
-        o.ks = o.taps * ((32 << s.src) / 16);
+        o.ks = o.taps * ((C0 << s.src) / 16);
+        o.cout_pad = round_up(s.cout, 32);
         if (o.lvl >= nbr) RSG_FAIL("fuse_module: conv %d leaves the module", c);
         if (s.k == 3) {
             if (s.src > 1) RSG_FAIL("fuse_module: conv %d: strided convs of branches 0 and 1 only", c);
@@ -397,18 +430,18 @@ extern "C" int rsg_fuse_module_plan(const rsg_fuse_module_desc* d, void* table_h
         }
         switch (s.role) {
         case RSG_FM_TO_GLOBAL:
-            if (!s.out16 || ((uintptr_t)s.out16 & 15) || s.out_ld < s.cout || (s.out_ld & 7)) RSG_FAIL("fuse_module: conv %d output", c);
+            if (!s.out16 || ((uintptr_t)s.out16 & 15) || s.out_ld < round_up(s.cout, 32) || (s.out_ld & 7)) RSG_FAIL("fuse_module: conv %d output", c);
             break;
         case RSG_FM_UP_Y0:
-            if (s.k != 1 || s.src < 1 || s.cout != 32 || s.relu || up0[s.src - 1] >= 0) RSG_FAIL("fuse_module: conv %d as an addend of y0", c);
+            if (s.k != 1 || s.src < 1 || s.cout != C0 || s.relu || up0[s.src - 1] >= 0) RSG_FAIL("fuse_module: conv %d as an addend of y0", c);
             up0[s.src - 1] = c;
             break;
         case RSG_FM_UP_Y1:
-            if (s.k != 1 || s.src < 2 || s.cout != 64 || s.relu || up1[s.src - 1] >= 0) RSG_FAIL("fuse_module: conv %d as an addend of y1", c);
+            if (s.k != 1 || s.src < 2 || s.cout != 2 * C0 || s.relu || up1[s.src - 1] >= 0) RSG_FAIL("fuse_module: conv %d as an addend of y1", c);
             up1[s.src - 1] = c;
             break;
         case RSG_FM_DOWN_Y1:
-            if (s.k != 3 || s.src != 0 || s.cout != 64 || s.relu || a.conv_y1 >= 0) RSG_FAIL("fuse_module: conv %d as the 0 -> 1 conv", c);
+            if (s.k != 3 || s.src != 0 || s.cout != 2 * C0 || s.relu || a.conv_y1 >= 0) RSG_FAIL("fuse_module: conv %d as the 0 -> 1 conv", c);
             a.conv_y1 = c;
             break;
         default: RSG_FAIL("fuse_module: conv %d role %d", c, s.role);
@@ -424,10 +457,10 @@ extern "C" int rsg_fuse_module_plan(const rsg_fuse_module_desc* d, void* table_h
     for (int R0 = 16; R0 >= 8; R0 >>= 1) {
         if ((d->h % R0) || (R0 >> (nbr - 1)) < 1) continue;
         int off = 0, rounds = 0;
-        const int rowc = d->w * 4;
+        const int rowc = d->w * (C0 / 8);
         for (int s = 0; s < FM_SLOTS; ++s) a.slot_br[s] = -1;
         for (int i = 0; i < nbr; ++i) {
-            const int rows = (R0 >> i) + a.halo[i], Wi = d->w >> i, ps = (64 << i) + 16;
+            const int rows = (R0 >> i) + a.halo[i], Wi = d->w >> i, ps = ((2 * C0) << i) + 16;
             a.off_x[i] = off;
             a.rp[i] = a.halo[i] ? fm_row_pitch(Wi + 1, ps, Wi / 2) : Wi * ps;
             off += rows * a.rp[i];
@@ -450,10 +483,10 @@ extern "C" int rsg_fuse_module_plan(const rsg_fuse_module_desc* d, void* table_h
     for (int c = 0; c < d->n_convs; ++c) {
         const FmConv& o = a.conv[c];
         const int npx = (a.R0 >> o.lvl) * (a.W >> o.lvl), groups = (npx + 31) / 32;
-        const int ngmax = o.ks >= 36 ? 2 : 3;
+        const int ngmax = o.ks >= 36 ? 2 : 3;           // (registers: 16 accumulators per group beside the fragment rings)
         if (groups > 255) RSG_FAIL("fuse_module: band too large");
         std::vector<J>& dst = (o.role == RSG_FM_UP_Y0 || o.role == RSG_FM_UP_Y1) ? ja : jb;
-        for (int ct = 0; ct < o.cout / 32; ++ct) {
+        for (int ct = 0; ct < o.cout_pad / 32; ++ct) {
             const int parts = (groups + ngmax - 1) / ngmax;
             for (int q = 0, g = 0; q < parts; ++q) {
                 const int ng = (groups - g + (parts - q) - 1) / (parts - q);
@@ -509,7 +542,7 @@ extern "C" int rsg_fuse_module_plan(const rsg_fuse_module_desc* d, void* table_h
     }
     if (g_fm_prefetch) {
         int n = 0;
-        for (int c = 0; c < d->n_convs; ++c) { a.pre_first[c] = n; n += (a.conv[c].cout >> 5) * a.conv[c].ks * 8; }
+        for (int c = 0; c < d->n_convs; ++c) { a.pre_first[c] = n; n += (a.conv[c].cout_pad >> 5) * a.conv[c].ks * 8; }
         a.pre_total = n;
     }
     launch2[0] = d->batch * (d->h / a.R0);

@@ -53,7 +53,7 @@ class FuseModuleDesc(C.Structure):
     """struct rsg_fuse_module_desc (include/rsgnet_hip.h)."""
     _fields_ = [("x", C.c_void_p * 4), ("y", C.c_void_p * 2), ("x_ld", C.c_int32 * 4), ("y_ld", C.c_int32 * 2),
                 ("batch", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("n_branches", C.c_int32), ("dtype", C.c_int32),
-                ("y1_fold", C.c_int32), ("n_convs", C.c_int32), ("reserved", C.c_int32), ("convs", FmConv * FM_MAX_CONVS)]
+                ("y1_fold", C.c_int32), ("n_convs", C.c_int32), ("c0", C.c_int32), ("convs", FmConv * FM_MAX_CONVS)]
 
 
 class ChainItem(C.Structure):

@@ -1390,7 +1390,9 @@ class _BackboneMixin:
             return None
         if getattr(self, "_defer_sum0", None) == name:
             return None                                  # the last module of pose_hrnet: its y0 sum rides on the classifier
-        if any(x.C != 32 << j or x.coff or x.planes or x.H != xs[0].H >> j or x.W != xs[0].W >> j for j, x in enumerate(xs)):
+        c0 = rows[1][0][0][0].in_channels                # channels of branch 0: 32 (HRNet-W32) or 48 (HRNet-W48, in 64-channel buffers)
+        if c0 not in (32, 48) or any(x.C != _round_up(c0 << j, 32) or x.coff or x.planes or x.H != xs[0].H >> j or x.W != xs[0].W >> j
+                                     for j, x in enumerate(xs)):
             return None
         if fold_into not in (None, (1, 0), (nbr - 1, 0)):
             return None
@@ -1399,10 +1401,10 @@ class _BackboneMixin:
         for (i, j), dep in depth.items():
             fl = rows[i][j]
             conv, bnm = (fl[0], fl[1]) if j > i else (fl[0][0], fl[0][1])
-            if conv.bias is not None or conv.in_channels != 32 << j:
+            if conv.bias is not None or conv.in_channels != c0 << j:
                 return None
             if j > i:                                    # 1x1, BatchNorm, up-sampled by the reader
-                if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.out_channels != 32 << i:
+                if conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.out_channels != c0 << i:
                     return None
                 role = hip.FM_UP_Y0 if i == 0 else hip.FM_UP_Y1 if i == 1 else hip.FM_TO_GLOBAL
                 take[(i, j)] = (conv, bnm, 1, role, False)
@@ -1411,7 +1413,7 @@ class _BackboneMixin:
                     return None
                 if j > 1:
                     continue                             # 2 -> 3 (590 KB of weights for 12 pixels of a band): grouped launch
-                if dep > 1 and conv.out_channels != 32 << j:
+                if conv.out_channels != (c0 << j if dep > 1 else c0 << i):
                     return None
                 role = hip.FM_DOWN_Y1 if (i, j) == (1, 0) else hip.FM_TO_GLOBAL
                 take[(i, j)] = (conv, bnm, 3, role, dep > 1)
@@ -1434,8 +1436,8 @@ class _BackboneMixin:
                 d.x_ld[j] = x.ld
             for i in range(2):
                 d.y[i] = 0x10000 if fake else ys[i].ptr()
-                d.y_ld[i] = 32 << i
-            d.batch, d.h, d.w, d.n_branches, d.dtype, d.y1_fold = B, H, W, nbr, dt, 1 if y1_fold else 0
+                d.y_ld[i] = _round_up(c0 << i, 32)
+            d.batch, d.h, d.w, d.n_branches, d.dtype, d.y1_fold, d.c0 = B, H, W, nbr, dt, 1 if y1_fold else 0, c0
             d.n_convs = len(take)
             for c, (ij, (conv, bnm, k, role, relu)) in enumerate(take.items()):
                 e = d.convs[c]
@@ -1444,26 +1446,25 @@ class _BackboneMixin:
                 e.src, e.k, e.cout, e.relu, e.role = ij[1], k, conv.out_channels, 1 if relu else 0, role
                 if role == hip.FM_TO_GLOBAL:
                     e.out16 = 0x10000 if fake else glob[ij].ptr()
-                    e.out_ld = conv.out_channels
+                    e.out_ld = _round_up(conv.out_channels, 32)
             return d
 
         nbytes = lib.rsg_fuse_module_table_bytes()
         launch2 = (C.c_int32 * 2)()
         probe = np.zeros(nbytes, np.uint8)
-        if any(conv.out_channels % 32 for conv, *_ in take.values()) or \
-                lib.rsg_fuse_module_plan(C.byref(desc(True)), probe.ctypes.data, launch2):
+        if lib.rsg_fuse_module_plan(C.byref(desc(True)), probe.ctypes.data, launch2):
             return None                                  # a shape the band kernel does not cover (LDS): grouped launches
         for ij, (conv, bnm, k, role, relu) in take.items():
             sc, sh = self.bn_fold(bnm)
             wp, bo, _i, _o = self.pack_conv(conv.weight, sc, sh, None)
             packed[ij] = (wp, bo)
-        y0 = self.new(H, W, 32, name=f"{name}.fuse.0")
-        y1 = self.new(H >> 1, W >> 1, 64, name=f"{name}.fuse.1.0.0+sum" if y1_fold else f"{name}.fuse.1")
+        y0 = self.new(H, W, _round_up(c0, 32), name=f"{name}.fuse.0")
+        y1 = self.new(H >> 1, W >> 1, 2 * c0, name=f"{name}.fuse.1.0.0+sum" if y1_fold else f"{name}.fuse.1")
         ys += [y0, y1]
         for ij, (conv, bnm, k, role, relu) in take.items():
             if role == hip.FM_TO_GLOBAL:
                 lvl = ij[1] + (1 if k == 3 else 0)
-                glob[ij] = self.new(H >> lvl, W >> lvl, conv.out_channels,
+                glob[ij] = self.new(H >> lvl, W >> lvl, _round_up(conv.out_channels, 32),
                                     name=f"{name}.fuse.{ij[0]}.{ij[1]}" + ("" if ij[1] > ij[0] else ".0"))
 
         def make():

@@ -53,26 +53,28 @@ def test_fuse_module_jobs_cover_every_output_tile_once():
     """The dealt job lists: every (conv, 32-channel tile, 32-pixel group) of a band exactly once, phase A (the LDS-resident
     1x1 results) in front of every wave's sync job, one sync job per wave."""
     lib = hip.lib()
-    for nbr, h, w in ((2, 64, 48), (3, 64, 48), (4, 64, 48), (4, 96, 72)):
+    for nbr, h, w, c0 in ((2, 64, 48, 32), (3, 64, 48, 32), (4, 64, 48, 32), (4, 96, 72, 32), (4, 96, 72, 48), (3, 96, 72, 48),
+                          (2, 96, 72, 48), (4, 64, 48, 48)):
+        r32 = lambda c: (c + 31) // 32 * 32
         d = hip.FuseModuleDesc()
         for j in range(nbr):
-            d.x[j], d.x_ld[j] = 0x10000, 32 << j
+            d.x[j], d.x_ld[j] = 0x10000, r32(c0 << j)
         for i in range(2):
-            d.y[i], d.y_ld[i] = 0x10000, 32 << i
-        d.batch, d.h, d.w, d.n_branches, d.dtype, d.y1_fold = 2, h, w, nbr, hip.RSG_F16, int(nbr == 2)
+            d.y[i], d.y_ld[i] = 0x10000, r32(c0 << i)
+        d.batch, d.h, d.w, d.n_branches, d.dtype, d.y1_fold, d.c0 = 2, h, w, nbr, hip.RSG_F16, int(nbr == 2), c0
         convs = []
         for i in range(nbr):
             for j in range(nbr):
                 if j > i:
-                    convs.append((j, 1, 32 << i, hip.FM_UP_Y0 if i == 0 else hip.FM_UP_Y1 if i == 1 else hip.FM_TO_GLOBAL))
+                    convs.append((j, 1, c0 << i, hip.FM_UP_Y0 if i == 0 else hip.FM_UP_Y1 if i == 1 else hip.FM_TO_GLOBAL))
                 elif j < i and j <= 1:
-                    convs.append((j, 3, (32 << i) if i - j == 1 else (32 << j), hip.FM_DOWN_Y1 if (i, j) == (1, 0) else hip.FM_TO_GLOBAL))
+                    convs.append((j, 3, (c0 << i) if i - j == 1 else (c0 << j), hip.FM_DOWN_Y1 if (i, j) == (1, 0) else hip.FM_TO_GLOBAL))
         d.n_convs = len(convs)
         for c, (src, k, cout, role) in enumerate(convs):
             e = d.convs[c]
             e.w_packed, e.bias, e.src, e.k, e.cout, e.role = 0x10000, 0x10000, src, k, cout, role
             if role == hip.FM_TO_GLOBAL:
-                e.out16, e.out_ld = 0x10000, cout
+                e.out16, e.out_ld = 0x10000, r32(cout)
         tab = np.zeros(lib.rsg_fuse_module_table_bytes(), np.uint8)
         l2 = (C.c_int32 * 2)()
         assert lib.rsg_fuse_module_plan(C.byref(d), tab.ctypes.data, l2) == 0, lib.rsg_last_error()
@@ -99,7 +101,7 @@ def test_fuse_module_jobs_cover_every_output_tile_once():
         for c, (src, k, cout, role) in enumerate(convs):
             lvl = src + (1 if k == 3 else 0)
             groups = ((R0 >> lvl) * (w >> lvl) + 31) // 32
-            for ct in range(cout // 32):
+            for ct in range(r32(cout) // 32):
                 for g in range(groups):
                     assert (c, ct, g) in seen, (nbr, c, ct, g)
-        assert len(seen) == sum(((R0 >> (s + (k == 3))) * (w >> (s + (k == 3))) + 31) // 32 * (co // 32) for s, k, co, _ in convs)
+        assert len(seen) == sum(((R0 >> (s + (k == 3))) * (w >> (s + (k == 3))) + 31) // 32 * (r32(co) // 32) for s, k, co, _ in convs)

@@ -38,16 +38,19 @@ def _fuse_maps(plan):
 
 
 @pytest.mark.parametrize("tag,dtype,batch", [("hrnet_w32_256x192", "fp16", 3), ("hrnet_w32_256x192", "bf16", 2),
-                                             ("rsgnet_w32_256x192_crowdpose", "fp16", 2)])
+                                             ("rsgnet_w32_256x192_crowdpose", "fp16", 2), ("hrnet_w48_384x288", "fp16", 2),
+                                             ("rsgnet_w48_256x192_crowdpose_sub", "fp16", 3)])
 def test_fuse_module_equals_the_grouped_launches(tag, dtype, batch):
     """Every fuse map of every module (outputs, and the intermediate maps of the strided chains) and the model's outputs:
     the same bits from the band launch + the remaining grouped levels as from the grouped launches alone.  Batch 3 / 2:
-    bands of different pictures share a workgroup index range; 256x192 crops: 4 bands of 16 rows per picture."""
+    bands of different pictures share a workgroup index range; 256x192 crops: 4 bands of 16 rows per picture (HRNet-W48's
+    widths, 48 / 96 / 192 / 384 channels with the 48-channel maps in 64-channel buffers: bands of 8 rows at 384x288)."""
     from rsgnet_amd.weights import synth_input
     cfg, model, sd, x, gold = load_case(tag)
     model = model.to(DEV)
     model.compute_dtype = dtype
-    x = synth_input(batch, (192, 256), 11).to(DEV)
+    from tests.util import TAGS
+    x = synth_input(batch, TAGS[tag][2], 11).to(DEV)
     new, old = _plans(model, batch)
     names_new = [n for n, _ in new.ops]
     assert any(n.endswith(".fuse.band") for n in names_new), names_new
