@@ -235,28 +235,21 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
-        for env, key in (("RSGNET_HIP_CHAIN_MAX_NI", b"chain_max_ni"), ("RSGNET_HIP_CHAIN_PITCH_PAD", b"chain_pitch_pad"),
-                         ("RSGNET_HIP_CONV_LDS", b"conv_lds_limit"), ("RSGNET_HIP_CHAIN_PREFETCH", b"chain_prefetch"),
-                         ("RSGNET_HIP_CONV_FULL_K", b"conv_full_k"), ("RSGNET_HIP_CONV_SPREAD", b"conv_spread"), ("RSGNET_HIP_BOTTLENECK_HEAD", b"bottleneck_head"),
-                         ("RSGNET_HIP_CHAIN_DUAL", b"chain_dual"),
-                         ("RSGNET_HIP_CHAIN_SPLIT_ROWS", b"chain_split_rows"), ("RSGNET_HIP_FM_PREFETCH", b"fm_prefetch")):
-            if os.environ.get(env):
-                if l.rsg_tune(key, int(os.environ[env])):       # the library validates the value
-                    raise RuntimeError(f"{env}={os.environ[env]}: {l.rsg_last_error().decode(errors='replace')}")
-        # the wrong-result timing switches (chain_debug bits 1|2, bottleneck_debug) exist only in a -DRSG_DEBUG build
-        # (RSGNET_HIP_DEBUG_BUILD=1 python -m rsgnet_amd.build --force) and are never set from the environment of a
-        # production process; tools/ call rsg_tune themselves and fail loudly on a production library
-        for env, key in (("RSGNET_HIP_BOTTLENECK_DEBUG", b"bottleneck_debug"), ("RSGNET_HIP_CHAIN_DEBUG", b"chain_debug")):
-            if os.environ.get(env) and os.environ.get("RSGNET_HIP_DEBUG_BUILD") == "1":
-                check_rc = l.rsg_tune(key, int(os.environ[env]))
-                if check_rc:
-                    raise RuntimeError(f"{env}: {l.rsg_last_error().decode(errors='replace')}")
-        if any(os.environ.get("RSGNET_HIP_WGRAD_" + k) for k in ("MIN_PX", "QUAD_MIN_WGS", "LDS", "PX_CAP", "WAVES")):
-            l.rsg_wgrad_tune(int(os.environ.get("RSGNET_HIP_WGRAD_MIN_PX", "0")), int(os.environ.get("RSGNET_HIP_WGRAD_QUAD_MIN_WGS", "0")),
-                             int(os.environ.get("RSGNET_HIP_WGRAD_LDS", "0")), int(os.environ.get("RSGNET_HIP_WGRAD_PX_CAP", "0")),
-                             int(os.environ.get("RSGNET_HIP_WGRAD_WAVES", "0")))
-        if os.environ.get("RSGNET_HIP_WGRAD_QUAD"):
-            l.rsg_wgrad_set_quad(int(os.environ["RSGNET_HIP_WGRAD_QUAD"]))
+        # RSGNET_HIP_TUNE="key=value,...": the library's knobs (rsg_tune validates the values; the wrong-result timing switches
+        # chain_debug bits 1|2 and bottleneck_debug exist only in a -DRSG_DEBUG build, RSGNET_HIP_DEBUG_BUILD=1), and the
+        # weight-gradient tiling (rsg_wgrad_tune / rsg_wgrad_set_quad) under the wgrad_ prefix
+        from . import switches as _sw
+        tune = _sw.tune_items()
+        wg = {k[6:]: v for k, v in tune.items() if k.startswith("wgrad_")}
+        for key, value in tune.items():
+            if key.startswith("wgrad_"):
+                continue
+            if l.rsg_tune(key.encode(), value):
+                raise RuntimeError(f"RSGNET_HIP_TUNE {key}={value}: {l.rsg_last_error().decode(errors='replace')}")
+        if any(k in wg for k in ("min_px", "quad_min_wgs", "lds", "px_cap", "waves")):
+            l.rsg_wgrad_tune(wg.get("min_px", 0), wg.get("quad_min_wgs", 0), wg.get("lds", 0), wg.get("px_cap", 0), wg.get("waves", 0))
+        if "quad" in wg:
+            l.rsg_wgrad_set_quad(wg["quad"])
         _lib = l
     return _lib
 

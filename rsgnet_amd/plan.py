@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
+from . import switches as sw
 
 BN_EPS = 1e-5
 
@@ -75,20 +76,6 @@ class VT:
         return t[..., self.coff: self.coff + self.C]
 
 
-def _env_int(name: str, default: int, lo: int, hi: int) -> int:
-    """An integer switch of the environment, validated where it is read (a bad value is an error, not a crash later)."""
-    raw = os.environ.get(name)
-    if raw is None or raw == "":
-        return default
-    try:
-        v = int(raw)
-    except ValueError:
-        raise ValueError(f"{name}={raw!r}: not an integer") from None
-    if not lo <= v <= hi:
-        raise ValueError(f"{name}={v}: allowed range {lo}..{hi}")
-    return v
-
-
 class OutSlot:
     """An fp32 output of the plan whose address may change from call to call: the ops that write it run eagerly
     behind the captured graph (`Plan.n_tail`), so a forward can hand out fresh tensors instead of clones of static
@@ -124,21 +111,21 @@ class Plan:
         self._keep: List[object] = []       # ctypes structs / tensors that must outlive the plan
         self._vts: List[VT] = []
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.graph_mode = os.environ.get("RSGNET_HIP_GRAPH", "capture")
+        self.graph_mode = sw.plan("graph")
         self.use_graph = self.graph_mode != "0"
-        self.use_chain = os.environ.get("RSGNET_HIP_CHAIN", "1") != "0"
-        self.use_group = os.environ.get("RSGNET_HIP_GROUP", "1") != "0"
+        self.use_chain = sw.plan_on("chain")
+        self.use_group = sw.plan_on("group")
         self.conv_log: List[dict] = []
         self.flops = 0
         # lanes = HIP streams the launches are spread over (independent HRNet branches run concurrently);
         # cross-lane ordering comes from events derived from each op's buffer reads/writes
         # a plan built for a side stream expects to share the GPU with another stream's forward: tuned for CU-time, not makespan
         self.throughput = bool(getattr(model, "_plan_for_side_stream", False))
-        self.n_lanes = _env_int("RSGNET_HIP_LANES", 4, 1, 4)
+        self.n_lanes = sw.plan_int("lanes")
         self._lane = 0
         self._streams: List[torch.cuda.Stream] = []
         # in-launch hand-off (chain_group items that wait on an earlier item): off after a failure (models/_base.py)
-        self.allow_handoff = os.environ.get("RSGNET_HIP_CHAIN_HANDOFF", "1") != "0" and \
+        self.allow_handoff = sw.plan_on("chain_handoff") and \
             not getattr(model, "_no_handoff", False)
         self._ho_flags: List[torch.Tensor] = []       # every flag buffer of this plan (re-zeroed after a timeout)
         self._ho_seen: Optional[int] = None           # error-word value the last time it was read
@@ -148,7 +135,7 @@ class Plan:
         # forwards between two asynchronous reads of the error word: every forward enqueues the 4-byte copy behind its
         # launches and looks at the previous forward's copy first, so at most ONE batch of outputs can leave a plan
         # whose hand-off gave up before HandoffTimeout is raised (advisor, round 2: was 32)
-        self.handoff_poll_every = _env_int("RSGNET_HIP_HANDOFF_POLL_EVERY", 1, 1, 1 << 20)
+        self.handoff_poll_every = sw.plan_int("handoff_poll_every")
 
     class _LaneCtx:
         def __init__(self, plan, lane):
@@ -438,16 +425,16 @@ class Plan:
             # HRNet-W48 widths: at 384x288 only the smallest map fits LDS whole, and these maps are MFMA-heavy enough
             # that a deeper halo costs more than a launch: ONE BasicBlock of every branch per grouped launch
             return 1 if self.lib.rsg_basic_chain_supported(C_, H, W, 2, self.batch, info) and \
-                os.environ.get("RSGNET_HIP_WIDE_CHAINS", "1") != "0" else 0
+                sw.plan_on("wide_chains") else 0
         if self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nblocks, self.batch, info) and info[0] == H:
-            # whole images stay in LDS.  RSGNET_HIP_CHAIN_SLICES=2 cuts the chain in two launches so that
+            # whole images stay in LDS.  RSGNET_HIP_PLAN chain_slices=2 cuts the chain in two launches so that
             # both grouped launches of a module hold a slice of EVERY branch (better balanced grids)
-            slices = _env_int("RSGNET_HIP_CHAIN_SLICES", 2, 1, 8)
+            slices = sw.plan_int("chain_slices")
             return max(1, nblocks // slices) if nblocks % slices == 0 else nblocks
         # row tiles: the MFMAs are far from busy on these wide, thin maps, so halo recompute is cheap;
-        # RSGNET_HIP_ROWTILE_BLOCKS blocks per launch (default 2: measured best; 4 makes the 2.6x halo
+        # RSGNET_HIP_PLAN rowtile_blocks blocks per launch (default 2: measured best; 4 makes the 2.6x halo
         # recompute and the second wave of workgroups cost more than the saved launch), then 1
-        want = _env_int("RSGNET_HIP_ROWTILE_BLOCKS", 2, 1, 4)
+        want = sw.plan_int("rowtile_blocks")
         for nb in (want, 2):
             if 0 < nb <= nblocks and nblocks % nb == 0 and \
                     self.lib.rsg_basic_chain_supported(C_, H, W, 2 * nb, self.batch, info) and info[0] >= 8:
@@ -766,9 +753,9 @@ class Plan:
         # it fits in one round.  Fewer, twice as long workgroups: a launch running ALONE gets slower (the longest workgroup
         # sets its makespan: chain family 826 -> 913 us, step +4 %), a launch that shares the GPU with another stream's
         # forward gets cheaper in CU-time (two streams: 1.340 -> 1.316, 1.342 -> 1.314 ms per batch of 64,
-        # profiles/r03n_ab_chain_pack_two_streams.txt).  RSGNET_HIP_CHAIN_PACK = auto (default): on for the plans of side
+        # profiles/r03n_ab_chain_pack_two_streams.txt).  RSGNET_HIP_PLAN chain_pack = auto (default): on for the plans of side
         # streams (self.throughput, models/_base.py plan_for), off for the default stream's; 0 / 1 force it.
-        pack = os.environ.get("RSGNET_HIP_CHAIN_PACK", "auto")
+        pack = sw.plan("chain_pack")
         if pack == "1" or (pack == "auto" and self.throughput):
             cus = torch.cuda.get_device_properties(self.device).multi_processor_count
             info = (C.c_int32 * 4)()
@@ -844,7 +831,7 @@ class Plan:
         name is in `names`, that map is cloned as [B,H,W,C] (buffers are reused by later ops, so it has to be taken
         on the spot).  Returns {name: tensor}; the plan's fp32 outputs hold this pass's results afterwards."""
         if self.graph_mode == "dag":
-            raise RuntimeError("run_with_taps needs RSGNET_HIP_GRAPH != dag")
+            raise RuntimeError("run_with_taps needs RSGNET_HIP_PLAN graph != dag")
         want, got = set(names), {}
         self._bind_input(x)
         for v in vars(self).values():          # the output ops write where the LAST forward's tensors were: those may have
@@ -906,7 +893,7 @@ class Plan:
             self._x_src = self.x_static.data_ptr()
 
     def _replay(self):
-        """RSGNET_HIP_GRAPH = 'capture' (default): stream capture of the single-stream launch order (the
+        """RSGNET_HIP_PLAN graph = 'capture' (default): stream capture of the single-stream launch order (the
         grouped launches already overlap independent work inside each grid); 'dag': explicit HIP graph with
         data-dependency edges (librsgnet_hip's graph API); '0': eager launches, lanes = streams."""
         self._replay_launch()
@@ -1032,10 +1019,10 @@ class _BackboneMixin:
         phases in[2Y+py, 2X+px], so tap (a,b) in {0,1}^2 of the 2x2 conv reads pixel (y+a-1, x+b-1) and the
         phase (py,px) of it carries w[2(a-1)+py+1, 2(b-1)+px+1] when that index is in [0,2], else 0."""
         self.x_static = torch.zeros(self.batch, 3, H, W, dtype=torch.float32, device=self.device)
-        fused = os.environ.get("RSGNET_HIP_STEM", "1") != "0" and m.conv1.out_channels == 64 and \
+        fused = sw.plan_on("stem") and m.conv1.out_channels == 64 and \
             m.conv2.in_channels == 64 and m.conv2.out_channels == 64 and m.conv2.kernel_size == (3, 3) and \
             m.conv2.stride == (2, 2) and H % 4 == 0 and W % 4 == 0
-        direct = fused and os.environ.get("RSGNET_HIP_STEM_DIRECT", "1") != "0"   # the stem reads the picture itself
+        direct = fused and sw.plan_on("stem_direct")   # the stem reads the picture itself
         xs = None
         lib, B, dt = self.lib, self.batch, self.dtype
         if not direct:
@@ -1106,7 +1093,7 @@ class _BackboneMixin:
 
     def _transition1_dual(self: Plan, ys: List[VT], trans) -> bool:
         """transition1 as ONE launch (rsg_conv_dual): both new branches start with a 3x3 conv of the same 256-channel map."""
-        if os.environ.get("RSGNET_HIP_TRANS_DUAL", "1") == "0" or len(ys) != 1 or len(trans) != 2 or trans[0] is None or \
+        if not sw.plan_on("trans_dual") or len(ys) != 1 or len(trans) != 2 or trans[0] is None or \
                 trans[1] is None or len(trans[1]) != 1:
             return False
         ca, cb, x = trans[0][0], trans[1][0][0], ys[0]
@@ -1167,7 +1154,7 @@ class _BackboneMixin:
             res = self._unit(x, blk.downsample[0], blk.downsample[1], name=name + ".downsample")
         # whole-Bottleneck fusion (rsg_bottleneck_fused) is opt-in: measured equal to conv1 + conv_pair in step time
         # (both are bound by exposed latency at 2 workgroups per CU), so the proven pair stays
-        if hasattr(blk, "conv3") and blk.downsample is None and os.environ.get("RSGNET_HIP_BOTTLENECK", "0") == "1" and \
+        if hasattr(blk, "conv3") and blk.downsample is None and sw.plan_on("bottleneck") and \
                 x.C == 256 and x.coff == 0 and blk.conv1.kernel_size == (1, 1) and blk.conv1.in_channels == 256 and \
                 blk.conv1.out_channels == 64 and blk.conv2.kernel_size == (3, 3) and blk.conv2.stride == (1, 1) and \
                 blk.conv2.out_channels == 64 and blk.conv3.kernel_size == (1, 1) and blk.conv3.out_channels == 256:
@@ -1175,7 +1162,7 @@ class _BackboneMixin:
         y = self._unit(x, blk.conv1, blk.bn1, relu=True, name=name + ".conv1")
         if hasattr(blk, "conv3"):
             c2, c3 = blk.conv2, blk.conv3
-            if os.environ.get("RSGNET_HIP_PAIR", "1") != "0" and c2.kernel_size == (3, 3) and c2.stride == (1, 1) and \
+            if sw.plan_on("pair") and c2.kernel_size == (3, 3) and c2.stride == (1, 1) and \
                     c2.out_channels == 64 and c2.in_channels % 64 == 0 and c3.kernel_size == (1, 1) and \
                     c3.out_channels % 32 == 0 and y.C == c2.in_channels:
                 return self.conv_pair(y, c2, blk.bn2, c3, blk.bn3, res, name=name + ".conv2+conv3")
@@ -1200,7 +1187,7 @@ class _BackboneMixin:
             cc = chan[b] = blocks[0].conv1.in_channels
             plain = plain and (cc == xs[b].C or (cc == 48 and xs[b].C == 64 and xs[b].coff == 0))
             steps[b] = self.chain_mode(cc, xs[b].H, xs[b].W, len(blocks)) if plain else 0
-        # RSGNET_HIP_CHAIN_HANDOFF (default on): ONE launch per module.  Whole-image branches run all their blocks in
+        # RSGNET_HIP_PLAN chain_handoff (default on): ONE launch per module.  Whole-image branches run all their blocks in
         # one chain; a row-tiled branch (halo grows with the chain) runs as two chains that hand over inside the
         # launch, so its second half needs no launch of its own (where half the CUs would idle).
         info = (C.c_int32 * 4)()
@@ -1226,10 +1213,10 @@ class _BackboneMixin:
             order = sorted(steps, key=lambda b: (not whole(b), -xs[b].C))       # whole-image chains first, widest first
             items, where = [], {}
             # the whole-image 64-channel chain as two row tiles (rsg_chain_item.split_rows): it is the launch's critical path
-            # in the two-branch module (8 layers on 64 CUs).  RSGNET_HIP_CHAIN_SPLIT64: 0 off (default), 1 two-branch modules,
+            # in the two-branch module (8 layers on 64 CUs).  RSGNET_HIP_PLAN chain_split64: 0 off (default), 1 two-branch modules,
             # 2 all.  Measured (round 5, profiles/r05_ab_chain_split64.txt): bit-identical; 1 changes nothing (the tiles' 1.5x
             # work gives back what the second 64 CUs buy), 2 costs a lone forward 14 %
-            split64 = _env_int("RSGNET_HIP_CHAIN_SPLIT64", 0, 0, 2)
+            split64 = sw.plan_int("chain_split64")
             for b in order:
                 blocks = list(mod.branches[b])
                 if whole(b):
@@ -1253,7 +1240,7 @@ class _BackboneMixin:
         # branches the chains do not cover (HRNet-W48's widths): conv k of EVERY such branch in one grouped launch
         # (they are independent; alone, a 12x9x384 conv fills a fraction of the 256 CUs and a launch costs ~3 us)
         loose = [b for b, s in steps.items() if not s]
-        if self.use_group and len(loose) > 1 and os.environ.get("RSGNET_HIP_ZIP_BRANCHES", "1") != "0" and \
+        if self.use_group and len(loose) > 1 and sw.plan_on("zip_branches") and \
                 len({len(mod.branches[b]) for b in loose}) == 1 and \
                 all(not hasattr(blk, "conv3") and blk.downsample is None for b in loose for blk in mod.branches[b]):
             mid: Dict[int, VT] = {}
@@ -1295,7 +1282,7 @@ class _BackboneMixin:
         if mod.fuse_layers is None:
             return xs
         # the LAST module of pose_hrnet (one output): its 1x1 convs, the sum and the classifier in one launch (HRNetPlan)
-        if getattr(self, "_defer_sum0", None) == name and os.environ.get("RSGNET_HIP_FUSE_HEAD4", "1") != "0" \
+        if getattr(self, "_defer_sum0", None) == name and sw.plan_on("fuse_head4") \
                 and len(mod.fuse_layers) == 1 and 2 <= len(xs) <= 4 and all(xs[j].C == 32 << j for j in range(len(xs))) \
                 and all(xs[j].coff == 0 for j in range(len(xs))) and xs[0].H % 8 == 0 and xs[0].W % 8 == 0 \
                 and all(mod.fuse_layers[0][j][0].kernel_size == (1, 1) and mod.fuse_layers[0][j][0].bias is None for j in range(1, len(xs))):
@@ -1319,7 +1306,7 @@ class _BackboneMixin:
         # output n_out-1 has no up-sampled addends and at most three others besides its longest chain: fold its sum
         fold_into = None
         last = n_out - 1
-        if os.environ.get("RSGNET_HIP_FOLD_SUM", "1") != "0" and last >= 1 and last == len(xs) - 1 \
+        if sw.plan_on("fold_sum") and last >= 1 and last == len(xs) - 1 \
                 and last <= 3 and depth.get((last, 0), 0) == last and depth[(last, 0)] == max_depth:
             fold_into = (last, 0)
             ready[last] = -1                              # no separate sum for it
@@ -1376,7 +1363,7 @@ class _BackboneMixin:
                         continue
                     outs[i] = self.fuse(same, low, name=f"{name}.fuse.{i}")
             if rider is not None and self._rider_out is None and outs[last] is not None and fold_into is not None \
-                    and level > depth[fold_into] - 1 and os.environ.get("RSGNET_HIP_TRANS_RIDE", "1") != "0":
+                    and level > depth[fold_into] - 1 and sw.plan_on("trans_ride"):
                 self._rider_out = rider(outs[last])       # y_last was finished by an EARLIER launch: independent of this one
             self.end_group(f"{name}.fuse.level{level}")
         return outs
@@ -1386,7 +1373,7 @@ class _BackboneMixin:
         pose_hrnet.py:190-268).  Fills outs[0], outs[1] and cur[(i, j)] of the level-0 convs it computes and returns their
         set; None (nothing recorded) when the module is not one it covers -- the caller then records level 0 as before."""
         nbr = len(xs)
-        if os.environ.get("RSGNET_HIP_FUSE_MODULE", "1") == "0" or not self.use_group or not 2 <= nbr <= 4 or len(rows) != nbr:
+        if not sw.plan_on("fuse_module") or not self.use_group or not 2 <= nbr <= 4 or len(rows) != nbr:
             return None
         if getattr(self, "_defer_sum0", None) == name:
             return None                                  # the last module of pose_hrnet: its y0 sum rides on the classifier
@@ -1493,31 +1480,31 @@ class _BackboneMixin:
         return set(take)
 
     def _record_backbone(self: Plan, m, H: int, W: int) -> List[VT]:
-        if os.environ.get("RSGNET_HIP_S2D", "1") != "0" and H % 2 == 0 and W % 2 == 0:
+        if sw.plan_on("s2d") and H % 2 == 0 and W % 2 == 0:
             x = self._record_stem_s2d(m, H, W)
         else:
             x = self._record_input(H, W)
             x = self._unit(x, m.conv1, m.bn1, relu=True, name="conv1")
         b0 = m.layer1[0]
-        fold = (os.environ.get("RSGNET_HIP_L1CAT", "1") != "0" and b0.downsample is not None
+        fold = (sw.plan_on("l1cat") and b0.downsample is not None
                 and hasattr(b0, "conv3") and b0.downsample[0].kernel_size == (1, 1)
                 and b0.downsample[0].stride == (1, 1) and b0.conv3.in_channels % 16 == 0
                 and m.conv2.out_channels % 16 == 0)
-        use_next = os.environ.get("RSGNET_HIP_PAIR_NEXT", "1") != "0" and os.environ.get("RSGNET_HIP_PAIR", "1") != "0" \
-            and os.environ.get("RSGNET_HIP_BOTTLENECK", "0") != "1"
+        use_next = sw.plan_on("pair_next") and sw.plan_on("pair") \
+            and not sw.plan_on("bottleneck")
         t_pre = None                # conv1 output of the NEXT block, already computed by the previous block's launch
         l1 = list(m.layer1)
         # layer1's 256-channel maps as channel-tile planes (rsgnet_hip.h, RSG_LAYOUT_*): when every one of them is written by
         # a conv_pair tail and read only as the next tail's residual or by transition1's conv_dual
-        planes = os.environ.get("RSGNET_HIP_L1_PLANES", "1") != "0" and fold and use_next and len(l1) > 1 \
-            and all(self._plain_bottleneck(b) for b in l1[1:]) and os.environ.get("RSGNET_HIP_PAIR_CAT", "1") != "0" \
+        planes = sw.plan_on("l1_planes") and fold and use_next and len(l1) > 1 \
+            and all(self._plain_bottleneck(b) for b in l1[1:]) and sw.plan_on("pair_cat") \
             and self._transition1_dual([VT(H // 4, W // 4, 256)], m.transition1) and b0.conv3.out_channels == 256
         if fold and use_next and len(l1) > 1 and self._plain_bottleneck(l1[1]) and b0.conv2.kernel_size == (3, 3) \
                 and b0.conv2.in_channels == 64 and b0.conv2.out_channels == 64 and b0.conv3.out_channels == 256 \
-                and m.conv2.out_channels == 64 and os.environ.get("RSGNET_HIP_PAIR_CAT", "1") != "0":
+                and m.conv2.out_channels == 64 and sw.plan_on("pair_cat"):
             # layer1.0 in TWO launches: conv1, then conv2 -> [conv3 | projected residual] as one K = 128 contraction over
             # [conv2 output | x] -> conv1 of layer1.1, all from LDS (rsg_conv_pair_next with cat_x)
-            stem_tail = x is None and os.environ.get("RSGNET_HIP_STEM_TAIL", "1") != "0" and b0.conv1.kernel_size == (1, 1) \
+            stem_tail = x is None and sw.plan_on("stem_tail") and b0.conv1.kernel_size == (1, 1) \
                 and b0.conv1.in_channels == 64 and b0.conv1.out_channels == 64 and b0.conv1.bias is None
             if stem_tail:      # layer1.0.conv1 rides on the stem's launch
                 xs, t = self.stem_to(m, None, tail=(b0.conv1, b0.bn1))
@@ -1557,7 +1544,7 @@ class _BackboneMixin:
         else:
             x = self.stem_to(m, None) if x is None else self._unit(x, m.conv2, m.bn2, relu=True, name="conv2")
             rest, k0 = list(m.layer1), 0
-        # runs of plain Bottlenecks: each block's launch also computes the next block's conv1 (RSGNET_HIP_PAIR_NEXT=0: off)
+        # runs of plain Bottlenecks: each block's launch also computes the next block's conv1 (RSGNET_HIP_PLAN pair_next=0: off)
         k = 0
         while k < len(rest):
             run = []
@@ -1628,7 +1615,7 @@ class HRNetPlan(Plan, _BackboneMixin):
         self._deferred_sum0 = None
         self._deferred_head4 = None
         n4 = len(model.stage4)
-        if os.environ.get("RSGNET_HIP_FUSE_CLASSIFIER", "1") != "0" and J <= 32 and fl.in_channels == 32 \
+        if sw.plan_on("fuse_classifier") and J <= 32 and fl.in_channels == 32 \
                 and model.stage4[n4 - 1].fuse_layers is not None and len(model.stage4[n4 - 1].fuse_layers) == 1:
             self._defer_sum0 = f"stage4.{n4 - 1}"
         ys = self._record_backbone(model, H, W)

@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
+from . import switches as sw
 from .plan import BN_EPS, VT, Plan
 
 
@@ -191,7 +192,7 @@ def record_rsgnet(p: Plan, model) -> None:
 
     # ---- joints-of-target branch (:991-1000); the limbs branch = SGM (:1003-1005) is independent of it and of the TRP, so
     # its two convs ride in this branch's launches (limbs_net beside kpt_net, the limb classifier beside the deconv phases)
-    ride = os.environ.get("RSGNET_HIP_LIMBS_RIDE", "1") != "0"
+    ride = sw.plan_on("limbs_ride")
     p.limbs_lo = torch.zeros(B, L, H4, W4, **f32)
     p.begin_group()
     k = p._unit(cat2, model.kpt_net[0], model.kpt_net[1], relu=True, name="kpt_net")

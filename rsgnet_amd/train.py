@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
+from . import switches as sw
 
 BF16 = hip.DTYPES["bf16"]
 
@@ -118,18 +119,18 @@ class TrainPlan:
         self._graphs: Optional[tuple] = None         # (forward graph, [one graph per backward segment])
         self._warm = 0
         import os
-        self.use_graph = os.environ.get("RSGNET_HIP_TRAIN_GRAPH", "1") != "0"
-        self.use_lanes = os.environ.get("RSGNET_HIP_TRAIN_LANES", "1") != "0"
-        # RSGNET_HIP_TRAIN_WGRAD_STREAM (profiles/r03o_train_wgrad_stream.txt; gradients bit-identical in every form):
+        self.use_graph = sw.train_on("graph")
+        self.use_lanes = sw.train_on("lanes")
+        # RSGNET_HIP_TRAIN wgrad_stream (profiles/r03o_train_wgrad_stream.txt; gradients bit-identical in every form):
         #   0  every launch of the backward pass on one stream (rounds 2-3: 13.11 ms per step of 32)
         #   1  the weight-gradient launches on a stream of their own INSIDE the segment's graph (events as graph edges):
         #      slower, 13.75 ms -- branches inside one graph cost more than they hide
         #   2  (default) the weight gradients of a backward segment as a GRAPH OF THEIR OWN, replayed on the side stream once
         #      the segment's data-gradient graph has been issued: it runs beside the NEXT segment's chain -- overlap between
         #      graphs, the form that paid for inference.  12.47 ms with the three data-parallel segments, 11.95 ms with one
-        #      segment per HighResolutionModule (RSGNET_HIP_TRAIN_SEGMENTS=module), 11.86 ms cutting every 40 launches
+        #      segment per HighResolutionModule (RSGNET_HIP_TRAIN segments=module), 11.86 ms cutting every 40 launches
         #      (every:40, default)
-        mode = os.environ.get("RSGNET_HIP_TRAIN_WGRAD_STREAM", "2")
+        mode = sw.train("wgrad_stream")
         self.wgrad_stream_on = mode == "1"
         self.wgrad_split = mode == "2"
         self._wgrad_stream: Optional[torch.cuda.Stream] = None
@@ -468,7 +469,7 @@ class TrainPlan:
         # the fuse paths (i <- j) are independent of each other: recorded as lanes, so that the k-th conv / BatchNorm of
         # every path (and, in the backward pass, their weight / data gradients) share grouped launches
         paths = [(i, j) for i, row in enumerate(mod.fuse_layers) for j in range(len(row)) if j != i]
-        lanes = self.use_lanes and len(paths) > 1 and os.environ.get("RSGNET_HIP_TRAIN_FUSE_LANES", "1") != "0"
+        lanes = self.use_lanes and len(paths) > 1 and sw.train_on("fuse_lanes")
         done: Dict[Tuple[int, int], T] = {}
         if lanes:
             self._begin_lanes(len(paths), shared=True)
@@ -623,7 +624,7 @@ class TrainPlan:
             parts = nm.split(".")
             return ".".join(parts[:2]) if parts[0].startswith("stage") and len(parts) > 1 else parts[0]
         cuts = []
-        seg_mode = os.environ.get("RSGNET_HIP_TRAIN_SEGMENTS", "every:40") if self.wgrad_split else "stage"
+        seg_mode = sw.train("segments") if self.wgrad_split else "stage"
         by_module = seg_mode == "module"
         every = int(seg_mode.split(":")[1]) if seg_mode.startswith("every:") else 0
         for k in range(1, len(self.bwd)):
@@ -656,7 +657,7 @@ class TrainPlan:
         # Alone it is neutral (13.40 vs 13.37 ms: the two kernels compete for the same memory system); it pays together
         # with main kernels that leave a quarter of the CUs to the reduction blocks (csrc/wgrad.hip, wgrad_group_tables):
         # 13.40 -> 13.07 ms per step
-        if os.environ.get("RSGNET_HIP_TRAIN_WGRAD_PIPE", "1") == "0":
+        if not sw.train_on("wgrad_pipe"):
             return
         for lo, hi in self._bwd_segments:
             chain = [rec[1] for rec in self.bwd[lo:hi] if isinstance(rec[1], _WgradLaunch)]
@@ -697,7 +698,7 @@ class TrainPlan:
         # x already has a gradient of its own (a BasicBlock's input: the residual branch of bn2 came first): the conv adds
         # it in its epilogue and writes in place -- one rounding instead of two, and no separate add launch (104 per step)
         fold = self._defer is None and x.needs_grad and x.grad is not None and not x.grad_shared and \
-            os.environ.get("RSGNET_HIP_TRAIN_FOLD_ADD", "1") != "0"
+            sw.train_on("fold_add")
         dx = x.grad if fold else torch.zeros_like(x.data)
         cin_real = w.shape[1]
         d = self._conv_desc(src, wp, self._zero_bias, dx, None, sh, sw, dy_c, cin_real, k, 1)

@@ -28,6 +28,8 @@ from typing import Optional
 import torch
 import torch.nn.functional as F
 
+from . import switches as sw
+
 
 def kt_machine_forward(kt, weight: torch.Tensor) -> torch.Tensor:
     """KTMachine.forward (pose_rsgnet.py:576-600): the limb classifier from the joint classifier's weights."""
@@ -260,15 +262,12 @@ def graphed_head(model, feat16: torch.Tensor, relation_target: Optional[torch.Te
 
 
 def train_forward(model, x: torch.Tensor, relation_target: Optional[torch.Tensor] = None):
-    """`model(x, relation_target)` under `model.train()` for pose_rsgnet.  RSGNET_HIP_TRAIN_HEAD_GRAPH=1 replays the head
+    """`model(x, relation_target)` under `model.train()` for pose_rsgnet.  RSGNET_HIP_TRAIN="head_graph=1" replays the head
     (forward and backward) as HIP graphs (`graphed_head`); by default its ~300 launches per step are enqueued eagerly, which
     the host hides behind the backbone's graphs at the shipped batch sizes (profiles/r04_head_capture.txt)."""
-    import os
     from .train import train_forward as backbone_forward
     feat16 = backbone_forward(model, x)                                   # HIP: one autograd node for the whole backbone
-    mode = os.environ.get("RSGNET_HIP_TRAIN_HEAD_GRAPH", "0")
-    if mode not in ("0", "1"):
-        raise ValueError(f"RSGNET_HIP_TRAIN_HEAD_GRAPH={mode!r}: 0 or 1")
+    mode = sw.train("head_graph")
     if mode == "1" and getattr(model, "_train_taps", None) is None and torch.is_grad_enabled():
         return graphed_head(model, feat16, relation_target)
     return head_forward(model, feat16, relation_target)

@@ -101,11 +101,9 @@ def _check_backbone_taps(plan, x, gold, model=None):
         except KeyError:                     # the stage-4 map is not materialised by this plan
             taps = plan.run_with_taps(x.cuda(), [v for k, v in names.items() if k != "stage4"])
         if names["stage4"] not in taps:      # HRNet-W32: that sum lives inside the classifier's launch (rsg_fuse_classifier)
-            os.environ["RSGNET_HIP_FUSE_CLASSIFIER"] = "0"
-            try:
+            from rsgnet_amd import switches
+            with switches.override("plan", fuse_classifier="0"):
                 plan2 = model._build_plan(plan.batch, plan.device) if model is not None else None
-            finally:
-                os.environ.pop("RSGNET_HIP_FUSE_CLASSIFIER", None)
             assert plan2 is not None, "stage4 tap missing"
             taps.update(plan2.run_with_taps(x.cuda(), [names["stage4"]]))
     torch.cuda.synchronize()

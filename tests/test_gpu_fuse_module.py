@@ -15,21 +15,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _plans(model, batch, **env):
+def _plans(model, batch):
     """(plan with the band launch, plan with the grouped launches) of one model."""
+    from rsgnet_amd import switches
     out = []
     for v in ("1", "0"):
-        old = {k: os.environ.get(k) for k in ("RSGNET_HIP_FUSE_MODULE", *env)}
-        os.environ["RSGNET_HIP_FUSE_MODULE"] = v
-        os.environ.update(env)
-        try:
+        with switches.override("plan", fuse_module=v):
             out.append(model._build_plan(batch, torch.device(DEV)))
-        finally:
-            for k, o in old.items():
-                if o is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = o
     return out
 
 
@@ -99,12 +91,10 @@ def test_fuse_module_replays_inside_the_graph_and_on_two_streams():
     plan = model.plan_for(x)
     assert any(n.endswith(".fuse.band") for n, _ in plan.ops)
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
-    os.environ["RSGNET_HIP_FUSE_MODULE"] = "0"
-    try:
+    from rsgnet_amd import switches
+    with switches.override("plan", fuse_module="0"):
         model.invalidate_plan()
         with torch.no_grad():
             y0 = model(x).clone()
-    finally:
-        os.environ.pop("RSGNET_HIP_FUSE_MODULE", None)
-        model.invalidate_plan()
+    model.invalidate_plan()
     assert torch.equal(y0, y1)

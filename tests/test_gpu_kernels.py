@@ -805,14 +805,14 @@ def test_bottleneck_fused_equals_three_convs(shape):
 
 def test_stem_fused_equals_two_convs():
     """rsg_stem_fused (conv1 as 2x2 s2d conv + conv2 3x3 s2 in one launch) against the two-launch path, bit for bit,
-    through the model plan: RSGNET_HIP_STEM=0/1 on the same weights and input."""
+    through the model plan: RSGNET_HIP_PLAN stem=0/1 on the same weights and input."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
     from util import load_case
     outs = {}
     for flag in ("0", "1"):
-        os.environ["RSGNET_HIP_STEM"] = flag
+        os.environ["RSGNET_HIP_PLAN"] = f"stem={flag}"
         try:
             cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
             model = model.cuda()
@@ -821,13 +821,13 @@ def test_stem_fused_equals_two_convs():
             names = [n for n, _ in list(model._plans.values())[0].ops]
             assert any(n.startswith("stem(conv1+conv2)") for n in names) == (flag == "1")
         finally:
-            os.environ.pop("RSGNET_HIP_STEM", None)
+            os.environ.pop("RSGNET_HIP_PLAN", None)
     assert torch.equal(outs["0"], outs["1"])
 
 
 def test_stem_tail_equals_stem_plus_conv1():
     """rsg_stem_fused_conv1 (layer1.0's 1x1 conv1 on the stem's output in the stem's launch) against the stem launch followed
-    by the rsg_conv_igemm launch, bit for bit, through the model plan: RSGNET_HIP_STEM_TAIL=0/1 on the same weights and
+    by the rsg_conv_igemm launch, bit for bit, through the model plan: RSGNET_HIP_PLAN stem_tail=0/1 on the same weights and
     input; the default plan has one launch fewer."""
     import os
     import sys
@@ -835,7 +835,7 @@ def test_stem_tail_equals_stem_plus_conv1():
     from util import load_case
     outs, nops = {}, {}
     for flag in ("0", "1"):
-        os.environ["RSGNET_HIP_STEM_TAIL"] = flag
+        os.environ["RSGNET_HIP_PLAN"] = f"stem_tail={flag}"
         try:
             cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
             model = model.cuda()
@@ -845,12 +845,12 @@ def test_stem_tail_equals_stem_plus_conv1():
             nops[flag] = len(names)
             assert ("stem(conv1+conv2)+layer1.0.conv1" in names) == (flag == "1") and ("layer1.0.conv1" in names) == (flag == "0")
         finally:
-            os.environ.pop("RSGNET_HIP_STEM_TAIL", None)
+            os.environ.pop("RSGNET_HIP_PLAN", None)
     assert torch.equal(outs["0"], outs["1"]) and nops["1"] == nops["0"] - 1
 
 
 def test_bottleneck_fused_through_the_plan():
-    """RSGNET_HIP_BOTTLENECK=1 (opt-in) replaces conv1 + conv_pair of layer1's plain Bottlenecks by one launch each;
+    """RSGNET_HIP_PLAN="bottleneck=1" (opt-in) replaces conv1 + conv_pair of layer1's plain Bottlenecks by one launch each;
     heatmaps stay within the golden tolerance of the default path."""
     import os
     import sys
@@ -858,7 +858,7 @@ def test_bottleneck_fused_through_the_plan():
     from util import load_case
     outs = {}
     for flag in ("0", "1"):
-        os.environ["RSGNET_HIP_BOTTLENECK"] = flag
+        os.environ["RSGNET_HIP_PLAN"] = f"bottleneck={flag}"
         try:
             cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
             model = model.cuda()
@@ -867,7 +867,7 @@ def test_bottleneck_fused_through_the_plan():
             names = [n for n, _ in list(model._plans.values())[0].ops]
             assert sum("conv1+conv2+conv3" in n for n in names) == (3 if flag == "1" else 0)
         finally:
-            os.environ.pop("RSGNET_HIP_BOTTLENECK", None)
+            os.environ.pop("RSGNET_HIP_PLAN", None)
     scale = float(outs["0"].std())
     # two fp16 evaluation orders of layer1 seen through 30 more layers: the fp16 noise floor of the whole network
     assert float((outs["0"] - outs["1"]).abs().max()) < 3e-2 * scale
@@ -1233,7 +1233,7 @@ def test_fuse_classifier_and_head4_equal_the_separate_launches():
     forms = {"separate": ("0", "0", "final_layer"), "sum+classifier": ("1", "0", "stage4.fuse.0+final_layer"),
              "module+classifier": ("1", "1", "stage4.fuse+final_layer")}
     for form, (fc, h4, last) in forms.items():
-        os.environ["RSGNET_HIP_FUSE_CLASSIFIER"], os.environ["RSGNET_HIP_FUSE_HEAD4"] = fc, h4
+        os.environ["RSGNET_HIP_PLAN"] = f"fuse_classifier={fc},fuse_head4={h4}"
         try:
             cfg, model, sd, x, gold = load_case("hrnet_w32_256x192")
             model = model.cuda()
@@ -1244,8 +1244,7 @@ def test_fuse_classifier_and_head4_equal_the_separate_launches():
             nops[form] = len(names)
             assert names[-1] == last, (form, names[-3:])
         finally:
-            os.environ.pop("RSGNET_HIP_FUSE_CLASSIFIER", None)
-            os.environ.pop("RSGNET_HIP_FUSE_HEAD4", None)
+            os.environ.pop("RSGNET_HIP_PLAN", None)
     assert torch.isfinite(outs["separate"]).all()
     assert torch.equal(outs["separate"], outs["sum+classifier"]) and torch.equal(outs["separate"], outs["module+classifier"])
     assert nops["sum+classifier"] == nops["separate"] - 1 and nops["module+classifier"] == nops["separate"] - 2

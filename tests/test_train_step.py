@@ -293,17 +293,17 @@ def test_data_parallel_training_two_ranks_on_the_gpu():
     assert np.array_equal(opt.flat_param.detach().cpu().numpy(), res[0][1])
 
 
-# The in-place fold of a data gradient into an existing one (RSGNET_HIP_TRAIN_FOLD_ADD) removes one bf16 rounding of the
+# The in-place fold of a data gradient into an existing one (RSGNET_HIP_TRAIN fold_add) removes one bf16 rounding of the
 # gradient MAP per BasicBlock; the difference random-walks down ~50 blocks (2^-9 * sqrt(50) ~ 1.4e-2 on the earliest
 # layers' maps).  A missing or doubled contribution anywhere moves a tensor by O(0.3-1).
 FOLD_BAR = 5e-2
 
 
 def _one_step_grads(monkeypatch, env):
-    """(heat maps, {name: gradient}) of one training step under the given RSGNET_HIP_TRAIN_* switches."""
+    """(heat maps, {name: gradient}) of one training step under the given RSGNET_HIP_TRAIN switches ({name: value})."""
     from rsgnet_amd.loss import JointsMSELoss
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    if env:
+        monkeypatch.setenv("RSGNET_HIP_TRAIN", ",".join(f"{k}={v}" for k, v in env.items()))
     cfg, model, sd, x, target, tw, gold = _case()
     model.load_state_dict(sd)
     model = model.cuda().train()
@@ -319,8 +319,8 @@ def _one_step_grads(monkeypatch, env):
         outs.append((out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}))
     for n in outs[0][1]:
         assert torch.equal(outs[0][1][n], outs[2][1][n]), (n, "eager launches vs graph replay")
-    for k in env:
-        monkeypatch.delenv(k)
+    if env:
+        monkeypatch.delenv("RSGNET_HIP_TRAIN")
     return outs[2]
 
 
@@ -336,9 +336,8 @@ def test_training_step_composition_is_independent_of_the_launch_structure(monkey
     the contributions to a shared branch gradient after the lanes' launches instead of one by one: measured 2.3e-2 on
     the earliest layers, FOLD_BAR) -- far below the O(0.3-1) a missing, doubled or misrouted contribution leaves."""
     base = _one_step_grads(monkeypatch, {})
-    plain = _one_step_grads(monkeypatch, {"RSGNET_HIP_TRAIN_LANES": "0", "RSGNET_HIP_TRAIN_FUSE_LANES": "0",
-                                          "RSGNET_HIP_TRAIN_FOLD_ADD": "0", "RSGNET_HIP_TRAIN_WGRAD_PIPE": "0",
-                                          "RSGNET_HIP_TRAIN_GRAPH": "0", "RSGNET_HIP_TRAIN_WGRAD_STREAM": "0"})
+    plain = _one_step_grads(monkeypatch, {"lanes": "0", "fuse_lanes": "0", "fold_add": "0", "wgrad_pipe": "0",
+                                          "graph": "0", "wgrad_stream": "0"})
     assert torch.equal(base[0], plain[0])                 # the forward has no such freedom at all
     worst = []
     for n, g in base[1].items():
@@ -350,14 +349,13 @@ def test_training_step_composition_is_independent_of_the_launch_structure(monkey
     print("composition: largest relative L2 differences", worst[:5])
     assert worst[0][0] < FOLD_BAR, worst[:8]
     # each switch alone against the default, same bar: a failure names the switch
-    for k, v in (("RSGNET_HIP_TRAIN_LANES", "0"), ("RSGNET_HIP_TRAIN_FOLD_ADD", "0"), ("RSGNET_HIP_TRAIN_WGRAD_PIPE", "0"),
-                 ("RSGNET_HIP_TRAIN_WGRAD_STREAM", "0"), ("RSGNET_HIP_TRAIN_WGRAD_STREAM", "1")):     # (default: 2)
+    for k, v in (("lanes", "0"), ("fold_add", "0"), ("wgrad_pipe", "0"), ("wgrad_stream", "0"), ("wgrad_stream", "1")):     # (default: 2)
         one = _one_step_grads(monkeypatch, {k: v})
         bad = [(float((one[1][n].double() - g.double()).norm()) / max(float(g.double().norm()), 1e-30), n) for n, g in base[1].items()]
         bad.sort(reverse=True)
         print(k, "=", v, ":", bad[:2])
         assert bad[0][0] < FOLD_BAR, (k, bad[:6])
-        if k in ("RSGNET_HIP_TRAIN_WGRAD_PIPE", "RSGNET_HIP_TRAIN_WGRAD_STREAM"):
+        if k in ("wgrad_pipe", "wgrad_stream"):
             # only WHERE the partial tiles are summed / WHEN a weight gradient runs (beside the data-gradient chain, on a
             # stream of its own) moves: same sums, same order
             assert bad[0][0] == 0.0, (k, bad[:6])
@@ -739,14 +737,14 @@ def test_rsgnet_training_call_of_the_reference_reaches_the_hip_trp():
 
 @pytest.mark.gpu
 def test_rsgnet_head_replayed_as_hip_graphs_equals_the_eager_head(monkeypatch):
-    """RSGNET_HIP_TRAIN_HEAD_GRAPH=1: the head's forward and backward captured by torch.cuda.make_graphed_callables
+    """RSGNET_HIP_TRAIN="head_graph=1": the head's forward and backward captured by torch.cuda.make_graphed_callables
     (train_rsgnet.graphed_head) and replayed.  Two training steps each way from the same state: outputs, loss, every
     gradient and every BatchNorm buffer bit for bit."""
     from rsgnet_amd.loss import JointsMSELoss, relation_target_vector, rsgnet_loss
     cfg, model, sd, (x, target, tw, all_t, all_w, limbs_t), gold = _rsg_case()
     res = []
     for mode in ("0", "1"):
-        monkeypatch.setenv("RSGNET_HIP_TRAIN_HEAD_GRAPH", mode)
+        monkeypatch.setenv("RSGNET_HIP_TRAIN", f"head_graph={mode}")
         from rsgnet_amd import models
         m = models.pose_rsgnet.get_pose_net(cfg, is_train=False)
         m.load_state_dict(sd)
@@ -792,7 +790,7 @@ def test_rsgnet_head_graphs_follow_optimizer_steps_and_mode_changes(monkeypatch)
     tgt = [t.to(dev) for t in (target, tw, all_t, all_w, limbs_t)]
     traces = []
     for mode in ("0", "1"):
-        monkeypatch.setenv("RSGNET_HIP_TRAIN_HEAD_GRAPH", mode)
+        monkeypatch.setenv("RSGNET_HIP_TRAIN", f"head_graph={mode}")
         m = models.pose_rsgnet.get_pose_net(cfg, is_train=False)
         m.load_state_dict(sd)
         m = m.to(dev).train()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timing experiment (GPU box): step time with every chain layer reading layer 0's weights (RSGNET_HIP_CHAIN_DEBUG=1, results
+"""Timing experiment (GPU box): step time with every chain layer reading layer 0's weights (RSGNET_HIP_TUNE=chain_debug=1, results
 are WRONG) against the real forward — how much of the chain kernels' time is the weight stream from L2?"""
 import os
 import sys
@@ -20,4 +20,4 @@ with torch.no_grad():
         model(x)
     e1.record()
     torch.cuda.synchronize()
-print(f"RSGNET_HIP_CHAIN_DEBUG={os.environ.get('RSGNET_HIP_CHAIN_DEBUG', '0')}: {e0.elapsed_time(e1) / 30:.4f} ms per step")
+print(f"RSGNET_HIP_TUNE={os.environ.get('RSGNET_HIP_TUNE', '')}: {e0.elapsed_time(e1) / 30:.4f} ms per step")

@@ -18,7 +18,7 @@ srcs = sorted(os.path.join(B.CSRC, f) for f in os.listdir(B.CSRC) if f.endswith(
 subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-shared",
                        "-DRSG_CONV_STAMPS", "-mllvm", "-amdgpu-mfma-vgpr-form", *srcs, "-o", so])
 os.environ["RSGNET_HIP_LIB"] = so
-os.environ["RSGNET_HIP_GRAPH"] = "0"
+os.environ["RSGNET_HIP_PLAN"] = "graph=0"
 import bench  # noqa: E402
 from rsgnet_amd import hip  # noqa: E402
 

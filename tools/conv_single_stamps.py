@@ -20,7 +20,7 @@ if not os.path.exists(so):
     subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-shared",
                            "-DRSG_CONV_STAMPS", "-mllvm", "-amdgpu-mfma-vgpr-form", *srcs, "-o", so])
 os.environ["RSGNET_HIP_LIB"] = so
-os.environ["RSGNET_HIP_GRAPH"] = "0"
+os.environ["RSGNET_HIP_PLAN"] = "graph=0"
 import bench  # noqa: E402
 from rsgnet_amd import hip  # noqa: E402
 

@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-os.environ["RSGNET_HIP_GRAPH"] = "0"
+os.environ["RSGNET_HIP_PLAN"] = "graph=0"
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
 from util import load_case  # noqa: E402

@@ -10,7 +10,7 @@ rc=$?; tail -25 $OUT/pytest_fm.log
 for rep in 1 2; do
   for v in 0 1; do
     for st in 2 1; do
-      env RSGNET_HIP_FUSE_MODULE=$v timeout -k 10 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --streams $st \
+      env RSGNET_HIP_PLAN="fuse_module=$v" timeout -k 10 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --streams $st \
         ${PEROP:+--per-op $OUT/per_op_${v}_${st}.json} > $OUT/fm_${v}_s${st}_${rep}.json 2> $OUT/fm_${v}_s${st}_${rep}.err || { tail -5 $OUT/fm_${v}_s${st}_${rep}.err; exit 1; }
       python - $OUT/fm_${v}_s${st}_${rep}.json "FUSE_MODULE=$v streams=$st run $rep" <<'PY'
 import json, sys

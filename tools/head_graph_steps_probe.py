@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU box probe: training steps of pose_rsgnet (FusedAdam through DataParallelStep, as bench.py --train) with the head
-eager and with the head replayed as HIP graphs (RSGNET_HIP_TRAIN_HEAD_GRAPH=1), step by step from the same state: loss,
+eager and with the head replayed as HIP graphs (RSGNET_HIP_TRAIN="head_graph=1"), step by step from the same state: loss,
 largest gradient and parameter differences, and the first tensors that differ."""
 import os
 import sys
@@ -22,7 +22,7 @@ dev = torch.device("cuda:0")
 
 
 def run(mode):
-    os.environ["RSGNET_HIP_TRAIN_HEAD_GRAPH"] = mode
+    os.environ["RSGNET_HIP_TRAIN"] = f"head_graph={mode}"
     cfg = make_cfg("pose_rsgnet", 32, (192, 256), 17)
     model = models.pose_rsgnet.get_pose_net(cfg, is_train=False)
     bn = dict(np.load(os.path.join(ROOT, "tests", "golden", "bnstats_rsgnet_w32_256x192_coco.npz")))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/lds_broadcast_canary.hip beside a model's forward graph on another stream: does the reduced form of the TRP
+"""(binaries under tools/_build/: `bash tools/build_reproducers.sh` rebuilds them from the sources; none is committed)
+tools/lds_broadcast_canary.hip beside a model's forward graph on another stream: does the reduced form of the TRP
 projection's access pattern (LDS table, uniform-address reads feeding an FMA chain) go wrong the way the kernel did?
 (hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast -shared -fPIC -o tools/_build/liblds_broadcast_canary.so tools/lds_broadcast_canary.hip)"""
 import ctypes, os, sys

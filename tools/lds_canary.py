@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/lds_canary.hip beside a model's forward graph on another stream: does anything write into the canary's LDS or
+"""(binaries under tools/_build/: `bash tools/build_reproducers.sh` rebuilds them from the sources; none is committed)
+tools/lds_canary.hip beside a model's forward graph on another stream: does anything write into the canary's LDS or
 damage its registers?  (hipcc --offload-arch=gfx950 -O2 -shared -fPIC -o tools/_build/liblds_canary.so tools/lds_canary.hip)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

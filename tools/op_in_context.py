@@ -7,7 +7,7 @@ import time
 
 import torch
 
-os.environ["RSGNET_HIP_GRAPH"] = "0"
+os.environ["RSGNET_HIP_PLAN"] = "graph=0"
 sys.path.insert(0, ".")
 import bench  # noqa: E402
 

@@ -40,7 +40,7 @@ def run(env):
 
 a, la = run({})
 b, lb = run({})
-c, lc = run({"RSGNET_HIP_TRAIN_WGRAD_STREAM": "0"})
+c, lc = run({"RSGNET_HIP_TRAIN": "wgrad_stream=0"})
 first_ab = next((i for i in range(N) if not torch.equal(a[i], b[i])), None)
 first_ac = next((i for i in range(N) if not torch.equal(a[i], c[i])), None)
 print(f"{N} training steps of 32 crops, parameters after every step: default vs default again: first difference at step {first_ab}; "

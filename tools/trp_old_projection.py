@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The TRP projection kernel as it stood before the fix (tools/trp_old_projection.hip), alone through its own .so, beside a
+"""(binaries under tools/_build/: `bash tools/build_reproducers.sh` rebuilds them from the sources; none is committed)
+The TRP projection kernel as it stood before the fix (tools/trp_old_projection.hip), alone through its own .so, beside a
 model's forward graph on another stream; variants: the plain build and one with every s_waitcnt forced to zero
 (-mllvm -amdgpu-waitcnt-forcezero).  Build:
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast [-mllvm -amdgpu-waitcnt-forcezero] -shared -fPIC \\

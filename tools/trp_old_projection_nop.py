@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""The ONE discriminating build DESIGN 9b' / VERDICT round 3 asked for: the TRP projection kernel as it stood (-O3 assembly of
+"""(binaries under tools/_build/: `bash tools/build_reproducers.sh` rebuilds them from the sources; none is committed)
+The ONE discriminating build DESIGN 9b' / VERDICT round 3 asked for: the TRP projection kernel as it stood (-O3 assembly of
 tools/trp_old_projection.hip) with `s_nop 3` in front of EVERY v_pk_fma_f32, i.e. four wait states between the v_mov_b32 that
 assembles a 64-bit operand and the packed FMA that reads it -- and nothing else changed (same registers, same loads, same
 order).  If the dropped FMA term is a read-after-write window between those two, this build cannot fail; if it still fails
