@@ -688,20 +688,20 @@ class TrainPlan:
         between) with the transposed, flipped weights (rsg_pack_conv_weights_device, transpose = 1)."""
         lib, B = self.lib, self.batch
         wp = self._packed(w, True)
-        src, sh, sw = dy, Ho, Wo
+        src, sh, swd = dy, Ho, Wo
         if stride == 2:
             if (2 * Ho, 2 * Wo) != (x.H, x.W):
                 raise NotImplementedError(f"{name}: stride-2 data gradient on an odd map")
             src = torch.zeros(B, 2 * Ho, 2 * Wo, dy_c, dtype=torch.bfloat16, device=self.device)
             self._emit("bwd", name + ".spread", lambda s: self._chk(lib.rsg_zero_insert2x(dy.data_ptr(), src.data_ptr(), B, Ho, Wo, dy_c, s), name))
-            sh, sw = 2 * Ho, 2 * Wo
+            sh, swd = 2 * Ho, 2 * Wo
         # x already has a gradient of its own (a BasicBlock's input: the residual branch of bn2 came first): the conv adds
         # it in its epilogue and writes in place -- one rounding instead of two, and no separate add launch (104 per step)
         fold = self._defer is None and x.needs_grad and x.grad is not None and not x.grad_shared and \
             sw.train_on("fold_add")
         dx = x.grad if fold else torch.zeros_like(x.data)
         cin_real = w.shape[1]
-        d = self._conv_desc(src, wp, self._zero_bias, dx, None, sh, sw, dy_c, cin_real, k, 1)
+        d = self._conv_desc(src, wp, self._zero_bias, dx, None, sh, swd, dy_c, cin_real, k, 1)
         if _round_up(cin_real, 32) != x.C:
             raise NotImplementedError(f"{name}: data gradient into a {x.C}-channel map")
         if fold:
