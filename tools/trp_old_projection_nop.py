@@ -6,7 +6,8 @@ assembles a 64-bit operand and the packed FMA that reads it -- and nothing else 
 order).  If the dropped FMA term is a read-after-write window between those two, this build cannot fail; if it still fails
 beside the model graph at the plain build's rate, the window is not the cause.  Both code objects are loaded through
 hipModuleLoad (tools/_build/trp_old_{plain,nop_before_pk_fma}.co; recipe: hipcc -S --cuda-device-only, the edit, clang -x
-assembler -target amdgcn-amd-amdhsa -mcpu=gfx950, ld.lld -shared)."""
+assembler -target amdgcn-amd-amdhsa -mcpu=gfx950, ld.lld -shared).
+Round 5: TRP_OLD_VARIANTS=plain,war_separated,plain runs the write-after-read build of tools/war_separate.py the same way."""
 import ctypes as C
 import os
 import sys
@@ -33,7 +34,7 @@ with torch.no_grad():
     with torch.cuda.stream(side):
         model(xc); model(xc)
     torch.cuda.synchronize()
-    for variant in ("plain", "nop_before_pk_fma", "plain"):
+    for variant in (os.environ.get("TRP_OLD_VARIANTS") or "plain,nop_before_pk_fma,plain").split(","):
         mod, fn = C.c_void_p(), C.c_void_p()
         assert hip.hipModuleLoad(C.byref(mod), os.path.join(here, "_build", f"trp_old_{variant}.co").encode()) == 0
         assert hip.hipModuleGetFunction(C.byref(fn), mod, NAME) == 0
