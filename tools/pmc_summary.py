@@ -9,7 +9,9 @@ import json
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
-FAM = (("chain_group_kernel", "chain_group_kernel"), ("chain_kernel", "chain_kernel"), ("conv_group_kernel", "conv_group_kernel"),
+FAM = (("fuse_module_kernel", "fuse_module_kernel"), ("fuse_head4_kernel", "fuse_head4_kernel"), ("conv_pair_next", "conv_pair_next(+cat)"),
+       ("conv_pair_kernel", "conv_pair_kernel"), ("conv_dual_kernel", "conv_dual_kernel"), ("stem_kernel", "stem_kernel"),
+       ("chain_group_wide_kernel", "chain_group_wide_kernel"), ("chain_group_kernel", "chain_group_kernel"), ("chain_kernel", "chain_kernel"), ("conv_group_kernel", "conv_group_kernel"),
        ("conv_igemm_kernel", "conv_igemm_kernel"), ("nchw_to_s2d16_kernel", "nchw_to_s2d16_kernel"), ("trp_", "trp kernels"))
 
 

@@ -17,7 +17,7 @@ with open("gpurun_out/pmc_sq/pmc_counter_collection.csv") as f:
             cnt[k] += 1
 out = {}
 for k, c in tot.items():
-    if not any(s in k for s in ("chain", "conv_", "stem", "trp", "bilinear", "crop")):
+    if not any(s in k for s in ("chain", "conv_", "stem", "trp", "bilinear", "crop", "fuse_")):
         continue
     wc = max(c["SQ_WAVE_CYCLES"], 1.0)
     # matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES counts cycles over all SIMDs (32 per 32x32x16 MFMA); the chip's
