@@ -42,6 +42,18 @@ def hip_lib_path():
     return hip.lib_path()
 
 
+def profile_build(path):
+    """The library build a committed profile was taken on: tools/gpu_r04_prof.sh writes <tag>_library_build.txt beside the
+    summaries of a visit; older evidence has none (None)."""
+    tag = os.path.basename(path).split("_")[0]
+    side = os.path.join(os.path.dirname(path), tag + "_library_build.txt")
+    if not os.path.exists(side):
+        return None
+    with open(side) as f:
+        words = f.read().split()
+    return words[words.index("build") + 1] if "build" in words else None
+
+
 def pmc_traffic(kernel_key, workload="hrnet_w32_256x192"):
     """HBM bytes per launch of a kernel from the committed PMC passes (profiles/*_pmc_summary.json:
     FETCH_SIZE x2-corrected as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE), or None.  The passes are
@@ -58,7 +70,7 @@ def pmc_traffic(kernel_key, workload="hrnet_w32_256x192"):
         return None
     return {"bytes_per_launch": int((d["fetch_mb_per_launch"] + d["write_mb_per_launch"]) * 1e6),
             "fetch_mb": d["fetch_mb_per_launch"], "write_mb": d["write_mb_per_launch"],
-            "source": os.path.basename(files[-1])}
+            "source": os.path.basename(files[-1]), "source_build": profile_build(files[-1])}
 def rocprof_kernel(kernel_prefix, workload, gflop_per_step, launches_per_step):
     """Average duration of a kernel in the committed `rocprofv3 --kernel-trace --stats` summary of the one-stream bench
     command (profiles/*_kernel_stats_one_stream.csv, tools/gpu_r04_prof.sh) and the roofline fraction it implies; None when
@@ -77,7 +89,7 @@ def rocprof_kernel(kernel_prefix, workload, gflop_per_step, launches_per_step):
                 us = float(r["AverageNs"]) / 1e3
                 tf = gflop_per_step / (launches_per_step * us) * 1e3
                 return {"avg_us_per_launch": round(us, 2), "tflops": round(tf, 1), "frac": round(tf / PEAK_TFLOPS, 4),
-                        "source": os.path.basename(files[-1])}
+                        "source": os.path.basename(files[-1]), "source_build": profile_build(files[-1])}
     return None
 
 
@@ -96,7 +108,8 @@ def pmc_mfma_busy(kernel_prefix, workload="hrnet_w32_256x192"):
         for k, v in d.items():
             if k.startswith(kernel_prefix) and v.get("mfma_busy_frac") is not None:
                 return {"mfma_busy_frac": v["mfma_busy_frac"], "wait_any_frac": v.get("wait_any_frac"),
-                        "wait_inst_any_frac": v.get("wait_inst_any_frac"), "source": os.path.basename(path)}
+                        "wait_inst_any_frac": v.get("wait_inst_any_frac"), "source": os.path.basename(path),
+                        "source_build": profile_build(path)}
     return None
 
 

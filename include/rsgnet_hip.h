@@ -447,6 +447,20 @@ int rsg_rows_project_f32(const float* a, const float* m, float* out, int64_t row
 size_t rsg_rows_gram_workspace_bytes(int32_t C);
 int rsg_rows_gram_f32(const float* a, const float* b, float* gram, float* colsum, int64_t rows, int32_t C, void* workspace,
                       void* stream);
+/* SGM graph convolution = KTMachine.forward (/root/reference/lib/models/pose_rsgnet.py:576-600; constructor :499-521):
+ *   K = matrix_limb (.) real_matrix_limb [limbs,joints];  T = K . wk  (wk = final_layer.weight as [joints,channels]);
+ *   wl = Linear2(LeakyReLU_slope(Linear1(T)))  [limbs,channels]  -- the limb classifier's weight of :1003-1005.
+ * Everything fp32, row-major, on the device; w1 / w2 in torch's Linear layout [out,in]; limbs, joints <= 32, channels <= 64.
+ * t_saved / h_saved [limbs,channels]: T and Linear1's output before the LeakyReLU, written by the forward and read by the
+ * backward (training).  One workgroup; every sum in index order (bit-reproducible).  The backward writes the gradients of
+ * matrix_limb (masked by the prior, as autograd's), wk, and the two Linears from d_wl [limbs,channels]. */
+int rsg_sgm_graph_conv(const float* matrix_limb, const float* prior, const float* wk, const float* w1, const float* b1,
+                       const float* w2, const float* b2, float* wl, float* t_saved, float* h_saved, int32_t limbs,
+                       int32_t joints, int32_t channels, float slope, void* stream);
+int rsg_sgm_graph_conv_backward(const float* matrix_limb, const float* prior, const float* wk, const float* w1,
+                                const float* w2, const float* t_saved, const float* h_saved, const float* d_wl,
+                                float* d_matrix_limb, float* d_wk, float* d_w1, float* d_b1, float* d_w2, float* d_b2,
+                                int32_t limbs, int32_t joints, int32_t channels, float slope, void* stream);
 /* optional materialisation of relation_score [batch,S,S] fp32 (association.py:294-295) */
 int rsg_trp_scores(const void* x, int32_t ld_x, float* scores, int32_t batch, int32_t S, int32_t C,
                    int32_t dtype, void* stream);

@@ -125,6 +125,8 @@ SYMBOLS = {
     "rsg_basic_chain_supported": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_basic_chain_supported_split": (C.c_int, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_conv_groupable": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rsg_sgm_graph_conv": (C.c_int, [_vp] * 10 + [_i, _i, _i, C.c_float, _vp]),
+    "rsg_sgm_graph_conv_backward": (C.c_int, [_vp] * 14 + [_i, _i, _i, C.c_float, _vp]),
     "rsg_fuse_module_table_bytes": (C.c_size_t, []),
     "rsg_fuse_module_plan": (C.c_int, [C.POINTER(FuseModuleDesc), _vp, C.POINTER(C.c_int32)]),
     "rsg_fuse_module_run": (C.c_int, [_vp, _i, _i, _i, _vp]),

@@ -38,8 +38,14 @@ def folded_type_conv_weight(model) -> torch.Tensor:
 
 
 def limb_classifier(model) -> torch.Tensor:
-    """KTMachine.forward(final_layer.weight) -> [L,C0,1,1]  (pose_rsgnet.py:576-600,1004)."""
+    """KTMachine.forward(final_layer.weight) -> [L,C0,1,1]  (pose_rsgnet.py:576-600,1004).  With the parameters on the GPU
+    (every plan build) the SGM's graph convolution runs on the library's kernel (rsg_sgm_graph_conv, fp32); on the CPU
+    (host-side tests against the goldens) the same four statements in fp64."""
     kt = model.kt_machine
+    if model.final_layer.weight.is_cuda:
+        from .train_ops import sgm_graph_conv
+        with torch.no_grad():
+            return sgm_graph_conv(kt, model.final_layer.weight.detach()).float().cpu()
     wk = model.final_layer.weight.detach().double().cpu()
     n_out, n_in, h, w = wk.shape
     k = kt.matrix_limb.detach().double().cpu() * kt.real_matrix_limb.detach().double().cpu()

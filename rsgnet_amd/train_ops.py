@@ -412,6 +412,53 @@ def rows_project(a: torch.Tensor, m: torch.Tensor, out: Optional[torch.Tensor] =
     return out
 
 
+class SgmGraphConv(torch.autograd.Function):
+    """The SGM's graph convolution (KTMachine.forward, /root/reference/lib/models/pose_rsgnet.py:576-600) on rsg_sgm_graph_conv:
+    Wl [L,D] = Linear2(LeakyReLU_0.02(Linear1((matrix_limb * prior) @ Wk))) with Wk [J,D] the joint classifier's weight; the
+    backward (rsg_sgm_graph_conv_backward) returns the gradients of matrix_limb, Wk and the two Linears.  fp32, one launch each."""
+
+    @staticmethod
+    def forward(ctx, limb, prior, wk, w1, b1, w2, b2, slope: float):
+        _need_gpu(wk, "SgmGraphConv")
+        lib = hip.lib()
+        L, J = limb.shape
+        D = wk.shape[1]
+        args = [t.detach().float().contiguous() for t in (limb, prior, wk, w1, b1, w2, b2)]
+        wl = torch.empty(L, D, dtype=torch.float32, device=wk.device)
+        t, h = torch.empty_like(wl), torch.empty_like(wl)
+        hip.check(lib.rsg_sgm_graph_conv(*[a.data_ptr() for a in args], wl.data_ptr(), t.data_ptr(), h.data_ptr(), L, J, D,
+                                         float(slope), _stream(wk)), "sgm_graph_conv")
+        ctx.save_for_backward(*args[:4], args[5], t, h)
+        ctx.slope = float(slope)
+        return wl
+
+    @staticmethod
+    def backward(ctx, d_wl):
+        lib = hip.lib()
+        limb, prior, wk, w1, w2, t, h = ctx.saved_tensors
+        L, J = limb.shape
+        D = wk.shape[1]
+        d_wl = d_wl.float().contiguous()
+        d_limb, d_wk, d_w1, d_w2 = (torch.empty_like(x) for x in (limb, wk, w1, w2))
+        d_b1 = torch.empty(D, dtype=torch.float32, device=wk.device)
+        d_b2 = torch.empty_like(d_b1)
+        hip.check(lib.rsg_sgm_graph_conv_backward(limb.data_ptr(), prior.data_ptr(), wk.data_ptr(), w1.data_ptr(), w2.data_ptr(),
+                                                  t.data_ptr(), h.data_ptr(), d_wl.data_ptr(), d_limb.data_ptr(), d_wk.data_ptr(),
+                                                  d_w1.data_ptr(), d_b1.data_ptr(), d_w2.data_ptr(), d_b2.data_ptr(), L, J, D, ctx.slope,
+                                                  _stream(wk)), "sgm_graph_conv_backward")
+        return d_limb, None, d_wk, d_w1, d_b1, d_w2, d_b2, None
+
+
+def sgm_graph_conv(kt: nn.Module, weight: torch.Tensor) -> torch.Tensor:
+    """kt_machine(final_layer.weight) -> [L,C0,1,1] on the HIP kernel (1x1 classifiers: the reshape of pose_rsgnet.py:591-593
+    is the identity on [J,C0])."""
+    n_out, n_in, kh, kw = weight.shape
+    l0, act, l2 = kt.kpt_transformer[0], kt.kpt_transformer[1], kt.kpt_transformer[2]
+    wl = SgmGraphConv.apply(kt.matrix_limb, kt.real_matrix_limb, weight.reshape(n_out, n_in * kh * kw), l0.weight, l0.bias,
+                            l2.weight, l2.bias, float(act.negative_slope))
+    return wl.reshape(wl.shape[0], n_in, kh, kw)
+
+
 class GroupNormTail(torch.autograd.Function):
     """out16 [B,S,C] bf16 = GroupNorm(8, C)(e @ w^T + bias) from the TRP's fp32 rows e [B,S,C]."""
 

@@ -14,7 +14,8 @@
   * what depends on the weights alone stays an ordinary autograd expression over a few KB, evaluated on the device by
     PyTorch-ROCm: type_fc (Linear -> BatchNorm1d over the J rows -> ReLU) folded with type_conv's weight into a 3x3 conv
     J -> C0, W'[o,j] = sum_c type_conv.W[o,c] * Tm[j,c] (the [B,600,H,W] map of pose_rsgnet.py:974 is never built);
-    KTMachine (the limb classifier's weight from final_layer's); the location clue loc_conv(loc_features);
+    the location clue loc_conv(loc_features); KTMachine -- the SGM's graph convolution, the limb classifier's weight from
+    final_layer's -- is the library's rsg_sgm_graph_conv in both directions (train_ops.SgmGraphConv);
   * W behind the TRP (1x1 conv + bias -> GroupNorm, association.py:298-300: `GroupNormTail`) and the two x2 bilinear
     up-samplings with the limb maps' sigmoid (`Bilinear2x`) are autograd nodes on the library's kernels too;
   * the keypoint branch's up-sampler (ConvTranspose2d + BatchNorm + ReLU) runs as four sub-pixel 2x2 convs with their
@@ -32,8 +33,13 @@ from . import switches as sw
 
 
 def kt_machine_forward(kt, weight: torch.Tensor) -> torch.Tensor:
-    """KTMachine.forward (pose_rsgnet.py:576-600): the limb classifier from the joint classifier's weights."""
+    """KTMachine.forward (pose_rsgnet.py:576-600): the limb classifier from the joint classifier's weights.  On the GPU: the
+    SGM graph-conv kernel in both directions (train_ops.SgmGraphConv); the expression below is its CPU statement (host-side
+    tests of the head's algebra against the fp64 oracle)."""
     n_out, n_in, h, w = weight.shape
+    if weight.is_cuda and n_out <= 32 and kt.matrix_limb.shape[0] <= 32 and n_in * h * w <= 64:
+        from .train_ops import sgm_graph_conv
+        return sgm_graph_conv(kt, weight)
     k = kt.matrix_limb * kt.real_matrix_limb                              # learned L x J masked by the 0/1 skeleton prior
     t = k @ weight.reshape(n_out, n_in * h * w)
     t = kt.kpt_transformer(t)                                            # Linear -> LeakyReLU(0.02) -> Linear

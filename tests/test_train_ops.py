@@ -173,3 +173,33 @@ def test_deconv_bn_relu_matches_autograd():
     print("  deconv_bn_relu:", {n: f"{v:.2e}" for n, v in errs.items()})
     assert ez < 2 ** -6
     assert errs["dx"] < 1e-2 and errs["dw"] < 1e-2 and errs["dgamma"] < 1e-2 and errs["dbeta"] < 1e-2, errs
+
+
+@pytest.mark.parametrize("limbs,joints,channels", [(18, 17, 32), (14, 14, 32), (14, 14, 48), (32, 32, 64), (1, 1, 8)])
+def test_sgm_graph_conv_matches_the_reference_module_and_its_autograd(limbs, joints, channels):
+    """rsg_sgm_graph_conv[_backward] against KTMachine's four statements (/root/reference/lib/models/pose_rsgnet.py:576-600) in
+    fp64 autograd on the CPU: the limb classifier and the gradients of matrix_limb, the joint classifier's weight and both
+    Linears; the prior's zeros stay zeros in d matrix_limb; two runs give the same bits."""
+    from rsgnet_amd.train_ops import SgmGraphConv
+    g = torch.Generator().manual_seed(limbs * 1000 + joints * 10 + channels)
+    limb = torch.randn(limbs, joints, generator=g)
+    prior = (torch.rand(limbs, joints, generator=g) < 0.2).float()
+    prior[0, 0] = 1.0
+    wk = torch.randn(joints, channels, generator=g) * 0.3
+    w1, w2 = (torch.randn(channels, channels, generator=g) * (2.0 / channels) ** 0.5 for _ in range(2))
+    b1, b2 = (torch.randn(channels, generator=g) * 0.1 for _ in range(2))
+    dwl = torch.randn(limbs, channels, generator=g)
+    dev = [t.cuda().requires_grad_(True) for t in (limb, wk, w1, b1, w2, b2)]
+    wl = SgmGraphConv.apply(dev[0], prior.cuda(), *dev[1:], 0.02)
+    grads = torch.autograd.grad((wl * dwl.cuda()).sum(), dev)
+    wl2 = SgmGraphConv.apply(dev[0], prior.cuda(), *dev[1:], 0.02)
+    grads2 = torch.autograd.grad((wl2 * dwl.cuda()).sum(), dev)
+    assert torch.equal(wl, wl2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+    ref = [t.double().requires_grad_(True) for t in (limb, wk, w1, b1, w2, b2)]
+    t = (ref[0] * prior.double()) @ ref[1]
+    out = F.linear(F.leaky_relu(F.linear(t, ref[2], ref[3]), 0.02), ref[4], ref[5])
+    want = torch.autograd.grad((out * dwl.double()).sum(), ref)
+    assert _rel(wl, out) < 2e-6
+    for name, a, b in zip(("matrix_limb", "wk", "w1", "b1", "w2", "b2"), grads, want):
+        assert _rel(a, b) < 5e-6, name
+    assert not (grads[0].cpu()[prior == 0]).any()

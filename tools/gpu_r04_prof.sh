@@ -4,6 +4,7 @@
 TAG=${TAG:-r04}
 mkdir -p gpurun_out; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || { tail -20 gpurun_out/build.log; exit 1; }
+python -c "from rsgnet_amd import build; print(build.describe())" > gpurun_out/${TAG}_library_build.txt
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --per-op gpurun_out/${TAG}_per_op.json > gpurun_out/${TAG}_bench.log 2>&1 || { tail -5 gpurun_out/${TAG}_bench.log; exit 1; }
 tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json
 rm -rf gpurun_out/prof gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
