@@ -269,7 +269,14 @@ static int stem_launch(const void* xs, const float* x_nchw_f32, const void* w1_p
     if ((uintptr_t)x_nchw_f32 & 7) RSG_FAIL("stem_fused: the picture must be 8-byte aligned");
     if (batch < 1 || h < 4 || w < 4 || (h & 3) || (w & 3) || out_ld < 64 || (out_ld & 7)) RSG_FAIL("stem_fused: bad shape");
     if (((uintptr_t)xs | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)out16) & 15) RSG_FAIL("stem_fused: alignment");
-    constexpr int TH2 = 4, TW2 = 12;
+    // tile of conv2 outputs per workgroup (-DRSG_STEM_TH2 / _TW2: same-visit A/B builds; every tiling gives the same bits)
+#ifndef RSG_STEM_TH2
+#define RSG_STEM_TH2 4
+#endif
+#ifndef RSG_STEM_TW2
+#define RSG_STEM_TW2 12
+#endif
+    constexpr int TH2 = RSG_STEM_TH2, TW2 = RSG_STEM_TW2;
     StemArgs a;
     a.xs = (const char*)xs; a.x32 = xs ? nullptr : x_nchw_f32; a.w1 = (const uint4*)w1_packed; a.b1 = bias1; a.w2 = (const uint4*)w2_packed; a.b2 = bias2;
     a.out = (char*)out16; a.B = batch; a.H1 = h / 2; a.W1 = w / 2; a.H2 = h / 4; a.W2 = w / 4; a.ldo = out_ld;
