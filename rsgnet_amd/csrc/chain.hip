@@ -710,9 +710,11 @@ extern int g_bottleneck_debug;
 #endif
 extern int g_fm_prefetch;              // fuse_module.hip
 extern int g_stem_persist;             // stem.hip
+extern int g_dual_waves;               // dual.hip
 extern "C" int rsg_tune(const char* key, int32_t value) {
     if (key && !strcmp(key, "fm_prefetch")) { g_fm_prefetch = value ? 1 : 0; return 0; }
     if (key && !strcmp(key, "stem_persist")) { g_stem_persist = value ? 1 : 0; return 0; }
+    if (key && !strcmp(key, "dual_waves") && (value == 2 || value == 4)) { g_dual_waves = value; return 0; }
     if (key && !strcmp(key, "bottleneck_head") && (value == 1 || value == 2)) { g_bottleneck_head = value; return 0; }
 #ifdef RSG_DEBUG
     if (key && !strcmp(key, "bottleneck_debug")) { g_bottleneck_debug = value; return 0; }

@@ -22,11 +22,17 @@ struct DualArgs {
 // CTA / CTB: 32-channel output tiles of conv A / conv B -- (1, 2) for HRNet-W32 (256 -> 32 and 256 -> 64), (2, 3) for
 // HRNet-W48 (256 -> 48 padded to 64, and 256 -> 96).  Conv A: a wave owns two pixel groups and all CTA tiles of them (one B
 // fragment feeds CTA MFMAs); conv B: 2 x CTB (pixel group, tile) jobs dealt to the four waves, job j = wave + 4 k.
-template <class DT, int CTA, int CTB>
-__global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
+// NW = 2 (round 5, HRNet-W32's transition): TWO waves per workgroup, four conv-A pixel groups each and both pixel groups of
+// ONE conv-B tile, so that a weight fragment feeds four / two MFMAs instead of two / one.  The launch is bound by the weight
+// fragments its waves fetch (885 MB per launch through the CUs' vector-memory paths at ~25 B/clk per CU = its 59 us; the map it
+// reads is 127 MB): half the fragments per pixel, the same three workgroups per CU.  Same per-pixel arithmetic: bit-identical.
+template <class DT, int CTA, int CTB, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) conv_dual_kernel(const DualArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TH = 16, TW = 16, TIH = 18, TIW = 18, CINB = 64, PS = 2 * CINB + 16, CPP = CINB / 8, KPT = 4, KSB = 36, NT = 2;
-    constexpr int NLD = 8, NPF = 6, NJB = (2 * CTB + 3) / 4;
+    constexpr int TH = 16, TW = 16, TIH = 18, TIW = 18, CINB = 64, PS = 2 * CINB + 16, CPP = CINB / 8, KPT = 4, KSB = 36, NT = 8 / NW;
+    constexpr int NLD = 8, NPF = 6, NJB = (2 * CTB + NW - 1) / NW, NTHR = 64 * NW;
+    constexpr bool SHARE_B = NW == 2 && CTB == 2;         // a wave's conv-B jobs are the two pixel groups of one tile
+    static_assert(NW == 4 || SHARE_B, "two waves: the conv-B jobs of a wave must share their tile");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hh = lane >> 5;
@@ -47,7 +53,7 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
     int pixB[NJB], opixB[NJB], ctB[NJB];
 #pragma unroll
     for (int k = 0; k < NJB; ++k) {
-        const int j = wave + 4 * k;                           // wave-uniform
+        const int j = wave + NW * k;                          // wave-uniform
         ctB[k] = j < 2 * CTB ? j % CTB : -1;
         const int q = (j < 2 * CTB ? j / CTB : 0) * 32 + n, py = q / (TW / 2), px = q - py * (TW / 2);
         pixB[k] = (2 * py) * p.RP + (2 * px) * PS + hh * 16;
@@ -64,7 +70,8 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
 #pragma unroll
     for (int c = 0; c < CTA; ++c) {
         bias16(p.bA + c * 32 + hh * 16, accA[0][c]);
-        accA[1][c] = accA[0][c];
+#pragma unroll
+        for (int g = 1; g < NT; ++g) accA[g][c] = accA[0][c];
     }
 #pragma unroll
     for (int k = 0; k < NJB; ++k) bias16(p.bB + (ctB[k] < 0 ? 0 : ctB[k]) * 32 + hh * 16, accB[k]);
@@ -84,12 +91,12 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
 #pragma unroll
         for (int f = 0; f < NPF; ++f) aq[f] = fragA(f);
         // ---- stage 64 channels of the input tile (+halo), zero outside the picture
-        for (int base = 0; base < total; base += 256 * NLD) {
+        for (int base = 0; base < total; base += NTHR * NLD) {
             uint4 r[NLD];
             int lo[NLD];
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
-                const int id = base + j * 256 + tid;
+                const int id = base + j * NTHR + tid;
                 r[j] = make_uint4(0, 0, 0, 0);
                 lo[j] = -1;
                 if (id < total) {
@@ -132,7 +139,28 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- conv B on the same staged tile, job by job
+        // ---- conv B on the same staged tile: both pixel groups of the wave's tile per fragment (two waves), or job by job
+        if constexpr (SHARE_B) {
+            const uint4* aB = p.wB + ((size_t)ctB[0] * KS + (size_t)ch * KSB) * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < NPF; ++f) aq[f] = aB[f * 64];
+            uint4 bq[2][2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) bq[0][k] = *reinterpret_cast<const uint4*>(smem + pixB[k] + boff(0));
+#pragma unroll
+            for (int ks = 0; ks < KSB; ++ks) {
+                const typename DT::vec8 a = __builtin_bit_cast(typename DT::vec8, aq[ks % NPF]);
+                if (ks + 1 < KSB) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) bq[(ks + 1) & 1][k] = *reinterpret_cast<const uint4*>(smem + pixB[k] + boff(ks + 1));
+                }
+                if (ks + NPF < KSB) aq[ks % NPF] = aB[(ks + NPF) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) accB[k] = DT::mfma(a, __builtin_bit_cast(typename DT::vec8, bq[ks & 1][k]), accB[k]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int k = 0; k < NJB; ++k) {
             if (ctB[k] < 0) continue;                         // wave-uniform
@@ -178,6 +206,8 @@ __global__ void __launch_bounds__(256) conv_dual_kernel(const DualArgs p) {
 // a: the stride-1 conv (3x3, pad 1, cin a multiple of 64, 16-bit NHWC output, no residual); the stride-2 conv reads the same
 // input: wB/biasB packed for (cin, cout_b, 3x3), outB [batch, h/2, w/2, out_ld_b] (h, w even).  (cout_a <= 32, cout_b = 64)
 // or (cout_a <= 64, cout_b = 96).
+int g_dual_waves = 2;                  // rsg_tune("dual_waves", 2|4): waves per workgroup of the 256 -> 32 / 64 form
+
 extern "C" int rsg_conv_dual(const rsg_conv_desc* a, const void* wB_packed, const float* biasB, void* outB16, int32_t out_ld_b,
                              int32_t cout_b, int32_t relu_b, void* stream) {
     if (!a || !a->in || !a->w_packed || !a->bias || !a->out16 || !wB_packed || !biasB || !outB16) RSG_FAIL("conv_dual: null pointer");
@@ -209,7 +239,10 @@ extern "C" int rsg_conv_dual(const rsg_conv_desc* a, const void* wB_packed, cons
     const int lds = 18 * p.RP;
     const dim3 grid(a->batch * p.tiles_x * p.tiles_y);
     hipStream_t s = (hipStream_t)stream;
-    if (cta == 1) {
+    if (cta == 1 && g_dual_waves == 2) {
+        if (a->dtype == RSG_BF16) RSG_LAUNCH((conv_dual_kernel<BF16, 1, 2, 2>), grid, dim3(128), lds, s, p);
+        else RSG_LAUNCH((conv_dual_kernel<F16, 1, 2, 2>), grid, dim3(128), lds, s, p);
+    } else if (cta == 1) {
         if (a->dtype == RSG_BF16) RSG_LAUNCH((conv_dual_kernel<BF16, 1, 2>), grid, dim3(256), lds, s, p);
         else RSG_LAUNCH((conv_dual_kernel<F16, 1, 2>), grid, dim3(256), lds, s, p);
     } else {

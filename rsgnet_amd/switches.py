@@ -68,7 +68,7 @@ TRAIN: Dict[str, Tuple[str, object]] = {
 }
 # RSGNET_HIP_TUNE: keys of rsg_tune (csrc/chain.hip) and, prefixed wgrad_, the five integers of rsg_wgrad_tune / rsg_wgrad_set_quad
 TUNE_KEYS = ("chain_max_ni", "chain_pitch_pad", "conv_lds_limit", "chain_prefetch", "conv_full_k", "conv_spread",
-             "bottleneck_head", "chain_dual", "chain_split_rows", "fm_prefetch", "stem_persist", "chain_debug", "bottleneck_debug",
+             "bottleneck_head", "chain_dual", "chain_split_rows", "fm_prefetch", "stem_persist", "dual_waves", "chain_debug", "bottleneck_debug",
              "wgrad_min_px", "wgrad_quad_min_wgs", "wgrad_lds", "wgrad_px_cap", "wgrad_waves", "wgrad_quad")
 
 _VARS = {"plan": ("RSGNET_HIP_PLAN", PLAN), "train": ("RSGNET_HIP_TRAIN", TRAIN)}
