@@ -28,3 +28,5 @@ timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAI
 python tools/sq_summary.py ${TAG}_tmp > /dev/null && mv profiles/${TAG}_tmp_sq_summary.json gpurun_out/${TAG}_sq_summary_rsgnet_crowdpose_fliptest.json
 head -8 gpurun_out/${TAG}_rsgnet_crowdpose_fliptest_kernel_stats.csv | cut -c1-150
 echo visit done
+# the raw counter / trace dumps stay on the box (gpurun copies back at most 64 MiB): the summaries above are what is kept
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/prof gpurun_out/prof_cp gpurun_out/prof_w48

@@ -18,3 +18,5 @@ mkdir -p profiles
 python tools/pmc_summary.py ${TAG}_tmp > /dev/null && mv profiles/${TAG}_tmp_pmc_summary.json gpurun_out/${TAG}_pmc_summary.json
 python tools/sq_summary.py ${TAG}_tmp > /dev/null && mv profiles/${TAG}_tmp_sq_summary.json gpurun_out/${TAG}_sq_summary.json
 head -c 400 gpurun_out/${TAG}_bench.json; echo; head -12 gpurun_out/${TAG}_kernel_stats_one_stream.csv | cut -c1-160
+# the raw counter / trace dumps stay on the box (gpurun copies back at most 64 MiB): the summaries above are what is kept
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq gpurun_out/prof gpurun_out/prof_cp gpurun_out/prof_w48

@@ -10,7 +10,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 FAM = (("fuse_module_kernel", "fuse_module_kernel"), ("fuse_head4_kernel", "fuse_head4_kernel"), ("conv_pair_next", "conv_pair_next(+cat)"),
-       ("conv_pair_kernel", "conv_pair_kernel"), ("conv_dual_kernel", "conv_dual_kernel"), ("stem_kernel", "stem_kernel"),
+       ("conv_pair_kernel", "conv_pair_kernel"), ("conv_dual_kernel", "conv_dual_kernel"), ("stem_persist_kernel", "stem_persist_kernel"), ("stem_kernel", "stem_kernel"),
        ("chain_group_wide_kernel", "chain_group_wide_kernel"), ("chain_group_kernel", "chain_group_kernel"), ("chain_kernel", "chain_kernel"), ("conv_group_kernel", "conv_group_kernel"),
        ("conv_igemm_kernel", "conv_igemm_kernel"), ("nchw_to_s2d16_kernel", "nchw_to_s2d16_kernel"), ("trp_", "trp kernels"))
 
