@@ -1248,3 +1248,63 @@ def test_fuse_classifier_and_head4_equal_the_separate_launches():
     assert torch.isfinite(outs["separate"]).all()
     assert torch.equal(outs["separate"], outs["sum+classifier"]) and torch.equal(outs["separate"], outs["module+classifier"])
     assert nops["sum+classifier"] == nops["separate"] - 1 and nops["module+classifier"] == nops["separate"] - 2
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 48, 0), (5, 100, 52, 0), (140, 64, 48, 0), (9, 256, 192, 0), (2, 384, 288, 1), (40, 96, 80, 1)])
+def test_persistent_stem_equals_the_per_tile_stem(shape):
+    """rsg_stem_fused_conv1 as persistent workgroups with conv2's weights in registers (stem_persist_kernel, the default) against
+    the one-tile-per-workgroup kernel (rsg_tune stem_persist 0), bit for bit, through the C ABI: both outputs (stem, layer1.0's
+    conv1), tiles that hang over the right / bottom edge (W/4 = 12, 13, 20), fewer tiles than workgroups and more (140 pictures:
+    560 tiles on 512 workgroups, so the walk over tiles and the prefetch of the next window run), the picture read directly
+    (fp32 NCHW) and through the space-to-depth map, fp16 and bf16."""
+    B, H, W, dt = shape
+    lib = hip.lib()
+    g = torch.Generator().manual_seed(H * 7 + W + B)
+    x = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    w1 = torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5
+    w2 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    w3 = torch.randn(64, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    w1s = torch.zeros(64, 16, 2, 2)                      # conv1 as a 2x2 conv over the space-to-depth picture (plan.py, _record_stem_s2d)
+    for a in range(2):
+        for py in range(2):
+            ky = 2 * (a - 1) + py + 1
+            if not 0 <= ky <= 2:
+                continue
+            for b in range(2):
+                for px in range(2):
+                    kx = 2 * (b - 1) + px + 1
+                    if 0 <= kx <= 2:
+                        w1s[:, (py * 2 + px) * 3:(py * 2 + px) * 3 + 3, a, b] = w1[:, :, ky, kx]
+
+    def pack(w):
+        O, I, kh, kw = w.shape
+        s, h = torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.1
+        wp = np.zeros(lib.rsg_conv_packed_bytes(I, O, kh, kw), np.uint8)
+        bo = np.zeros(O, np.float32)
+        hip.check(lib.rsg_pack_conv_weights_host(np.ascontiguousarray(w.numpy()).ctypes.data, s.numpy().ctypes.data, h.numpy().ctypes.data,
+                                                 None, I, O, kh, kw, dt, wp.ctypes.data, bo.ctypes.data))
+        return torch.from_numpy(wp).to(DEV), torch.from_numpy(bo).to(DEV)
+
+    (p1, b1), (p2, b2), (p3, b3) = pack(w1s), pack(w2), pack(w3)
+    t16 = torch.bfloat16 if dt else torch.float16
+    xs = torch.empty(B, H // 2, W // 2, 16, dtype=t16, device=DEV)
+    hip.check(lib.rsg_nchw_f32_to_s2d_nhwc16(x.data_ptr(), xs.data_ptr(), B, 3, H, W, dt, _stream()), "s2d")
+    res = {}
+    try:
+        for persist in (0, 1):
+            assert lib.rsg_tune(b"stem_persist", persist) == 0
+            for direct in (0, 1):
+                out = torch.full((B, H // 4, W // 4, 64), float("nan"), dtype=t16, device=DEV)
+                out3 = torch.full_like(out, float("nan"))
+                hip.check(lib.rsg_stem_fused_conv1(None if direct else xs.data_ptr(), x.data_ptr() if direct else None, p1.data_ptr(),
+                                                   b1.data_ptr(), p2.data_ptr(), b2.data_ptr(), out.data_ptr(), 64, p3.data_ptr(),
+                                                   b3.data_ptr(), out3.data_ptr(), 64, B, H, W, dt, _stream()), "stem_fused_conv1")
+                torch.cuda.synchronize()
+                assert torch.isfinite(out.float()).all() and torch.isfinite(out3.float()).all()
+                res[persist, direct] = (out, out3)
+    finally:
+        lib.rsg_tune(b"stem_persist", 1)
+    for direct in (0, 1):
+        assert torch.equal(res[0, direct][0], res[1, direct][0]) and torch.equal(res[0, direct][1], res[1, direct][1]), direct
+    assert torch.equal(res[1, 0][0], res[1, 1][0])                       # both input paths round the picture alike
+    assert float(res[1, 1][0].float().abs().max()) > 0.1
