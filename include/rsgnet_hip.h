@@ -358,6 +358,10 @@ int rsg_fuse_module_table_jobs(const void* table_host, int32_t* info4, int32_t* 
  * (pose_rsgnet.py:1009-1013) */
 int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t planes, int32_t h, int32_t w,
                             int32_t sigmoid, void* stream);
+/* Two maps of the same size in ONE launch (RSGNet's multi_kpt_scores and limbs_scores, pose_rsgnet.py:1009-1013: the second
+ * through torch.sigmoid): map a's planes, then map b's. */
+int rsg_bilinear2x_pair_nchw_f32(const float* in_a, float* out_a, int32_t planes_a, int32_t sigmoid_a, const float* in_b,
+                                 float* out_b, int32_t planes_b, int32_t sigmoid_b, int32_t h, int32_t w, void* stream);
 /* Backward of rsg_bilinear2x_nchw_f32 (training; autograd of F.interpolate(scale_factor=2, 'bilinear', align_corners=True)
  * [+ torch.sigmoid], /root/reference/lib/models/pose_rsgnet.py:1009-1013): din [planes,h,w] from dout [planes,2h,2w];
  * prob = the forward's sigmoid output (the gradient then passes through p (1 - p) first) or NULL.  Gather form, fixed order. */
@@ -399,6 +403,13 @@ size_t rsg_trp_tail_workspace_bytes(int32_t batch, int32_t S, int32_t C);
 int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,
                  const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
                  int32_t dtype, void* workspace, void* stream);
+/* The same with the input form and the workspace's use as arguments: e16_ld = 0: e is fp32 [batch,S,C] (rsg_trp_tail), else
+ * the 16-bit map of rsg_trp_tail_in16 with that channel stride; keep_y = 0 (inference): the fp32 projection y = W e + b is NOT
+ * written to the workspace -- only rsg_trp_tail_backward reads it -- and the GroupNorm pass recomputes it from e (the same
+ * expression, the same bits): 4 C bytes per position less written and read back. */
+int rsg_trp_tail_ex(const void* e, int32_t e16_ld, const float* w, const float* bias, const float* gn_gamma,
+                    const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
+                    int32_t dtype, int32_t keep_y, void* workspace, void* stream);
 /* RELATION_SUB_SAMPLE variant of the TRP (/root/reference/lib/models/association.py:254-268,286-287; set by
  * experiments/crowdpose/hrnet/"rsgnet_w48_256x192_adam_lr1e-3 .yaml":42): the relation runs on the 2x2 max-pooled map
  * and an up-sampling deconv + BatchNorm + ReLU precedes W.

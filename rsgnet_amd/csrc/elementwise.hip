@@ -154,37 +154,52 @@ extern "C" int rsg_hr_fuse_sum(const void* const* same, int32_t n_same, const vo
 }
 
 // ---- bilinear x2, align_corners=True, optional sigmoid, fp32 NCHW (pose_rsgnet.py:1009-1013) -----------
-// src = dst * (in-1)/(out-1); out = 2*in.  One thread per 4 consecutive output x (16-byte store).
-__global__ void __launch_bounds__(256) bilinear2x_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                        int h, int w, long total4, int sigmoid) {
-    const int ow = 2 * w, oh = 2 * h;
+// src = dst * (in-1)/(out-1); out = 2*in.  A workgroup owns BL_ROWS output rows of one plane: it stages the source rows they
+// read (about half as many) in LDS with coalesced loads, then every thread produces float4s of output -- four LDS reads and
+// three lerps per output.  (Round 5: the one-thread-per-float4 form with its operands in registers selected by compare chains
+// was 370 instructions per float4, branches included, and bound by instruction issue at 2.7 TB/s of stores; this form is a
+// quarter of that.)  Up to two maps per launch (RSGNet's multi-joint scores and its limb maps, the latter through a sigmoid):
+// the planes of map b follow those of map a in the grid.  Expressions and their association are ATen's upsample_bilinear2d.
+#ifndef BL_ROWS
+#define BL_ROWS 64
+#endif
+struct BilinearArgs {
+    const float* in[2];
+    float* out[2];
+    int planes[2], sigmoid[2];
+    int h, w, bands;
+};
+
+__global__ void __launch_bounds__(256) bilinear2x_kernel(const BilinearArgs a) {
+    extern __shared__ float bl_rows[];                   // [(BL_ROWS / 2 + 2) source rows][w]
+    const int h = a.h, w = a.w, ow = 2 * w, oh = 2 * h;
     const float ry = oh > 1 ? (float)(h - 1) / (float)(oh - 1) : 0.f;
     const float rx = ow > 1 ? (float)(w - 1) / (float)(ow - 1) : 0.f;
-    // 32-bit index arithmetic (total4 < 2^31 is checked on the host): two 64-bit divisions per thread made this
-    // kernel 3x slower than its 16-byte stores allow
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {
-        const unsigned ow4 = ow / 4;
-        const unsigned t = i / ow4;
-        const int x4 = (int)(i - t * ow4);
-        const unsigned pl = t / (unsigned)oh;
-        const int oy = (int)(t - pl * oh);
+    int pl = blockIdx.x / a.bands;
+    const int band = blockIdx.x - pl * a.bands;
+    const int m = pl >= a.planes[0] ? 1 : 0;             // which map (block-uniform)
+    pl -= m ? a.planes[0] : 0;
+    const float* in = (m ? a.in[1] : a.in[0]) + (size_t)pl * h * w;
+    float* out = (m ? a.out[1] : a.out[0]) + (size_t)pl * oh * ow;
+    const int sig = m ? a.sigmoid[1] : a.sigmoid[0];
+    const int oy0 = band * BL_ROWS, oy1 = min(oy0 + BL_ROWS, oh);
+    const int ys0 = (int)(ry * (float)oy0);              // first source row any output row of the band reads
+    int ys1 = (int)(ry * (float)(oy1 - 1)) + 1;          // last one
+    if (ys1 > h - 1) ys1 = h - 1;
+    const int nsrc = (ys1 - ys0 + 1) * w;
+    for (int i = threadIdx.x; i < nsrc; i += 256) bl_rows[i] = in[ys0 * w + i];
+    __syncthreads();
+    const int ow4 = ow >> 2, items = (oy1 - oy0) * ow4;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int r = it / ow4, x4 = it - r * ow4;
+        const int oy = oy0 + r;
         const float sy = ry * oy;
         int y0 = (int)sy;
         if (y0 > h - 1) y0 = h - 1;
         const int y1 = y0 < h - 1 ? y0 + 1 : y0;
         const float wy = sy - (float)y0;
-        const float* r0 = in + ((size_t)pl * h + y0) * w;
-        const float* r1 = in + ((size_t)pl * h + y1) * w;
-        // the 4 outputs read source columns a .. a+3 at most (rx < 1/2): 4 loads per row instead of 8
-        int a = (int)(rx * (float)(x4 * 4));
-        if (a > w - 1) a = w - 1;
-        float s0[4], s1[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = a + k < w ? a + k : w - 1;
-            s0[k] = r0[c];
-            s1[k] = r1[c];
-        }
+        const float* r0 = bl_rows + (y0 - ys0) * w;
+        const float* r1 = bl_rows + (y1 - ys0) * w;
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -194,33 +209,44 @@ __global__ void __launch_bounds__(256) bilinear2x_kernel(const float* __restrict
             if (xa > w - 1) xa = w - 1;
             const int xb = xa < w - 1 ? xa + 1 : xa;
             const float wx = sx - (float)xa;
-            const int da = xa - a, db = xb - a;           // 0..2 and 0..3
-            const float ta = da == 0 ? s0[0] : da == 1 ? s0[1] : s0[2];
-            const float tb = db == 0 ? s0[0] : db == 1 ? s0[1] : db == 2 ? s0[2] : s0[3];
-            const float ba = da == 0 ? s1[0] : da == 1 ? s1[1] : s1[2];
-            const float bb = db == 0 ? s1[0] : db == 1 ? s1[1] : db == 2 ? s1[2] : s1[3];
             // same association as ATen's upsample_bilinear2d: lerp in x on both rows, then in y
-            const float top = ta * (1.f - wx) + tb * wx;
-            const float bot = ba * (1.f - wx) + bb * wx;
+            const float top = r0[xa] * (1.f - wx) + r0[xb] * wx;
+            const float bot = r1[xa] * (1.f - wx) + r1[xb] * wx;
             float v = top * (1.f - wy) + bot * wy;
-            if (sigmoid) v = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+            if (sig) v = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
             o[k] = v;
         }
-        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(out + (size_t)oy * ow + x4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
+}
+
+static int bilinear_launch(const float* in_a, float* out_a, int planes_a, int sig_a, const float* in_b, float* out_b, int planes_b,
+                           int sig_b, int h, int w, void* stream, const char* what) {
+    if (!in_a || !out_a || planes_a < 1 || h < 1 || w < 2 || (w % 2) || planes_b < 0 || (planes_b && (!in_b || !out_b)))
+        RSG_FAIL("%s: bad arguments", what);
+    if ((((uintptr_t)out_a | (uintptr_t)out_b) & 15)) RSG_FAIL("%s: outputs must be 16-byte aligned", what);
+    BilinearArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in[0] = in_a; a.out[0] = out_a; a.planes[0] = planes_a; a.sigmoid[0] = sig_a ? 1 : 0;
+    a.in[1] = in_b; a.out[1] = out_b; a.planes[1] = planes_b; a.sigmoid[1] = sig_b ? 1 : 0;
+    a.h = h; a.w = w; a.bands = ceil_div(2 * h, BL_ROWS);
+    const long blocks = (long)(planes_a + planes_b) * a.bands;
+    const int lds = (BL_ROWS / 2 + 2) * w * (int)sizeof(float);
+    if (blocks >= (1L << 31) || lds > 64 * 1024) RSG_FAIL("%s: map too large (%ld workgroups, %d B of LDS)", what, blocks, lds);
+    RSG_LAUNCH(bilinear2x_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH(what);
+    return 0;
 }
 
 extern "C" int rsg_bilinear2x_nchw_f32(const float* in, float* out, int32_t planes, int32_t h, int32_t w,
                                        int32_t sigmoid, void* stream) {
-    if (!in || !out || planes < 1 || h < 1 || w < 2 || (w % 2)) RSG_FAIL("bilinear2x: bad arguments");
-    const long total4 = (long)planes * (2 * h) * (2 * w / 4);
-    if (total4 >= (1L << 31)) RSG_FAIL("bilinear2x: too many elements for 32-bit indexing");
-    long blocks = (total4 + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    RSG_LAUNCH(bilinear2x_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, in, out, h, w,
-                       total4, sigmoid);
-    RSG_CHECK_LAUNCH("bilinear2x");
-    return 0;
+    return bilinear_launch(in, out, planes, sigmoid, nullptr, nullptr, 0, 0, h, w, stream, "bilinear2x");
+}
+
+extern "C" int rsg_bilinear2x_pair_nchw_f32(const float* in_a, float* out_a, int32_t planes_a, int32_t sigmoid_a, const float* in_b,
+                                            float* out_b, int32_t planes_b, int32_t sigmoid_b, int32_t h, int32_t w, void* stream) {
+    if (planes_b < 1) RSG_FAIL("bilinear2x_pair: the second map has no planes");
+    return bilinear_launch(in_a, out_a, planes_a, sigmoid_a, in_b, out_b, planes_b, sigmoid_b, h, w, stream, "bilinear2x_pair");
 }
 
 // ---- backward of the above (training: pose_rsgnet.py:1009-1013 under autograd) -------------------------------------------

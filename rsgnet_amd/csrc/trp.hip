@@ -497,6 +497,29 @@ __device__ __forceinline__ float block_sum256(float v, float* red) {
 
 // IN = float: e is TRP's fp32 E [B,S,C].  IN = a 16-bit storage type: e is a 16-bit NHWC map with channel stride e_ld
 // (RELATION_SUB_SAMPLE: the output of the up-sampling deconv, association.py:254-268).
+// One position's row of E as fp32 (shared by the two passes of the tail)
+template <int C, class IN>
+__device__ __forceinline__ void trp_load_row(const void* e_, int e_ld, size_t pos, float (&xv)[C]) {
+    if constexpr (sizeof(IN) == 4) {
+        const float* e = reinterpret_cast<const float*>(e_) + pos * C;
+#pragma unroll
+        for (int k = 0; k < C / 4; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(e + 4 * k);
+            xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
+        }
+    } else {
+        const char* e = reinterpret_cast<const char*>(e_) + pos * e_ld * 2;
+#pragma unroll
+        for (int k = 0; k < C / 8; ++k) {
+            const typename IN::vec8 v = __builtin_bit_cast(typename IN::vec8, *reinterpret_cast<const uint4*>(e + 16 * k));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[8 * k + j] = (float)v[j];
+        }
+    }
+}
+
+// y == nullptr (inference, rsg_trp_tail_ex keep_y = 0): only the GroupNorm partials leave the kernel; the second pass
+// recomputes W e + b (1 024 - 2 304 multiply-adds per position) instead of reading 4 C bytes per position back
 template <int C, class IN>
 __global__ void __launch_bounds__(256) trp_w_project_kernel(const void* __restrict__ e_, int e_ld, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y,
@@ -506,22 +529,7 @@ __global__ void __launch_bounds__(256) trp_w_project_kernel(const void* __restri
     const int b = blockIdx.y, s = blockIdx.x * 256 + threadIdx.x;
     const size_t row = ((size_t)b * S + s) * C;
     float xv[C], yv[C];
-    if constexpr (sizeof(IN) == 4) {
-        const float* e = reinterpret_cast<const float*>(e_);
-#pragma unroll
-        for (int k = 0; k < C / 4; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(e + row + 4 * k);
-            xv[4 * k] = v.x; xv[4 * k + 1] = v.y; xv[4 * k + 2] = v.z; xv[4 * k + 3] = v.w;
-        }
-    } else {
-        const char* e = reinterpret_cast<const char*>(e_) + ((size_t)b * S + s) * e_ld * 2;
-#pragma unroll
-        for (int k = 0; k < C / 8; ++k) {
-            const typename IN::vec8 v = __builtin_bit_cast(typename IN::vec8, *reinterpret_cast<const uint4*>(e + 16 * k));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[8 * k + j] = (float)v[j];
-        }
-    }
+    trp_load_row<C, IN>(e_, e_ld, (size_t)b * S + s, xv);
 #pragma unroll
     for (int co = 0; co < C; ++co) {
         // W and its bias are read through the scalar cache into SGPRs (uniform addresses).  They used to be staged in LDS and
@@ -532,9 +540,11 @@ __global__ void __launch_bounds__(256) trp_w_project_kernel(const void* __restri
         for (int ci = 0; ci < C; ++ci) acc = fmaf(w[co * C + ci], xv[ci], acc);
         yv[co] = acc;
     }
+    if (y) {
 #pragma unroll
-    for (int k = 0; k < C / 4; ++k)
-        *reinterpret_cast<float4*>(y + row + 4 * k) = make_float4(yv[4 * k], yv[4 * k + 1], yv[4 * k + 2], yv[4 * k + 3]);
+        for (int k = 0; k < C / 4; ++k)
+            *reinterpret_cast<float4*>(y + row + 4 * k) = make_float4(yv[4 * k], yv[4 * k + 1], yv[4 * k + 2], yv[4 * k + 3]);
+    }
     float* po = part + (((size_t)b * gridDim.x + blockIdx.x) * G) * 2;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -550,11 +560,14 @@ __global__ void __launch_bounds__(256) trp_w_project_kernel(const void* __restri
     }
 }
 
-template <class DT, int C>
+// IN = void: y is read from the workspace (training keeps it for the backward).  Otherwise (inference): y is recomputed from
+// E (IN = float or the 16-bit storage type, as in trp_w_project_kernel) with the project kernel's own expression.
+template <class DT, int C, class IN = void>
 __global__ void __launch_bounds__(256) trp_gn_apply_kernel(const float* __restrict__ y, const float* __restrict__ part,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, char* __restrict__ out,
-                                                          int out_ld, int S) {
+                                                          int out_ld, int S, const void* __restrict__ e_ = nullptr, int e_ld = 0,
+                                                          const float* __restrict__ w = nullptr, const float* __restrict__ bias = nullptr) {
     constexpr int G = 8, CG = C / G;
     // every thread merges the crop's partials itself (uniform addresses: scalar loads, the same operations in the same order
     // in every thread); no LDS (see trp_w_project_kernel)
@@ -581,13 +594,27 @@ __global__ void __launch_bounds__(256) trp_gn_apply_kernel(const float* __restri
         }
     }
     const int s = blockIdx.x * 256 + threadIdx.x;
-    const float* yr = y + ((size_t)b * S + s) * C;
     typename DT::elem* orow = reinterpret_cast<typename DT::elem*>(out) + ((size_t)b * S + s) * out_ld;
+    float xv[std::is_void<IN>::value ? 1 : C];
+    if constexpr (!std::is_void<IN>::value) trp_load_row<C, IN>(e_, e_ld, (size_t)b * S + s, xv);
 #pragma unroll
     for (int k = 0; k < C / 8; ++k) {
-        const float4 v0 = *reinterpret_cast<const float4*>(yr + 8 * k);
-        const float4 v1 = *reinterpret_cast<const float4*>(yr + 8 * k + 4);
-        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float vv[8];
+        if constexpr (std::is_void<IN>::value) {
+            const float* yr = y + ((size_t)b * S + s) * C;
+            const float4 v0 = *reinterpret_cast<const float4*>(yr + 8 * k);
+            const float4 v1 = *reinterpret_cast<const float4*>(yr + 8 * k + 4);
+            vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int co = 8 * k + j;
+                float acc = bias[co];                    // trp_w_project_kernel's expression: the same bits
+#pragma unroll
+                for (int ci = 0; ci < C; ++ci) acc = fmaf(w[co * C + ci], xv[ci], acc);
+                vv[j] = acc;
+            }
+        }
         typename DT::vec8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (typename DT::elem)(vv[j] * scale[8 * k + j] + shift[8 * k + j]);
@@ -601,7 +628,7 @@ extern "C" size_t rsg_trp_tail_workspace_bytes(int32_t batch, int32_t S, int32_t
 
 static int trp_tail_impl(const void* e, int e16_ld, const float* w, const float* bias, const float* gn_gamma,
                          const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S,
-                         int32_t C, int32_t dtype, void* workspace, void* stream) {
+                         int32_t C, int32_t dtype, void* workspace, void* stream, bool keep_y = true) {
     if (!e || !w || !bias || !gn_gamma || !gn_beta || !out || !workspace) RSG_FAIL("trp_tail: null pointer");
     if (C != 32 && C != 48) RSG_FAIL("trp_tail: C=%d (32 and 48 are built)", C);
     if (S % 256) RSG_FAIL("trp_tail: S=%d must be a multiple of 256", S);
@@ -610,19 +637,41 @@ static int trp_tail_impl(const void* e, int e16_ld, const float* w, const float*
     float* y = (float*)workspace;
     float* part = y + (size_t)batch * S * C;
     dim3 grid(S / 256, batch);
-#define RSG_WP(C_, IN_) RSG_LAUNCH((trp_w_project_kernel<C_, IN_>), grid, dim3(256), 0, (hipStream_t)stream, e, e16_ld, w, bias, y, part, S)
+    float* const yw = keep_y ? y : nullptr;
+#define RSG_WP(C_, IN_) RSG_LAUNCH((trp_w_project_kernel<C_, IN_>), grid, dim3(256), 0, (hipStream_t)stream, e, e16_ld, w, bias, yw, part, S)
     if (!e16_ld) { if (C == 32) RSG_WP(32, float); else RSG_WP(48, float); }
     else if (dtype == RSG_BF16) { if (C == 32) RSG_WP(32, BF16); else RSG_WP(48, BF16); }
     else { if (C == 32) RSG_WP(32, F16); else RSG_WP(48, F16); }
 #undef RSG_WP
     RSG_CHECK_LAUNCH("trp_tail(project)");
 #define RSG_GN(DT_, C_) RSG_LAUNCH((trp_gn_apply_kernel<DT_, C_>), grid, dim3(256), 0, (hipStream_t)stream, \
-                                   (const float*)y, (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S)
-    if (dtype == RSG_BF16) { if (C == 32) RSG_GN(BF16, 32); else RSG_GN(BF16, 48); }
-    else { if (C == 32) RSG_GN(F16, 32); else RSG_GN(F16, 48); }
+                                   (const float*)y, (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S, (const void*)nullptr, 0, \
+                                   (const float*)nullptr, (const float*)nullptr)
+#define RSG_GNR(DT_, C_, IN_) RSG_LAUNCH((trp_gn_apply_kernel<DT_, C_, IN_>), grid, dim3(256), 0, (hipStream_t)stream, \
+                                        (const float*)nullptr, (const float*)part, gn_gamma, gn_beta, (char*)out, out_ld, S, e, e16_ld, w, bias)
+    if (keep_y) {
+        if (dtype == RSG_BF16) { if (C == 32) RSG_GN(BF16, 32); else RSG_GN(BF16, 48); }
+        else { if (C == 32) RSG_GN(F16, 32); else RSG_GN(F16, 48); }
+    } else if (!e16_ld) {
+        if (dtype == RSG_BF16) { if (C == 32) RSG_GNR(BF16, 32, float); else RSG_GNR(BF16, 48, float); }
+        else { if (C == 32) RSG_GNR(F16, 32, float); else RSG_GNR(F16, 48, float); }
+    } else {
+        if (dtype == RSG_BF16) { if (C == 32) RSG_GNR(BF16, 32, BF16); else RSG_GNR(BF16, 48, BF16); }
+        else { if (C == 32) RSG_GNR(F16, 32, F16); else RSG_GNR(F16, 48, F16); }
+    }
+#undef RSG_GNR
 #undef RSG_GN
     RSG_CHECK_LAUNCH("trp_tail(groupnorm)");
     return 0;
+}
+
+// keep_y = 0 (inference): the fp32 projection is not written to the workspace (nothing reads it: rsg_trp_tail_backward is
+// training's); the GroupNorm pass recomputes it.  e16_ld = 0: e is fp32 [batch,S,C]; else the 16-bit map of rsg_trp_tail_in16.
+extern "C" int rsg_trp_tail_ex(const void* e, int32_t e16_ld, const float* w, const float* bias, const float* gn_gamma,
+                               const float* gn_beta, void* out, int32_t out_ld, int32_t batch, int32_t S, int32_t C,
+                               int32_t dtype, int32_t keep_y, void* workspace, void* stream) {
+    if (e16_ld && e16_ld < 8) RSG_FAIL("trp_tail_ex: e_ld=%d", e16_ld);
+    return trp_tail_impl(e, e16_ld, w, bias, gn_gamma, gn_beta, out, out_ld, batch, S, C, dtype, workspace, stream, keep_y != 0);
 }
 
 extern "C" int rsg_trp_tail(const float* e, const float* w, const float* bias, const float* gn_gamma,

@@ -151,10 +151,12 @@ SYMBOLS = {
     "rsg_flip_merge_nchw_f32": (C.c_int, [_vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_decode_heatmaps": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "rsg_bilinear2x_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "rsg_bilinear2x_pair_nchw_f32": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_attention": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_project_g": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rsg_trp_tail_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "rsg_trp_tail": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rsg_trp_tail_ex": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rsg_trp_scores": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "rsg_loss_workspace_bytes": (C.c_size_t, [_i]),
     "rsg_joints_mse_loss": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, C.c_float, _vp, _i, _vp, _vp, _vp]),

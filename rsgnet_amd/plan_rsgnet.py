@@ -183,16 +183,16 @@ def record_rsgnet(p: Plan, model) -> None:
 
         def make_tail():
             a = (up.ptr(), up.ld, ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
-                 rel.ld, B, S, c0, dt, p.tail_ws.data_ptr())
-            return lambda s: hip.check(lib.rsg_trp_tail_in16(*a, s), "trp_tail_in16")
+                 rel.ld, B, S, c0, dt, 0, p.tail_ws.data_ptr())           # keep_y = 0: nothing reads the fp32 projection in inference
+            return lambda s: hip.check(lib.rsg_trp_tail_ex(*a, s), "trp_tail_in16")
 
         p.custom("trp_tail", [up], [rel], make_tail)
         p.flops += B * 2 * S * c0 * c0
     else:
         def make_tail():
-            a = (p.e32.data_ptr(), ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
-                 rel.ld, B, S, c0, dt, p.tail_ws.data_ptr())
-            return lambda s: hip.check(lib.rsg_trp_tail(*a, s), "trp_tail")
+            a = (p.e32.data_ptr(), 0, ww.data_ptr(), bw.data_ptr(), gam.data_ptr(), bet.data_ptr(), rel.ptr(),
+                 rel.ld, B, S, c0, dt, 0, p.tail_ws.data_ptr())           # keep_y = 0
+            return lambda s: hip.check(lib.rsg_trp_tail_ex(*a, s), "trp_tail")
 
         p.custom("trp_tail", [p.e32], [rel], make_tail)
 
@@ -222,21 +222,21 @@ def record_rsgnet(p: Plan, model) -> None:
     from .plan import OutSlot
     p.kpt_slot, p.multi_slot, p.limbs_slot = OutSlot(p.kpt), OutSlot(p.multi_up), OutSlot(p.limbs)
 
-    def make_up(src, slot, planes, sig):
-        a = (src.data_ptr(), planes, H4, W4, sig)
-        return lambda: (lambda s: hip.check(lib.rsg_bilinear2x_nchw_f32(a[0], slot.ptr, *a[1:], s), "bilinear2x"))
+    def make_up():              # both x2 up-samplings (:1009-1013) in one launch: the multi-joint scores, then the limb maps through the sigmoid
+        ma, la = p.multi_lo.data_ptr(), p.limbs_lo.data_ptr()
+        return lambda s: hip.check(lib.rsg_bilinear2x_pair_nchw_f32(ma, p.multi_slot.ptr, B * J, 0, la, p.limbs_slot.ptr, B * L, 1,
+                                                                    H4, W4, s), "bilinear2x_pair")
 
     if not ride:
         with p.on_lane(1):      # independent of TRP and the joints-of-target branch: its own stream
             lf = p._unit(fvis, model.limbs_net[0], model.limbs_net[1], relu=True, name="limbs_net")
             p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
-    # the three ops that write the model's outputs come last: they run eagerly behind the captured graph and write
+    # the two ops that write the model's outputs come last: they run eagerly behind the captured graph and write
     # straight into the tensors a forward hands out (Plan.n_tail, OutSlot)
     fl = model.final_layer
     p.conv(k3, fl.weight, None, fl.bias, out_f32=p.kpt_slot, want16=False, name="final_layer")
-    p.custom("bilinear2x+sigmoid(limbs)", [p.limbs_lo], [p.limbs], make_up(p.limbs_lo, p.limbs_slot, B * L, 1))
-    p.custom("bilinear2x(multi)", [p.multi_lo], [p.multi_up], make_up(p.multi_lo, p.multi_slot, B * J, 0))
-    p.n_tail = 3
+    p.custom("bilinear2x(multi)+bilinear2x+sigmoid(limbs)", [p.multi_lo, p.limbs_lo], [p.multi_up, p.limbs], make_up)
+    p.n_tail = 2
 
     # the constant location clue: filled once, right after allocation, for every crop slot
     orig_finalize = p.finalize

@@ -1308,3 +1308,55 @@ def test_persistent_stem_equals_the_per_tile_stem(shape):
         assert torch.equal(res[0, direct][0], res[1, direct][0]) and torch.equal(res[0, direct][1], res[1, direct][1]), direct
     assert torch.equal(res[1, 0][0], res[1, 1][0])                       # both input paths round the picture alike
     assert float(res[1, 1][0].float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("hw", [(64, 48), (96, 72), (7, 10)])
+def test_bilinear2x_pair_equals_two_launches(hw):
+    """rsg_bilinear2x_pair_nchw_f32 (RSGNet's two x2 up-samplings, pose_rsgnet.py:1009-1013, as one launch: the second map
+    through the sigmoid) gives bit for bit what two rsg_bilinear2x_nchw_f32 launches give; row bands that end inside the map
+    (2h not a multiple of 16) included."""
+    lib = hip.lib()
+    h, w = hw
+    g = torch.Generator().manual_seed(h * w)
+    a, b = torch.randn(3, 17, h, w, generator=g).to(DEV), torch.randn(3, 18, h, w, generator=g).to(DEV)
+    oa, ob = torch.empty(3, 17, 2 * h, 2 * w, device=DEV), torch.empty(3, 18, 2 * h, 2 * w, device=DEV)
+    pa, pb = torch.full_like(oa, float("nan")), torch.full_like(ob, float("nan"))
+    hip.check(lib.rsg_bilinear2x_nchw_f32(a.data_ptr(), oa.data_ptr(), 51, h, w, 0, _stream()))
+    hip.check(lib.rsg_bilinear2x_nchw_f32(b.data_ptr(), ob.data_ptr(), 54, h, w, 1, _stream()))
+    hip.check(lib.rsg_bilinear2x_pair_nchw_f32(a.data_ptr(), pa.data_ptr(), 51, 0, b.data_ptr(), pb.data_ptr(), 54, 1, h, w, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(pa, oa) and torch.equal(pb, ob)
+    want = torch.sigmoid(F.interpolate(b.cpu(), scale_factor=2, mode="bilinear", align_corners=True))
+    assert float((pb.cpu() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(32, 0, 0), (48, 0, 0), (32, 64, 0), (48, 64, 1)])
+def test_trp_tail_without_the_projection_round_trip_equals_the_tail(cfg):
+    """rsg_trp_tail_ex with keep_y = 0 (inference: the fp32 projection W e + b is recomputed by the GroupNorm pass instead of
+    written to the workspace and read back) gives bit for bit the output of rsg_trp_tail / rsg_trp_tail_in16 (keep_y = 1),
+    for fp32 rows and for the 16-bit map of the sub-sampled variant, C = 32 and 48."""
+    lib = hip.lib()
+    Cc, e_ld, dt = cfg
+    B, S = 3, 768
+    g = torch.Generator().manual_seed(Cc + e_ld)
+    t16 = torch.bfloat16 if dt else torch.float16
+    if e_ld:
+        e = (torch.randn(B, S, e_ld, generator=g) * 2).to(t16).to(DEV)
+    else:
+        e = (torch.randn(B, S, Cc, generator=g) * 30 + 100).to(DEV)      # E is ~S times larger than its variation (trp.hip header)
+    w = (torch.randn(Cc, Cc, generator=g) * 0.2).to(DEV)
+    bias, gam, bet = ((torch.randn(Cc, generator=g) * 0.3 + k).to(DEV) for k in (0.0, 1.0, 0.0))
+    ws = torch.empty(lib.rsg_trp_tail_workspace_bytes(B, S, Cc), dtype=torch.uint8, device=DEV)
+    outs = []
+    for keep in (1, 0):
+        ws.fill_(0xFF)                                                    # NaN patterns: a pass that read y without writing it would show
+        out = torch.full((B, S, 64), float("nan"), dtype=t16, device=DEV)
+        hip.check(lib.rsg_trp_tail_ex(e.data_ptr(), e_ld, w.data_ptr(), bias.data_ptr(), gam.data_ptr(), bet.data_ptr(), out.data_ptr(),
+                                      64, B, S, Cc, dt, keep, ws.data_ptr(), _stream()), "trp_tail_ex")
+        torch.cuda.synchronize()
+        outs.append(out[..., :Cc].clone())
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+    x = (e[..., :Cc] if e_ld else e).float().cpu()
+    y = x @ w.cpu().t() + bias.cpu()
+    want = F.group_norm(y.permute(0, 2, 1), 8, gam.cpu(), bet.cpu(), 1e-5).permute(0, 2, 1)
+    assert float((outs[1].float().cpu() - want).abs().max()) < (0.06 if dt else 0.01)
