@@ -28,6 +28,18 @@ __device__ __forceinline__ float sigmoid_f32(float a) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(a * -1.4426950408889634f));
 }
 
+// Which 16-byte piece of a K / G^T tile thread p stages.  Rows of four pieces (C = 32; every G^T tile) are padded to five slots
+// for the ds_read_b128s of the MFMA operands (5 n mod 16 is a permutation on every 16-lane read group); a ds_write_b128 is
+// served in groups of eight lanes whose slots must differ mod 8, and with p -> (row p / 4, piece p % 4) a group spans two rows
+// whose slots 5 r and 5 r + 8 collide (a quarter of the LDS cycles of the attention kernel in bank conflicts,
+// profiles/r04g_sq_summary_rsgnet_crowdpose_fliptest.json).  Eight consecutive lanes take the SAME piece of eight consecutive
+// rows instead: slots 5 r + piece, r = r0 .. r0 + 7 -- 5 r mod 8 is a permutation.  The global side is unchanged in what it
+// touches (a wave-instruction still reads 16 whole rows).  Six-piece rows (C = 48) keep the plain order.
+template <int PK>
+__device__ __forceinline__ int trp_row(int p) { return PK == 4 ? ((p & 7) | ((p >> 5) << 3)) : p / PK; }
+template <int PK>
+__device__ __forceinline__ int trp_piece(int p) { return PK == 4 ? ((p >> 3) & 3) : p % PK; }
+
 struct TrpArgs {
     const char* x;       // [B,S,ldx] 16-bit
     const char* gT;      // [B,C,S] 16-bit, key-permuted
@@ -93,10 +105,10 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
                 const int p = threadIdx.x + k * 256;
                 v[u][k] = make_uint4(0, 0, 0, 0);
                 if (p < NKP) {
-                    const int row = p / PK, piece = p % PK;
+                    const int row = trp_row<PK>(p), piece = trp_piece<PK>(p);
                     v[u][k] = *reinterpret_cast<const uint4*>(xb + ((size_t)(j0 + row) * a.ldx + piece * 8) * 2);
                 } else if (p < NPIECE) {
-                    const int q = p - NKP, row = q >> 2, piece = q & 3;
+                    const int q = p - NKP, row = trp_row<4>(q), piece = trp_piece<4>(q);
                     v[u][k] = *reinterpret_cast<const uint4*>(a.gT + (((size_t)b * C + row) * a.S + j0 + piece * 8) * 2);
                 }
             }
@@ -108,8 +120,8 @@ __global__ void __launch_bounds__(256) trp_kernel(const TrpArgs a) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int p = threadIdx.x + k * 256;
-                if (p < NKP) tk[buf][u][(p / PK) * RSK + p % PK] = v[u][k];
-                else if (p < NPIECE) tg[buf][u][((p - NKP) >> 2) * 5 + ((p - NKP) & 3)] = v[u][k];
+                if (p < NKP) tk[buf][u][trp_row<PK>(p) * RSK + trp_piece<PK>(p)] = v[u][k];
+                else if (p < NPIECE) tg[buf][u][trp_row<4>(p - NKP) * 5 + trp_piece<4>(p - NKP)] = v[u][k];
             }
     };
     auto do_tile = [&](int j0, const uint4* tkb, const uint4* tgb) {
