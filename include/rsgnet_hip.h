@@ -124,6 +124,13 @@ int32_t rsg_conv_pair_next_perm(int32_t l);
 int rsg_conv_pair_next(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias, const void* residual,
                        int32_t res_ld, void* out16, int32_t out_ld, const void* next_w_packed, const float* next_bias,
                        void* next_out16, int32_t next_out_ld, const void* cat_x, int32_t cat_ld, void* stream);
+/* A 3x3 stride-1 conv 32 -> 32 (+BN folded, +ReLU) and the 1x1 conv (+bias) that follows it, fp32 NCHW result, in ONE launch --
+ * RSGNet's predict_net -> final_layer (/root/reference/lib/models/pose_rsgnet.py:999-1000): the first conv's accumulators,
+ * rounded to 16 bits, are the second's MFMA operand in registers; the 32-channel map between them is never stored.
+ * tail_w_packed: the 1x1's weight packed by rsg_pack_conv_weights_host exactly as for rsg_conv_igemm; tail_bias: 32 floats; tail_cout <= 32; out_nchw_f32: [batch, tail_cout, phys_h, phys_w].
+ * Bit-identical to the two rsg_conv_igemm launches. */
+int rsg_conv_tail1x1(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias, int32_t tail_cout,
+                     float* out_nchw_f32, void* stream);
 /* A whole Bottleneck without downsample branch (pose_hrnet.py:85-101: conv1 1x1 256->64, conv2 3x3, conv3 1x1
  * 64->256, each + BatchNorm, + x, ReLU) in ONE launch: conv1 is evaluated per tile (with its one-pixel halo) straight
  * into LDS, so neither 64-channel map ever reaches HBM.  x: 256-channel NHWC map (pixel stride x_ld elements), also

@@ -20,7 +20,7 @@ static __device__ unsigned long long* g_conv_stamps = nullptr;      // [blocks][
 #endif
 
 template <class DT, int CINB, int TAPH, int TAPW, int WM, int WN, int NT, bool TAIL = false, int HEAD = 0, bool NEXT = false, bool KCAT = false,
-          class ARGS = ConvArgs>
+          class ARGS = ConvArgs, bool RTAIL = false>
 __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, const int block_y, char* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int KPT = CINB / 16;       // k-steps per filter tap
@@ -463,6 +463,62 @@ __device__ __forceinline__ void conv_body(const ARGS& p, const int block_x, cons
                         *reinterpret_cast<uint4*>(dst + k * 16) = __builtin_bit_cast(uint4, __builtin_convertvector(f, typename DT::vec8));
                     }
                 }
+            }
+        }
+        RSG_CSTAMP(4);
+        return;
+    }
+    if constexpr (RTAIL) {
+        // ---- register tail (rsg_conv_tail1x1): this conv has 32 output channels (WM == 1, one tile: a lane pair holds ALL
+        // channels of its pixel), and a 1x1 conv over exactly those channels follows (RSGNet: predict_net -> final_layer,
+        // pose_rsgnet.py:999-1000).  The ReLU'd accumulators, rounded to 16 bits as the map the two-launch form stores, ARE the
+        // B operand of the 1x1's two k-steps (after one half-wave swap of a chunk, below): no LDS, no barrier, and the 32-channel map at the output's resolution (50 MB per 64 crops
+        // at 128x96) is neither written nor read back.  p.out32 / p.C2 / p.bias2 / p.wpk2 describe the 1x1 (fp32 NCHW output).
+        static_assert(WM == 1 && !TAIL && !HEAD, "one 32-channel output tile per workgroup");
+        const bool relu1 = p.relu & 1;
+        uint4 a2[2];
+        a2[0] = p.wpk2[lane];
+        a2[1] = p.wpk2[64 + lane];
+        float b2[16];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 bv = *reinterpret_cast<const float4*>(p.bias2 + hh * 16 + r4 * 4);
+            b2[r4 * 4 + 0] = bv.x; b2[r4 * 4 + 1] = bv.y; b2[r4 * 4 + 2] = bv.z; b2[r4 * 4 + 3] = bv.w;
+        }
+        const int plane = p.Hp * p.Wp;
+#pragma unroll
+        for (int g = 0; g < NT; ++g) {
+            typename DT::vec8 o[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = relu1 ? fmaxf(acc[g][k * 8 + e], 0.f) : acc[g][k * 8 + e];
+                o[k] = __builtin_convertvector(f, typename DT::vec8);       // the generic epilogue's rounding
+            }
+            // lane (n, hh) holds channels 16 hh .. 16 hh + 15 of its pixel; k-step s of the 1x1 wants channels 16 s + 8 hh .. + 7
+            // from it: the second chunk of the lower half-wave and the first chunk of the upper one trade places
+            // (v_permlane32_swap: lanes 32-63 of the first chunk's registers <-> lanes 0-31 of the second's), then chunk 0 / chunk 1 are the two
+            // k-steps' fragments in the 1x1 conv's OWN channel order (plain weight pack, the two launches' summation order)
+            u32x4 c0 = __builtin_bit_cast(u32x4, o[0]), c1 = __builtin_bit_cast(u32x4, o[1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // (the builtin trades the UPPER 32 lanes of its first operand with the LOWER 32 of its second)
+                const auto sw2 = __builtin_amdgcn_permlane32_swap(c0[e], c1[e], false, false);
+                c0[e] = sw2[0];
+                c1[e] = sw2[1];
+            }
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = b2[r];
+            t = DT::mfma(__builtin_bit_cast(typename DT::vec8, a2[0]), __builtin_bit_cast(typename DT::vec8, c0), t);
+            t = DT::mfma(__builtin_bit_cast(typename DT::vec8, a2[1]), __builtin_bit_cast(typename DT::vec8, c1), t);
+            if (opix[g] < 0) continue;
+            const int rem = opix[g] - b * plane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = hh * 16 + r;
+                if (c < p.C2) p.out32[((size_t)b * p.C2 + c) * plane + rem] = t[r];
             }
         }
         RSG_CSTAMP(4);

@@ -419,6 +419,48 @@ extern "C" int rsg_conv_pair_next(const rsg_conv_desc* inner, const void* tail_w
                        stream, next_w_packed, next_bias, next_out16, next_out_ld, cat_x, cat_ld);
 }
 
+// A 3x3 (or 1x1 / 2x2) conv with 32 input-block channels and exactly 32 output channels (+BN folded, +ReLU) followed by a 1x1
+// conv over those 32 channels (+bias) whose result leaves as fp32 NCHW -- RSGNet's predict_net -> final_layer
+// (/root/reference/lib/models/pose_rsgnet.py:999-1000) -- in ONE launch: conv_body's register tail.  `inner` describes the first
+// conv (its out16 / out_nchw_f32 are ignored: the 32-channel map is not stored); tail_w_packed: the 1x1's weight [tail_cout, 32]
+// packed by rsg_pack_conv_weights_host as for rsg_conv_igemm; tail_bias: round_up(tail_cout, 32) floats; out_nchw_f32: [batch, tail_cout, phys_h, phys_w].  Bit-identical to rsg_conv_igemm (16-bit output) + rsg_conv_igemm
+// (1x1, fp32 NCHW output).
+template <class DT>
+__global__ void __launch_bounds__(256) conv_rtail_kernel(const ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_body<DT, 32, 3, 3, 1, 4, 3, false, 0, false, false, ConvArgs, true>(p, rsg_xcd_tile(blockIdx.x, gridDim.x), 0, smem);
+}
+
+extern "C" int rsg_conv_tail1x1(const rsg_conv_desc* inner, const void* tail_w_packed, const float* tail_bias, int32_t tail_cout,
+                                float* out_nchw_f32, void* stream) {
+    if (!inner || !tail_w_packed || !tail_bias || !out_nchw_f32) RSG_FAIL("conv_tail1x1: null pointer");
+    if (inner->kh != 3 || inner->kw != 3 || inner->stride != 1 || inner->in_c != 32 || inner->out_c != 32 || inner->residual ||
+        inner->up != 1 || inner->relu_tile_mask)
+        RSG_FAIL("conv_tail1x1: the first conv must be 3x3 stride 1, 32 -> 32 channels, no residual (got %dx%d s%d %d -> %d)",
+                 inner->kh, inner->kw, inner->stride, inner->in_c, inner->out_c);
+    if (tail_cout < 1 || tail_cout > 32) RSG_FAIL("conv_tail1x1: %d output channels (1..32: one MFMA tile)", tail_cout);
+    if ((((uintptr_t)tail_w_packed | (uintptr_t)tail_bias) & 15) || ((uintptr_t)out_nchw_f32 & 3)) RSG_FAIL("conv_tail1x1: alignment");
+    rsg_conv_desc d = *inner;
+    d.out16 = nullptr; d.out_nchw_f32 = out_nchw_f32;      // (validated as the conv's own fp32 output; the kernel writes the tail's)
+    d.out_c_store = 0; d.tile_hint = 0;
+    ConvArgs a;
+    TilePlan t;
+    dim3 grid;
+    if (rsg_conv_prepare(&d, a, t, grid)) return 1;
+    if (t.CINB != 32 || t.WM != 1 || t.NT != 3 || grid.y != 1) {
+        // the chooser spread a small grid over finer tiles: force the (1 x 4 waves, 3 pixel groups) form this kernel is built for
+        d.tile_hint = 1 | (3 << 4) | (std::min(inner->out_h, 8) << 8) | (std::min(inner->out_w, 48) << 16);
+        if (rsg_conv_prepare(&d, a, t, grid)) return 1;
+        if (t.CINB != 32 || t.WM != 1 || t.NT != 3 || grid.y != 1) RSG_FAIL("conv_tail1x1: no (1, 4, 3) tiling for a %dx%d map", inner->out_h, inner->out_w);
+    }
+    a.out = nullptr;
+    a.wpk2 = (const uint4*)tail_w_packed; a.bias2 = tail_bias; a.C2 = tail_cout;
+    if (inner->dtype == RSG_BF16) RSG_LAUNCH(conv_rtail_kernel<BF16>, grid, dim3(256), t.lds, (hipStream_t)stream, a);
+    else RSG_LAUNCH(conv_rtail_kernel<F16>, grid, dim3(256), t.lds, (hipStream_t)stream, a);
+    RSG_CHECK_LAUNCH("conv_tail1x1");
+    return 0;
+}
+
 // logical input channel l of the head's packed weights <-> channel of x (see conv_body HEAD)
 extern "C" int32_t rsg_bottleneck_head_perm(int32_t l) { return 128 * ((l >> 3) & 1) + 8 * (l >> 4) + (l & 7); }
 

@@ -102,6 +102,7 @@ SYMBOLS = {
     "rsg_conv_dual": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _i, _i, _vp]),
     "rsg_conv_pair": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     "rsg_conv_pair_next_perm": (C.c_int32, [_i]),
+    "rsg_conv_tail1x1": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _vp]),
     "rsg_conv_pair_next": (C.c_int, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "rsg_bottleneck_head_perm": (C.c_int32, [_i]),
     "rsg_bottleneck_fused": (C.c_int, [C.POINTER(ConvDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -310,6 +310,25 @@ class Plan:
         self.flops += 2 * self.batch * out_hw[0] * out_hw[1] * O * I * kh * kw
         return out
 
+    def conv_tail1x1(self, x: VT, conv: nn.Conv2d, bn, tail_weight: torch.Tensor, tail_bias, out_f32, name="") -> None:
+        """Record a 3x3 stride-1 conv 32 -> 32 (+BN, +ReLU) and the 1x1 conv (+bias, fp32 NCHW output) that follows it as ONE
+        launch (rsg_conv_tail1x1: the first conv's accumulators are the second's MFMA operand; the 32-channel map between them
+        is never stored).  out_f32: the output tensor or its OutSlot."""
+        scale, shift = self.bn_fold(bn)
+        wp, bo, I, O = self.pack_conv(conv.weight, scale, shift, conv.bias)
+        J = int(tail_weight.shape[0])
+        if (I, O) != (32, 32) or x.C != 32 or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or J > 32 or \
+                tuple(tail_weight.shape[1:]) != (32, 1, 1):
+            raise ValueError(f"{name}: conv_tail1x1 takes a 3x3 stride-1 conv 32 -> 32 followed by a 1x1 conv 32 -> <= 32")
+        wp2, bo2 = self.pack_conv(tail_weight, None, None, tail_bias)[:2]
+        out_slot = None
+        if isinstance(out_f32, OutSlot):
+            out_slot, out_f32 = out_f32, out_f32.static
+        self._record(dict(kind="conv_tail", x=x, wp=wp, bias=bo, res=None, out=None, out_f32=out_f32, out_slot=out_slot, I=32, O=32,
+                          kh=3, kw=3, stride=1, pad=(1, 1), up=(1, 0, 0), out_hw=(x.H, x.W), phys_hw=(x.H, x.W), relu=True,
+                          wp2=wp2, bias2=bo2, J=J, name=name), [x], [out_f32])
+        self.flops += 2 * self.batch * x.H * x.W * (32 * 32 * 9 + J * 32)
+
     def conv_pair(self, x: VT, conv_a, bn_a, conv_b, bn_b, residual: Optional[VT], name="", next_unit=None,
                   tail=None, cat_x: Optional[VT] = None, planes: bool = False):
         """Record Bottleneck conv2 (3x3, 64 outputs, BN, ReLU) + conv3 (1x1, BN, + residual, ReLU) as ONE launch
@@ -576,6 +595,21 @@ class Plan:
                 hip.check(rc, nm)
 
         self.ops.append((r["name"], launch))
+
+    def _lower_conv_tail(self, r):
+        d = self._conv_desc(r)
+        self._keep.append(d)
+        nm, slot, J = r["name"], r.get("out_slot"), r["J"]
+        self.conv_log.append(dict(name=nm, flops=float(2 * self.batch * r["out_hw"][0] * r["out_hw"][1] * (32 * 32 * 9 + J * 32))))
+        ref, w2, b2, static = C.byref(d), r["wp2"].data_ptr(), r["bias2"].data_ptr(), r["out_f32"].data_ptr()
+        fn = self.lib.rsg_conv_tail1x1
+
+        def launch(stream):
+            rc = fn(ref, w2, b2, J, slot.ptr if slot is not None else static, stream)
+            if rc:
+                hip.check(rc, nm)
+
+        self.ops.append((nm, launch))
 
     def _lower_conv_pair(self, r):
         rr = dict(r)

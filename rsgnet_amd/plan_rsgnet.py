@@ -213,7 +213,11 @@ def record_rsgnet(p: Plan, model) -> None:
     if ride:
         p.conv(lf, limb_classifier(model), None, None, out_f32=p.limbs_lo, want16=False, name="limbs(sgm)")
     p.end_group("deconv+limbs(sgm)" if ride else "deconv")
-    k3 = p._unit(k2, model.predict_net[0], model.predict_net[1], relu=True, name="predict_net")
+    # predict_net -> final_layer (:999-1000) as ONE launch when the head is 32 channels wide: the 3x3 conv's accumulators feed the
+    # classifier's MFMAs in registers (rsg_conv_tail1x1); the 50 MB map between them (64 crops at 128x96) is never stored
+    head_tail = sw.plan_on("head_tail") and c0 == 32 and J <= 32 and model.predict_net[0].kernel_size == (3, 3) and \
+        model.final_layer.kernel_size == (1, 1)
+    k3 = None if head_tail else p._unit(k2, model.predict_net[0], model.predict_net[1], relu=True, name="predict_net")
 
     # ---- limbs branch = SGM (:1003-1013)
     p.kpt = torch.zeros(B, J, 2 * H4, 2 * W4, **f32)
@@ -234,7 +238,10 @@ def record_rsgnet(p: Plan, model) -> None:
     # the two ops that write the model's outputs come last: they run eagerly behind the captured graph and write
     # straight into the tensors a forward hands out (Plan.n_tail, OutSlot)
     fl = model.final_layer
-    p.conv(k3, fl.weight, None, fl.bias, out_f32=p.kpt_slot, want16=False, name="final_layer")
+    if head_tail:
+        p.conv_tail1x1(k2, model.predict_net[0], model.predict_net[1], fl.weight, fl.bias, p.kpt_slot, name="predict_net+final_layer")
+    else:
+        p.conv(k3, fl.weight, None, fl.bias, out_f32=p.kpt_slot, want16=False, name="final_layer")
     p.custom("bilinear2x(multi)+bilinear2x+sigmoid(limbs)", [p.multi_lo, p.limbs_lo], [p.multi_up, p.limbs], make_up)
     p.n_tail = 2
 

@@ -55,6 +55,7 @@ PLAN: Dict[str, Tuple[str, object]] = {
     "fuse_head4": ("1", ("0", "1")),          # the last module's fuse + classifier in one launch
     "fuse_classifier": ("1", ("0", "1")),
     "limbs_ride": ("1", ("0", "1")),
+    "head_tail": ("1", ("0", "1")),           # RSGNet: predict_net + final_layer as one launch (rsg_conv_tail1x1, round 5)
 }
 TRAIN: Dict[str, Tuple[str, object]] = {
     "graph": ("1", ("0", "1")),

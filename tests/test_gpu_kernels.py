@@ -1360,3 +1360,28 @@ def test_trp_tail_without_the_projection_round_trip_equals_the_tail(cfg):
     y = x @ w.cpu().t() + bias.cpu()
     want = F.group_norm(y.permute(0, 2, 1), 8, gam.cpu(), bet.cpu(), 1e-5).permute(0, 2, 1)
     assert float((outs[1].float().cpu() - want).abs().max()) < (0.06 if dt else 0.01)
+
+
+@pytest.mark.parametrize("tag", ["rsgnet_w32_256x192_coco", "rsgnet_w32_256x192_crowdpose"])
+def test_head_tail_equals_the_two_launches(tag):
+    """rsg_conv_tail1x1 (predict_net's accumulators as final_layer's MFMA operand, pose_rsgnet.py:999-1000: one launch, the
+    32-channel map between them never stored) against the two rsg_conv_igemm launches, bit for bit, through the model plan:
+    RSGNET_HIP_PLAN head_tail=0/1 on the same weights and input (17 and 14 joints); the default plan has one launch fewer."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import load_case
+    outs, names = {}, {}
+    for flag in ("0", "1"):
+        os.environ["RSGNET_HIP_PLAN"] = f"head_tail={flag}"
+        try:
+            cfg, model, sd, x, gold = load_case(tag)
+            model = model.cuda()
+            with torch.no_grad():
+                outs[flag] = [t.cpu() for t in model(torch.cat([x] * 3).cuda())[:3]]
+            names[flag] = [n for n, _ in list(model._plans.values())[0].ops]
+        finally:
+            os.environ.pop("RSGNET_HIP_PLAN", None)
+    assert "predict_net+final_layer" in names["1"] and "final_layer" in names["0"] and len(names["1"]) == len(names["0"]) - 1
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
