@@ -7,7 +7,8 @@ order).  If the dropped FMA term is a read-after-write window between those two,
 beside the model graph at the plain build's rate, the window is not the cause.  Both code objects are loaded through
 hipModuleLoad (tools/_build/trp_old_{plain,nop_before_pk_fma}.co; recipe: hipcc -S --cuda-device-only, the edit, clang -x
 assembler -target amdgcn-amd-amdhsa -mcpu=gfx950, ld.lld -shared).
-Round 5: TRP_OLD_VARIANTS=plain,war_separated,plain runs the write-after-read build of tools/war_separate.py the same way."""
+Round 5: `bash tools/build_reproducers.sh && TRP_OLD_VARIANTS=plain,war_separated,plain python tools/trp_old_projection_nop.py`
+runs the write-after-read build of tools/war_separate.py the same way (profiles/r05_trp_war_discriminator.txt)."""
 import ctypes as C
 import os
 import sys
