@@ -263,8 +263,8 @@ __global__ void __launch_bounds__(256, 3) stem_kernel(const StemArgs p) {
 // output-channel tiles x 2 pixel columns) stays on its CU and walks tiles of 4 x 16 conv2 outputs; the 36 fragments of conv2's
 // weights that its wave multiplies with stay in 144 REGISTERS for the whole launch (two workgroups per CU = two waves per
 // SIMD = 256 registers each), conv1's and the tail's 4 + 4 fragments are re-read per tile (L2 hits, requested a phase early).
-// The next tile's window of the picture is requested right behind the barrier that ends conv1 and written to LDS behind
-// conv2, so that its memory latency runs under the multiplies: two barriers per tile.  Per-pixel arithmetic, k order and
+// The next tile's window of the picture is requested in front of conv1 and written to LDS behind conv2 (the window buffer is
+// free from the barrier that ends conv1), so that its memory latency runs under both convs: two barriers per tile.  Per-pixel arithmetic, k order and
 // rounding are stem_kernel's: bit-identical (the stem tests compare through the model).
 template <class DT, bool X32>
 __global__ void __launch_bounds__(256, 2) stem_persist_kernel(const StemArgs p, const int ntiles) {
@@ -280,6 +280,9 @@ __global__ void __launch_bounds__(256, 2) stem_persist_kernel(const StemArgs p, 
     char* const sS = smem;                                 // s2d window of the current tile
     char* const sH = sS + RS * RPS;                        // conv1 window
     char* const sT = sH + R1 * RP1;                        // conv2 output tile for the tail [64 pixels][64 ch + pad]
+    // the three folded-BN biases wait in LDS: read per tile as global loads they would queue BEHIND the prefetch of the next
+    // tile's window (vmcnt retires in order) and expose its latency at the first bias a conv needs
+    float* const sB = reinterpret_cast<float*>(sT + 64 * PS1);        // [3][64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -359,6 +362,11 @@ __global__ void __launch_bounds__(256, 2) stem_persist_kernel(const StemArgs p, 
 
     int t = blockIdx.x;
     if (t >= ntiles) return;
+    if (tid < 64) {
+        sB[tid] = p.b1[tid];
+        sB[64 + tid] = p.b2[tid];
+        sB[128 + tid] = p.w3 ? p.b3[tid] : 0.f;
+    }
     request(t);
     deposit();
     __syncthreads();
@@ -366,14 +374,18 @@ __global__ void __launch_bounds__(256, 2) stem_persist_kernel(const StemArgs p, 
         int b, y2, x2;
         tile_origin(t, b, y2, x2);
         const int y1 = 2 * y2 - 1, x1 = 2 * x2 - 1;
+        const int tn = t + gridDim.x;
         // ---- conv1 on the R1 x C1 window, one 32-position group at a time ------------------------------------------------
         {
             uint4 a1[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) a1[k] = p.w1[((size_t)wm * 4 + k) * 64 + lane];
+            // the next tile's picture window: requested BEHIND conv1's own fragments (conv1 then waits for those only) and in
+            // flight under conv1 and conv2
+            if (tn < ntiles) request(tn);
             float4 bv1[4];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) bv1[r4] = *reinterpret_cast<const float4*>(p.b1 + cbase + r4 * 4);
+            for (int r4 = 0; r4 < 4; ++r4) bv1[r4] = *reinterpret_cast<const float4*>(sB + cbase + r4 * 4);
 #pragma unroll 1
             for (int g = 0; g < NT1; ++g) {
                 const int q = (wn * NT1 + g) * 32 + n;
@@ -404,8 +416,6 @@ __global__ void __launch_bounds__(256, 2) stem_persist_kernel(const StemArgs p, 
             }
         }
         __syncthreads();                                   // the conv1 window is complete; the s2d window is free
-        const int tn = t + gridDim.x;
-        if (tn < ntiles) request(tn);                      // lands under conv2
         // ---- conv2 (3x3 stride 2) from the conv1 window: this wave's 32 outputs x 32 channels ----------------------------
         const int q2 = wn * 32 + n;
         const int py = q2 / TW2, px = q2 - py * TW2;
@@ -415,7 +425,7 @@ __global__ void __launch_bounds__(256, 2) stem_persist_kernel(const StemArgs p, 
             f32x16 acc2;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.b2 + cbase + r4 * 4);
+                const float4 bv = *reinterpret_cast<const float4*>(sB + 64 + cbase + r4 * 4);
                 acc2[r4 * 4 + 0] = bv.x; acc2[r4 * 4 + 1] = bv.y; acc2[r4 * 4 + 2] = bv.z; acc2[r4 * 4 + 3] = bv.w;
             }
             constexpr int NB = 4;
@@ -452,7 +462,7 @@ __global__ void __launch_bounds__(256, 2) stem_persist_kernel(const StemArgs p, 
             f32x16 acc3;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.b3 + cbase + r4 * 4);
+                const float4 bv = *reinterpret_cast<const float4*>(sB + 128 + cbase + r4 * 4);
                 acc3[r4 * 4 + 0] = bv.x; acc3[r4 * 4 + 1] = bv.y; acc3[r4 * 4 + 2] = bv.z; acc3[r4 * 4 + 3] = bv.w;
             }
 #pragma unroll
@@ -508,7 +518,7 @@ static int stem_launch(const void* xs, const float* x_nchw_f32, const void* w1_p
         constexpr int PH = 4, PW = 16;
         a.tiles_x = ceil_div(a.W2, PW); a.tiles_y = ceil_div(a.H2, PH);
         const int ntiles = batch * a.tiles_x * a.tiles_y;
-        const int plds = (2 * PH + 2) * stem_pitch_s(2 * PW + 2, 2 * PW + 1) + (2 * PH + 1) * stem_pitch_1(2 * PW + 1, PW) + 64 * 144;
+        const int plds = (2 * PH + 2) * stem_pitch_s(2 * PW + 2, 2 * PW + 1) + (2 * PH + 1) * stem_pitch_1(2 * PW + 1, PW) + 64 * 144 + 3 * 64 * 4;
         static int cus[RSG_MAX_DEVICES], lds_set[RSG_MAX_DEVICES][4];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RSG_MAX_DEVICES) RSG_FAIL("stem_fused: no current device");
