@@ -228,11 +228,19 @@ typedef struct rsg_chain_item {
                                       rows, recomputed): 1.5x the work of a 32-row map's 8-layer chain on twice the CUs, for
                                       the chain that is a launch's critical path; rsg_basic_chain_supported_split says whether
                                       the shape allows it.  0: the library's own choice */
-    int32_t reserved;              /* 0 */
+    int32_t exchange;              /* 1 (HRNet-W32's widths, nlayers a multiple of 4): the row tiles hold a halo of nlayers / 2 rows and
+                                      trade it half way through the chain INSIDE the launch -- every tile writes the rows its
+                                      neighbours lack to `workspace` (rsg_basic_chain_exchange_bytes bytes), raises a word of
+                                      `done_flags` (3 zeroed words per workgroup, self-clearing) for each, waits for theirs --
+                                      instead of two chains of nlayers / 2 layers handing the whole map over through memory.
+                                      One staging and one store per tile; every tile counts as a waiter of the launch */
     int32_t in_ld, out_ld;         /* pixel stride (elements) of in / out; 0 = dense (= c).  Only c = 48 takes other strides
                                       (HRNet-W48 keeps its 48-channel maps in 64-channel buffers) */
 } rsg_chain_item;
 int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int32_t dtype, void* stream);
+/* rsg_chain_item.exchange: bytes of the item's workspace, 0 when the shape does not run in that form; info4 (or NULL) =
+ * {rows per tile, 1, LDS bytes, workgroups} */
+size_t rsg_basic_chain_exchange_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch, int32_t* info4);
 /* rsg_basic_chain_supported for an item with split_rows = 1: 1 and info4 = {rows per tile, 1, LDS bytes, workgroups} when
  * the map can run as two row tiles, else 0 */
 int rsg_basic_chain_supported_split(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch, int32_t* info4);

@@ -84,6 +84,13 @@ struct ChainArgs {
     const int* wait;
     int dual;     // 1: two LDS images (ping-pong): a layer reads one and writes the other, the block input stays in LDS
     int ldi, ldo; // pixel stride (elements) of in / out; == C except for the 48-channel maps of HRNet-W48 (kept in 64-channel buffers)
+    // halo exchange inside the launch (rsg_chain_item.exchange, chain16 bodies): a row-tiled chain of 2 k layers holds a k-row
+    // halo; after layer k every tile publishes the rows its neighbours lack (xbuf, written through), raises a word of xflag for
+    // each of them, waits for theirs and replaces its stale halo rows -- ONE staging and ONE final store for all 2 k layers
+    // where two k-layer chains handing over through memory stage and store twice.  All null / 0 for an ordinary chain.
+    char* xbuf;   // [workgroup][2 sides][halo rows][W][C] 16-bit
+    int* xflag;   // [workgroup][3]: word 0 = "my rows for the tile above are in xbuf", word 1 = "... for the tile below"
+    int xchg;     // the layer in front of which the exchange happens (k), 0 = none
     int debug;    // rsg_tune("chain_debug"): bit 4 = fault injection, producers never signal (the error word's test); -DRSG_DEBUG builds only: bit 2 = no block-input fetch (timing experiment, WRONG results)
 };
 
@@ -773,7 +780,7 @@ static chain_fn chain_lookup(int C, int npix, int dual) {
 // Picks (tile rows, images per workgroup) for a chain; returns 0 when the shape is supported.
 // ni_want: images per workgroup asked for in whole-image mode (0 = the process-wide default, rsg_tune)
 static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs& a, int& lds, int& nthr,
-                          bool grouped = false, int ni_want = 0, bool force_split = false) {
+                          bool grouped = false, int ni_want = 0, bool force_split = false, bool exchange = false) {
     const ChainCfg* cfg = nullptr;
     for (const ChainCfg& c : (grouped ? kChainGroupCfgs : kChainCfgs)) if (c.C == C) cfg = &c;
     if (ni_want < 1) ni_want = g_chain_max_ni;
@@ -799,7 +806,8 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     const bool split_rows = (g_chain_split_rows && C == 384 && nlayers == 2 && H >= 8 && batch * 4 <= 256 &&
                              (H / 2 + nlayers) * W <= 96) ||
                             (force_split && H >= 16 && H / 2 + nlayers < H);
-    if (!split_rows && H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
+    if (exchange && (!chain_is16(C) || nlayers < 4 || (nlayers & 3))) return 1;   // halves of whole BasicBlocks, chain16 bodies only
+    if (!exchange && !split_rows && H * W <= cap && bytes(1, H) <= CHAIN_LDS_LIMIT) {            // whole images
         int ni = cap / (H * W);
         while (ni > 1 && (bytes(ni, H) > CHAIN_LDS_LIMIT || ni > batch || ni > ni_want)) --ni;
         a.TH = H; a.R = H; a.halo = 0; a.NI = ni; a.tiles_y = 1;
@@ -812,12 +820,15 @@ static int chain_geometry(int C, int H, int W, int nlayers, int batch, ChainArgs
     }
     // row tiles with halo recompute: the fewest tiles whose window (TH rows + an L-row halo on every side
     // that is not the picture's edge) fits the pixel capacity and the LDS
+    const int halo = exchange ? nlayers / 2 : nlayers;   // with the exchange the halo is renewed half way
     for (int tiles = 2; tiles <= H; ++tiles) {
         const int TH = ceil_div(H, tiles);
-        const int R = TH + (tiles == 2 ? 1 : 2) * nlayers;
+        const int R = TH + (tiles == 2 ? 1 : 2) * halo;
         if (TH < 4) break;
         if (R > H || R * W > cap || bytes(1, R) > CHAIN_LDS_LIMIT) continue;
-        a.TH = TH; a.R = R; a.halo = nlayers; a.NI = 1; a.tiles_y = ceil_div(H, TH); a.dual = 0;
+        if (exchange && (TH < halo || H % TH)) return 1;  // a tile gives `halo` of its own rows to each neighbour
+        a.TH = TH; a.R = R; a.halo = halo; a.NI = 1; a.tiles_y = ceil_div(H, TH); a.dual = 0;
+        a.xchg = exchange ? halo : 0;
         lds = bytes(1, R);
         return 0;
     }
@@ -895,6 +906,18 @@ extern "C" size_t rsg_basic_chain_workspace_bytes(int32_t c, int32_t h, int32_t 
     return chain_ws_bytes(c, a, batch, nlayers, chain_is_wide(c) ? RSG_CHAIN_WIDE_THREADS : 512);
 }
 
+// rsg_chain_item.exchange: bytes of the item's workspace (the exchange buffer) and, through info4 = {rows per tile, 1, LDS bytes,
+// workgroups}, whether the shape runs in that form at all (0: it does not)
+extern "C" size_t rsg_basic_chain_exchange_bytes(int32_t c, int32_t h, int32_t w, int32_t nlayers, int32_t batch, int32_t* info4) {
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    int lds = 0, nthr = 0;
+    if (nlayers < 4 || nlayers > RSG_CHAIN_MAX_LAYERS || batch < 1) return 0;
+    if (chain_geometry(c, h, w, nlayers, batch, a, lds, nthr, true, 0, false, true)) return 0;
+    if (info4) { info4[0] = a.TH; info4[1] = 1; info4[2] = lds; info4[3] = batch * a.tiles_y; }
+    return (size_t)batch * a.tiles_y * 2 * a.halo * w * c * 2;
+}
+
 extern "C" int rsg_basic_chain(const void* in, void* out, const void* const* w_packed, const float* const* bias,
                                int32_t nlayers, int32_t batch, int32_t h, int32_t w, int32_t c, int32_t dtype,
                                void* workspace, void* stream) {
@@ -944,8 +967,11 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         ChainArgs& a = g.a[i];
         int lds = 0, nthr = 0;
         if (it.split_rows & ~1) RSG_FAIL("chain_group: item %d: split_rows = %d (0 or 1)", i, it.split_rows);
-        if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr, true, it.images_per_workgroup, it.split_rows != 0))
-            RSG_FAIL("chain_group: unsupported shape C=%d %dx%d L=%d", it.c, it.h, it.w, it.nlayers);
+        if (it.exchange & ~1) RSG_FAIL("chain_group: item %d: exchange = %d (0 or 1)", i, it.exchange);
+        if (it.exchange && (it.split_rows || it.wait_flags || !it.done_flags || ((uintptr_t)it.done_flags & 3)))
+            RSG_FAIL("chain_group: item %d: a chain with a halo exchange takes zeroed done_flags (3 words per workgroup) and neither wait_flags nor split_rows", i);
+        if (chain_geometry(it.c, it.h, it.w, it.nlayers, it.batch, a, lds, nthr, true, it.images_per_workgroup, it.split_rows != 0, it.exchange != 0))
+            RSG_FAIL("chain_group: unsupported shape C=%d %dx%d L=%d%s", it.c, it.h, it.w, it.nlayers, it.exchange ? " with a halo exchange" : "");
         if ((!it.workspace || ((uintptr_t)it.workspace & 15))) RSG_FAIL("chain_group: item %d needs a workspace", i);
         if ((long long)it.batch * it.h * it.w * it.c * 2 >= (1LL << 31))
             RSG_FAIL("chain_group: item %d: map of %lld bytes exceeds the 32-bit buffer offsets", i,
@@ -959,8 +985,13 @@ extern "C" int rsg_basic_chain_group(const rsg_chain_item* items, int32_t n, int
         if (chain_is_wide(it.c) != chain_is_wide(items[0].c))
             RSG_FAIL("chain_group: item %d: the 48/96/192/384-channel chains (768 threads) cannot share a launch with the others", i);
         a.ws = (uint4*)it.workspace;
-        a.done = (int*)it.done_flags;
+        a.done = it.exchange ? nullptr : (int*)it.done_flags;
         a.wait = (const int*)it.wait_flags;
+        if (it.exchange) {                     // (workspace: rsg_basic_chain_exchange_bytes; every tile both signals and waits)
+            a.xbuf = (char*)it.workspace;
+            a.xflag = (int*)it.done_flags;
+            waiters += it.batch * a.tiles_y;
+        }
         a.debug = g_chain_debug;
         if (it.wait_flags) {
             // the producer comes EARLIER in the grid (in-order dispatch then makes the wait short; correctness does

@@ -365,8 +365,59 @@ __device__ __forceinline__ void chain16_body(const ChainArgs& p, const int block
         chain16_barrier();                               // the new image is complete
         RSG_STAMP(6 + 4 * l);
     };
+    // ---- halo exchange (ChainArgs::xchg, in-place images only): in front of layer `xchg` the tile's halo rows are as stale as a
+    // halo of xchg rows gets (one row per layer).  Every tile copies the rows its neighbours lack -- its own first / last
+    // `halo` output rows, which ARE valid -- from the LDS image to xbuf (written through), raises the neighbour's word, waits
+    // for the neighbours' words and copies their rows over its halo.  The poll is bounded like the hand-off's (a tile whose
+    // neighbour never shows up goes on with stale rows and the error word counts it); the words clear themselves.
+    auto exchange = [&]() {
+        const int XR = p.halo, rowc = W * CPP, chunks = XR * rowc;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(p.xbuf, 0, p.B * p.tiles_y * 2 * chunks * 16, 0x00020000);
+        const int first = block_id - tile;                // workgroup of the picture's tile 0
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {            // 0: for the tile above, 1: for the tile below
+            const int nb = tile + (side ? 1 : -1);
+            if (nb < 0 || nb >= p.tiles_y) continue;      // (uniform)
+            const int r0 = (side ? min((tile + 1) * p.TH, p.H) - XR : tile * p.TH) - y_first;
+            for (int i = tid; i < chunks; i += NTHR) {
+                const int r = i / rowc, c = i - r * rowc;
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + (r0 + r + 1) * RP + PS + (c / CPP) * PS + (c % CPP) * 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrs, ((block_id * 2 + side) * chunks + i) * 16, 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left the CU
+        __syncthreads();
+        if (tid < 2) {
+            const int nb = tile + (tid ? 1 : -1);
+            if (nb >= 0 && nb < p.tiles_y) {
+                if (!(p.debug & 4)) __hip_atomic_store(p.xflag + block_id * 3 + tid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the tile above raises ITS word 1 (rows for the tile below it), the tile below its word 0
+                int* f = p.xflag + (first + nb) * 3 + (tid ? 0 : 1);
+                int spin = 0;
+                for (; spin < (1 << 20) && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+                    __builtin_amdgcn_s_sleep(8);
+                if (spin == (1 << 20)) atomicAdd(&g_chain_handoff_timeouts, 1u);
+                else __hip_atomic_store(f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {            // rows FROM the tile above (0) / below (1): that tile's other side
+            const int nb = tile + (side ? 1 : -1);
+            if (nb < 0 || nb >= p.tiles_y) continue;
+            const int r0 = (side ? (tile + 1) * p.TH : tile * p.TH - XR) - y_first;
+            for (int i = tid; i < chunks; i += NTHR) {
+                const int r = i / rowc, c = i - r * rowc;
+                const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                    xrs, (((first + nb) * 2 + (side ? 0 : 1)) * chunks + i) * 16, 0, 16));
+                *reinterpret_cast<uint4*>(smem + (r0 + r + 1) * RP + PS + (c / CPP) * PS + (c % CPP) * 16) = v;
+            }
+        }
+        __syncthreads();
+    };
 #pragma unroll 1
     for (int l = 0; l < p.nlayers; l += 2) {             // one BasicBlock per iteration
+        if (!DUAL && p.xchg && l == p.xchg) exchange();
         uint4 xr[NG][NX];
         layer(l, std::false_type{}, xr);
         layer(l + 1, std::true_type{}, xr);

@@ -61,7 +61,7 @@ class ChainItem(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("w_packed", C.POINTER(C.c_void_p)),
                 ("bias", C.POINTER(C.c_void_p)), ("nlayers", C.c_int32), ("batch", C.c_int32), ("h", C.c_int32),
                 ("w", C.c_int32), ("c", C.c_int32), ("images_per_workgroup", C.c_int32), ("workspace", C.c_void_p),
-                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("split_rows", C.c_int32), ("reserved", C.c_int32),
+                ("done_flags", C.c_void_p), ("wait_flags", C.c_void_p), ("split_rows", C.c_int32), ("exchange", C.c_int32),
                 ("in_ld", C.c_int32), ("out_ld", C.c_int32)]
 
 
@@ -120,6 +120,7 @@ SYMBOLS = {
     "rsg_basic_chain": (C.c_int, [_vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "rsg_basic_chain_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "rsg_basic_chain_group": (C.c_int, [C.POINTER(ChainItem), _i, _i, _vp]),
+    "rsg_basic_chain_exchange_bytes": (C.c_size_t, [_i, _i, _i, _i, _i, C.POINTER(C.c_int32)]),
     "rsg_chain_handoff_timeouts": (C.c_int, [C.POINTER(C.c_uint32)]),
     "rsg_chain_handoff_timeouts_async": (C.c_int, [_vp, _vp]),
     "rsg_basic_chain_handoff_max_waiters": (C.c_int, []),

@@ -422,11 +422,21 @@ class Plan:
             layers = [(allw[k * n0:(k + 1) * n0], b) for k, (_, b) in enumerate(layers)]
             out = self.new(x.H, x.W, x.C, name=name)
             split = bool(item[2]) if len(item) > 2 else False
+            exch = bool(item[3]) if len(item) > 3 else False     # halo exchange inside the launch (rsg_chain_item.exchange)
             cc = blocks[0].conv1.in_channels             # 48 of a 64-channel buffer for HRNet-W48's first branch
             # position k of every grouped launch shares one scratch buffer per size; it is named among the op's
             # writes, so every scheduler (lanes, explicit graph) keeps the sharers in order
-            ws = self._chain_workspace(len(subs), x, len(layers), cc)
-            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, c=cc, split=split))
+            if exch:
+                need = int(self.lib.rsg_basic_chain_exchange_bytes(cc, x.H, x.W, len(layers), self.batch, None))
+                if not need:
+                    raise ValueError(f"{name}: a {cc}-channel {x.H}x{x.W} chain of {len(layers)} layers cannot trade its halo inside the launch")
+                pool = self.__dict__.setdefault("_chain_ws", {})
+                if ("x", len(subs), need) not in pool:
+                    pool[("x", len(subs), need)] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                ws = pool[("x", len(subs), need)]
+            else:
+                ws = self._chain_workspace(len(subs), x, len(layers), cc)
+            subs.append(dict(x=x, out=out, layers=layers, after=after, ws=ws, c=cc, split=split, exch=exch))
             outs.append(out)
             self.flops += 2 * self.batch * x.H * x.W * cc * cc * 9 * len(layers)
         self._record(dict(kind="chain_group", subs=subs, name=name),
@@ -772,6 +782,13 @@ class Plan:
             it.nlayers, it.batch, it.h, it.w, it.c = n, self.batch, x.H, x.W, cc
             it.workspace = d["ws"].data_ptr() if d["ws"] is not None else None
             it.split_rows = 1 if d.get("split") else 0
+            if d.get("exch"):
+                info = (C.c_int32 * 4)()
+                self.lib.rsg_basic_chain_exchange_bytes(cc, x.H, x.W, n, self.batch, info)
+                flags = torch.zeros(3 * info[3], dtype=torch.int32, device=self.device)     # zeroed once, self-clearing
+                self._keep.append(flags)
+                self._ho_flags.append(flags)          # ... and again by _handoff_failed after a poll that gave up
+                it.exchange, it.done_flags = 1, flags.data_ptr()
             log.append((cc, x.H, x.W, n))
         for k, d in enumerate(subs):
             if d.get("after") is not None:
@@ -795,8 +812,11 @@ class Plan:
             info = (C.c_int32 * 4)()
             blocks = []
             for it in items:
-                (self.lib.rsg_basic_chain_supported_split if it.split_rows else self.lib.rsg_basic_chain_supported)(
-                    it.c, it.h, it.w, it.nlayers, it.batch, info)
+                if it.exchange:
+                    self.lib.rsg_basic_chain_exchange_bytes(it.c, it.h, it.w, it.nlayers, it.batch, info)
+                else:
+                    (self.lib.rsg_basic_chain_supported_split if it.split_rows else self.lib.rsg_basic_chain_supported)(
+                        it.c, it.h, it.w, it.nlayers, it.batch, info)
                 blocks.append((info[3], info[0] == it.h))
             total = sum(b for b, _ in blocks)
             for k in sorted(range(len(subs)), key=lambda k: items[k].h * items[k].w):
@@ -1259,12 +1279,25 @@ class _BackboneMixin:
                         and self.batch * 2 <= 256 and not self.throughput and \
                         bool(self.lib.rsg_basic_chain_supported_split(64, xs[b].H, xs[b].W, 2 * len(blocks), self.batch, info))
                     items.append((xs[b], blocks, sp))
+            # A row-tiled branch as ONE chain whose tiles trade their halo rows half way, inside the launch
+            # (rsg_chain_item.exchange): one staging and one store per tile instead of two -- ~9 % less CU-time for the 64x48x32
+            # branch -- but twice as long workgroups (a longer launch when it runs alone).  RSGNET_HIP_PLAN chain_exchange =
+            # auto (default): on for the plans of side streams (throughput, like chain_pack), off for the default stream's.
+            xmode = sw.plan("chain_exchange")
+            def xch(b):
+                n = 2 * len(mod.branches[b])
+                return (xmode == "1" or (xmode == "auto" and self.throughput)) and n % 4 == 0 and \
+                    2 * steps[b] == len(mod.branches[b]) and \
+                    bool(self.lib.rsg_basic_chain_exchange_bytes(chan[b], xs[b].H, xs[b].W, n, self.batch, None))
             for b in order:                      # first halves, then second halves: a producer precedes its consumer
                 if not whole(b):
                     where[b] = len(items)
-                    items.append((xs[b], list(mod.branches[b])[:steps[b]]))
+                    if xch(b):
+                        items.append((xs[b], list(mod.branches[b]), False, True))
+                    else:
+                        items.append((xs[b], list(mod.branches[b])[:steps[b]]))
             for b in order:
-                if not whole(b):
+                if not whole(b) and not xch(b):
                     first, where[b] = where[b], len(items)
                     items.append((first, list(mod.branches[b])[steps[b]:]))
             outs = self.chain_group(items, f"{name}.chains")

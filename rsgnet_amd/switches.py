@@ -36,6 +36,7 @@ PLAN: Dict[str, Tuple[str, object]] = {
     "chain_slices": ("2", (1, 8)),
     "rowtile_blocks": ("2", (1, 4)),
     "chain_pack": ("auto", ("auto", "0", "1")),   # two images per workgroup in over-subscribed chain launches (side-stream plans)
+    "chain_exchange": ("auto", ("auto", "0", "1")),   # row-tiled chains trade their halo inside the launch (side-stream plans, round 5)
     "chain_split64": ("0", (0, 2)),           # rsg_chain_item.split_rows for the 32x24x64 chain (r05: neutral / slower)
     "zip_branches": ("1", ("0", "1")),
     "stem": ("1", ("0", "1")),                # conv1 + conv2 in one launch

@@ -455,6 +455,100 @@ def test_chain_group_handoff_inside_one_launch():
     assert lib.rsg_basic_chain_group(items, 3, 0, _stream()) != 0
 
 
+def test_chain_group_halo_exchange_inside_one_launch():
+    """A row-tiled 8-layer chain whose tiles trade their halo rows after layer 4 INSIDE the launch (rsg_chain_item.exchange:
+    one staging and one store per tile, a 4-row halo instead of two 4-layer chains' staging + store each) gives bit for bit
+    what the two 4-layer launches give, next to a long whole-image chain; every flag word is clear again afterwards; a
+    producer that never raises its flag (debug bit 4) ends in a counted time-out, not a hang."""
+    lib = hip.lib()
+    B, L = 64, 4
+    g = torch.Generator().manual_seed(6)
+    x32 = torch.randn(B, 64, 48, 32, generator=g).half().to(DEV)
+    x64 = torch.randn(B, 32, 24, 64, generator=g).half().to(DEV)
+    k32, w32, b32 = _chain_layers(lib, 32, 2 * L, 1)
+    k64, w64, b64 = _chain_layers(lib, 64, 2 * L, 3)
+
+    def ws(Cc, H, W, n):
+        return torch.empty(lib.rsg_basic_chain_workspace_bytes(Cc, H, W, n, B), dtype=torch.uint8, device=DEV)
+
+    def arr(v):
+        return (C.c_void_p * len(v))(*v)
+
+    mid, ref32, ref64 = torch.empty_like(x32), torch.empty_like(x32), torch.empty_like(x64)
+    wsa, wsc = ws(32, 64, 48, L), ws(64, 32, 24, 2 * L)
+    hip.check(lib.rsg_basic_chain(x32.data_ptr(), mid.data_ptr(), arr(w32[:L]), arr(b32[:L]), L, B, 64, 48, 32, 0, wsa.data_ptr(), _stream()))
+    hip.check(lib.rsg_basic_chain(mid.data_ptr(), ref32.data_ptr(), arr(w32[L:]), arr(b32[L:]), L, B, 64, 48, 32, 0, wsa.data_ptr(), _stream()))
+    hip.check(lib.rsg_basic_chain(x64.data_ptr(), ref64.data_ptr(), arr(w64), arr(b64), 2 * L, B, 32, 24, 64, 0, wsc.data_ptr(), _stream()))
+    torch.cuda.synchronize()
+
+    info = (C.c_int32 * 4)()
+    need = lib.rsg_basic_chain_exchange_bytes(32, 64, 48, 2 * L, B, info)
+    assert need > 0 and info[0] == 32 and info[3] == 2 * B                  # two 32-row tiles per image, 4-row halo
+    assert lib.rsg_basic_chain_exchange_bytes(32, 64, 48, 2 * L + 2, B, None) == 0      # layers in fours (the trade is half way)
+    xbuf = torch.empty(need, dtype=torch.uint8, device=DEV)
+    flags = torch.zeros(info[3] * 3, dtype=torch.int32, device=DEV)
+    items = (hip.ChainItem * 2)()
+    outs = [torch.empty_like(x64), torch.empty_like(x32)]
+    keep = []
+    for it, (xin, Cc, H, W, wp, bp), out in zip(items, [(x64, 64, 32, 24, w64, b64), (x32, 32, 64, 48, w32, b32)], outs):
+        wa, ba = arr(wp), arr(bp)
+        keep += [wa, ba]
+        it.inp, it.out = xin.data_ptr(), out.data_ptr()
+        it.w_packed, it.bias = C.cast(wa, C.POINTER(C.c_void_p)), C.cast(ba, C.POINTER(C.c_void_p))
+        it.nlayers, it.batch, it.h, it.w, it.c = 2 * L, B, H, W, Cc
+    items[0].workspace = wsc.data_ptr()
+    items[1].workspace, items[1].done_flags, items[1].exchange = xbuf.data_ptr(), flags.data_ptr(), 1
+    for rep in range(8):
+        for o in outs:
+            o.fill_(float("nan"))
+        xbuf.fill_(0xff)
+        hip.check(lib.rsg_basic_chain_group(items, 2, 0, _stream()), "chain_group")
+        torch.cuda.synchronize()
+        assert not flags.any()                               # self-clearing
+        assert torch.equal(outs[0], ref64), rep
+        assert torch.equal(outs[1], ref32), rep
+    n0, n1 = C.c_uint32(0), C.c_uint32(0)
+    hip.check(lib.rsg_chain_handoff_timeouts(C.byref(n0)))
+    # fault injection: nobody raises a flag -> every poll gives up, the launch still drains, the error is counted
+    hip.check(lib.rsg_tune(b"chain_debug", 4))
+    try:
+        hip.check(lib.rsg_basic_chain_group(items, 2, 0, _stream()), "chain_group")
+        torch.cuda.synchronize()
+    finally:
+        hip.check(lib.rsg_tune(b"chain_debug", 0))
+    hip.check(lib.rsg_chain_handoff_timeouts(C.byref(n1)))
+    assert n1.value > n0.value
+    flags.zero_()
+    hip.check(lib.rsg_basic_chain_group(items, 2, 0, _stream()), "chain_group")        # ... and the next launch is right again
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], ref32) and not flags.any()
+    # an exchange item needs its flags, and no hand-off of the other kind
+    items[1].done_flags = None
+    assert lib.rsg_basic_chain_group(items, 2, 0, _stream()) != 0
+
+
+@pytest.mark.parametrize("tag", ["hrnet_w32_256x192"])
+def test_chain_exchange_plan_equals_the_handoff_plan(tag):
+    """RSGNET_HIP_PLAN chain_exchange=0/1 on the same weights and input: the plan with the in-launch halo trade (default for the
+    plans of side streams) gives the heat maps of the plan with the two-chain hand-off, bit for bit."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from util import load_case
+    outs, names = {}, {}
+    for flag in ("0", "1"):
+        os.environ["RSGNET_HIP_PLAN"] = f"chain_exchange={flag}"
+        try:
+            cfg, model, sd, x, gold = load_case(tag)
+            model = model.cuda()
+            with torch.no_grad():
+                outs[flag] = model(torch.cat([x] * 8).cuda()).cpu()
+                outs[flag + "b"] = model(torch.cat([x] * 8).cuda()).cpu()          # flags clean for the second replay
+        finally:
+            os.environ.pop("RSGNET_HIP_PLAN", None)
+    assert torch.equal(outs["0"], outs["1"]) and torch.equal(outs["1"], outs["1b"])
+
+
 def test_chain_group_w48_widths_one_launch():
     """One BasicBlock of every HRNet-W48 stage-4 branch (48 / 96 / 192 / 384 channels at 96x72 ... 12x9) in ONE grouped
     launch of the 12-wave kernel gives bit for bit what the separate launches give; the 48-channel map lives in a
