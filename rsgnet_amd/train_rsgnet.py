@@ -32,6 +32,18 @@ import torch.nn.functional as F
 from . import switches as sw
 
 
+def _loc_clue(m) -> torch.Tensor:
+    """loc_conv(loc_features) (pose_rsgnet.py:693-697,979-980) with its 1x1 conv over the four constant planes written as a
+    broadcast product and a fixed-order sum: the framework's weight-gradient kernel for this 4-channel convolution
+    accumulates atomically, so its low bits differed between identical steps (one parameter of 1 830, 7e-12 of 3e-5: found by
+    test_rsgnet_training_call_of_the_reference_reaches_the_hip_trp) -- the training step is bit-reproducible, this included."""
+    conv, rest = m.loc_conv[0], m.loc_conv[1:]
+    y = (conv.weight * m.loc_features).sum(1).unsqueeze(0)          # [C0,4,1,1] * [1,4,h,w] -> [1,C0,h,w]
+    if conv.bias is not None:
+        y = y + conv.bias.reshape(1, -1, 1, 1)
+    return rest(y)
+
+
 def kt_machine_forward(kt, weight: torch.Tensor) -> torch.Tensor:
     """KTMachine.forward (pose_rsgnet.py:576-600): the limb classifier from the joint classifier's weights.  On the GPU: the
     SGM graph-conv kernel in both directions (train_ops.SgmGraphConv); the expression below is its CPU statement (host-side
@@ -178,7 +190,7 @@ def head_forward(model, feat16: torch.Tensor, relation_target: Optional[torch.Te
     multi = conv1x1_out(m, "multi_final_layer", feat16, m.multi_final_layer.weight, m.multi_final_layer.bias)   # :961
     vis = conv_bn_relu(m, "vis_conv", feat16, m.vis_conv[0].weight, m.vis_conv[1])                            # :965
     typ = conv_bn_relu(m, "type_conv", nchw_to_nhwc16(multi), type_conv_weight(m), m.type_conv[1])           # :971-977
-    loc = nchw_to_nhwc16(m.loc_conv(m.loc_features)).expand(B, -1, -1, -1)                                     # :979-980
+    loc = nchw_to_nhwc16(_loc_clue(m)).expand(B, -1, -1, -1)                                                  # :979-980
     f = conv_bn_relu(m, "contact_conv", torch.cat((vis, typ, loc), dim=3), m.contact_conv[0].weight, m.contact_conv[1])
     f = conv_bn_relu(m, "predict_contact_net", f, m.predict_contact_net[0].weight, m.predict_contact_net[1])   # :982-984
     rh = m.relation_head
