@@ -1,5 +1,5 @@
 #!/bin/bash
-# Soak (round 4: the new chain bodies; round 5, TAG=r05: band launches, persistent stem, two-wave conv_dual, piece-major TRP staging): one-stream replays bit-identical to the first, and forwards overlapping on two streams
+# Soak (round 4: the new chain bodies; round 5, TAG=r05: band launches, persistent stem, two-wave conv_dual, piece-major TRP staging, the halo exchange inside the chain launches of side-stream plans): one-stream replays bit-identical to the first, and forwards overlapping on two streams
 # bit-identical to the one-stream result (the regime the headline value is measured in).
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1 || exit 1
