@@ -24,6 +24,17 @@ SHAPES = [  # name, cin, cout, H, W (input), k, stride, residual
 ]
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "head":      # the 3x3 convs of RSGNet-W32's head (pose_rsgnet.py:666-750)
+    SHAPES = [
+        ("contact_conv 96->96 3x3", 96, 96, 64, 48, 3, 1, False),
+        ("predict_contact_net 96->32 3x3", 96, 32, 64, 48, 3, 1, False),
+        ("kpt_net 64->32 3x3", 64, 32, 64, 48, 3, 1, False),
+        ("vis_conv / limbs_net 32->32 3x3", 32, 32, 64, 48, 3, 1, False),
+        ("type_conv(folded) 32->32 3x3 (17 of 32 in)", 32, 32, 64, 48, 3, 1, False),
+        ("predict_net 32->32 3x3 128x96", 32, 32, 128, 96, 3, 1, False),
+    ]
+
+
 def bench(desc, reps=5):
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
