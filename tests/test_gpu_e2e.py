@@ -1,4 +1,5 @@
 """End-to-end parity on the GPU: the drop-in models against the reference-captured goldens."""
+import ctypes
 import os
 
 import numpy as np
@@ -295,6 +296,20 @@ def test_other_input_sizes_against_the_oracle(width, wh, batch):
     ref = po.hrnet_forward(sd, cfg, x)
     e = _stats(f"W{width} {wh[1]}x{wh[0]} heatmaps vs oracle", y, ref.numpy())
     assert torch.isfinite(y).all() and e < REL_TOL * float(ref.std())
+    # the plan of a side stream (two images per workgroup in over-subscribed chain launches; the row-tiled 32-channel branch
+    # as one chain whose tiles trade their halo inside the launch -- at 384x288 EIGHT tiles per image, the inner ones with
+    # two neighbours) gives the same bits
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad(), torch.cuda.stream(side):
+        y2 = model(x.cuda())
+        y3 = model(x.cuda())
+    side.synchronize()
+    assert torch.equal(y2.cpu(), y) and torch.equal(y3.cpu(), y)
+    if width == 32:
+        names = [n for p_ in model._plans.values() if p_.throughput for n, _ in p_.ops]
+        assert names and any(it.exchange for p_ in model._plans.values() if p_.throughput for arr in p_._keep
+                             if isinstance(arr, ctypes.Array) and arr._type_.__name__ == "ChainItem" for it in arr)
 
 
 @pytest.mark.parametrize("tag", ["rsgnet_w32_256x192_coco", "rsgnet_w32_256x192_crowdpose",
